@@ -1,0 +1,55 @@
+// Shared helpers for the gfx950 kernels of libctunet_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "ctunet_hip.h"
+
+#define CTU_ABI_VERSION 1
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+void ctu_set_error(const char* fmt, ...);
+
+#define CTU_REQUIRE(cond, ...)                 \
+    do {                                       \
+        if (!(cond)) {                         \
+            ctu_set_error(__VA_ARGS__);        \
+            return CTU_EINVAL;                 \
+        }                                      \
+    } while (0)
+
+#define CTU_CHECK_LAUNCH(name)                                                     \
+    do {                                                                           \
+        hipError_t e_ = hipGetLastError();                                         \
+        if (e_ != hipSuccess) {                                                    \
+            ctu_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));   \
+            return CTU_ELAUNCH;                                                    \
+        }                                                                          \
+    } while (0)
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// lazy-BN input transform on 4 consecutive channels
+__device__ __forceinline__ float4 xform4(float4 v, float4 sc, float4 sh, int relu) {
+    v.x = fmaf(v.x, sc.x, sh.x);
+    v.y = fmaf(v.y, sc.y, sh.y);
+    v.z = fmaf(v.z, sc.z, sh.z);
+    v.w = fmaf(v.w, sc.w, sh.w);
+    if (relu) {
+        v.x = fmaxf(v.x, 0.f);
+        v.y = fmaxf(v.y, 0.f);
+        v.z = fmaxf(v.z, 0.f);
+        v.w = fmaxf(v.w, 0.f);
+    }
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}

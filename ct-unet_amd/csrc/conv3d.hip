@@ -1,0 +1,513 @@
+// 3D convolution (k=3 / k=5, stride 1, "same" zero padding) for gfx950 as implicit GEMM on
+// v_mfma_f32_16x16x4_f32: forward / data-gradient kernel, weight-gradient kernel, packing.
+//
+// Replaces nn.Conv3d at ctunet/pytorch/models.py:26,29,38,41,71,76 (k3, no bias) and
+// :403,407,430,434,482-488 (k5, bias), plus their autograd backward.
+//
+// Data layout (DESIGN.md "HBM layout"): activations are channels-last fp32 with a channel
+// stride, channel counts padded to 8.  GEMM view: M = output voxels, N = output channels,
+// K = taps x input channels.  A block owns a TDxTHxTW box of output voxels (16 M-tiles of 16
+// voxels, 4 waves x MT tiles), stages the haloed input box for ONE 8-channel chunk into LDS
+// (12 floats per voxel: 8 + 4 pad -> conflict-free ds_read_b64 of 16 consecutive voxels) with
+// the lazy-BN transform applied on the way in, stages that chunk's packed weights, and walks
+// the taps with compile-time LDS offsets.  One ds_read_b64 per lane feeds two MFMAs: lane
+// (m, kq) holds channels {2kq, 2kq+1}; MFMA #0 contracts channels {0,2,4,6}, #1 {1,3,5,7}.
+#include "common.h"
+
+namespace {
+
+struct ConvP {
+    const float* in;
+    const float* in_scale;
+    const float* in_shift;
+    const float* wp;
+    const float* bias;
+    float* out;
+    float* stats;
+    int in_cs, rin_p, in_relu, out_cs, nout_p;
+    int N, D, H, W;
+    int tiles_d, tiles_h, tiles_w;
+};
+
+template <int KS>
+struct Taps {
+    static constexpr int TAPS = KS * KS * KS;
+    static constexpr int STAPS = (KS == 3) ? 27 : KS * KS;   // taps whose weights sit in LDS at once
+    static constexpr int NSTAGE = TAPS / STAPS;
+};
+
+__host__ __device__ inline void pick_tile(int W, int* td, int* th, int* tw) {
+    if (W >= 16) { *td = 4; *th = 4; *tw = 16; }
+    else if (W >= 8) { *td = 4; *th = 8; *tw = 8; }
+    else { *td = 4; *th = 4; *tw = 4; }
+}
+
+constexpr int VS = 12;   // LDS floats per halo voxel (8 channels + 4 pad)
+
+template <int KS, int NT, int TD, int TH, int TW>
+__global__ __launch_bounds__(256) void conv3d_fwd_kernel(ConvP p) {
+    constexpr int PAD = (KS - 1) / 2;
+    constexpr int HD = TD + KS - 1, HH = TH + KS - 1, HW = TW + KS - 1;
+    constexpr int HV = HD * HH * HW;
+    constexpr int NVOX = TD * TH * TW;
+    constexpr int NMT = NVOX / 16;
+    static_assert(NMT % 4 == 0, "block tile must hold a multiple of 4 M-tiles");
+    constexpr int MT = NMT / 4;
+    constexpr int STAPS = Taps<KS>::STAPS, NSTAGE = Taps<KS>::NSTAGE;
+    constexpr int WFL = STAPS * NT * 128;
+    constexpr int AITEMS = HV * 2;
+    constexpr int AITER = (AITEMS + 255) / 256;
+
+    __shared__ __attribute__((aligned(16))) float sA[HV * VS];
+    __shared__ __attribute__((aligned(16))) float sW[WFL];
+    __shared__ float sRed[4 * NT * 16 * 2];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, kq = lane >> 4;
+
+    int bx = blockIdx.x;
+    const int tx = bx % p.tiles_w; bx /= p.tiles_w;
+    const int ty = bx % p.tiles_h; bx /= p.tiles_h;
+    const int tz = bx % p.tiles_d; bx /= p.tiles_d;
+    const int n_img = bx;
+    const int d0 = tz * TD, h0 = ty * TH, w0 = tx * TW;
+    const int by = blockIdx.y;
+
+    // per-lane LDS base (floats) of each of this wave's M-tiles
+    int abase[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int vt = (wave * MT + mt) * 16 + m;
+        const int tw = vt % TW, th = (vt / TW) % TH, td = vt / (TW * TH);
+        abase[mt] = ((td * HH + th) * HW + tw) * VS + kq * 2;
+    }
+    const int bbase = kq * 32 + m * 2;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nchunk = p.rin_p >> 3;
+    const int half = tid & 1;
+    const bool has_xf = p.in_scale != nullptr;
+    const float* wblk = p.wp + (size_t)by * nchunk * NSTAGE * WFL;
+
+    for (int c = 0; c < nchunk; ++c) {
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (has_xf) {
+            sc = *reinterpret_cast<const float4*>(p.in_scale + c * 8 + half * 4);
+            sh = *reinterpret_cast<const float4*>(p.in_shift + c * 8 + half * 4);
+        }
+        __syncthreads();   // previous chunk's readers are done with sA / sW
+        // ---- stage the haloed input box, 8 channels of chunk c
+        float4 vals[AITER];
+#pragma unroll
+        for (int it = 0; it < AITER; ++it) {
+            const int i = tid + it * 256;
+            const int v = i >> 1;
+            const int pw = v % HW, t2 = v / HW, ph = t2 % HH, pd = t2 / HH;
+            const int gd = d0 + pd - PAD, gh = h0 + ph - PAD, gw = w0 + pw - PAD;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < AITEMS && (unsigned)gd < (unsigned)p.D && (unsigned)gh < (unsigned)p.H &&
+                (unsigned)gw < (unsigned)p.W) {
+                const size_t vox = (((size_t)n_img * p.D + gd) * p.H + gh) * p.W + gw;
+                val = *reinterpret_cast<const float4*>(p.in + vox * p.in_cs + c * 8 + half * 4);
+                if (has_xf) val = xform4(val, sc, sh, p.in_relu);
+            }
+            vals[it] = val;
+        }
+#pragma unroll
+        for (int it = 0; it < AITER; ++it) {
+            const int i = tid + it * 256;
+            if (i < AITEMS) *reinterpret_cast<float4*>(&sA[(i >> 1) * VS + half * 4]) = vals[it];
+        }
+        for (int s = 0; s < NSTAGE; ++s) {
+            if (s > 0) __syncthreads();
+            const float* wsrc = wblk + ((size_t)c * NSTAGE + s) * WFL;
+            for (int i = tid * 4; i < WFL; i += 1024)
+                *reinterpret_cast<float4*>(&sW[i]) = *reinterpret_cast<const float4*>(wsrc + i);
+            __syncthreads();
+#pragma unroll
+            for (int ts = 0; ts < STAPS; ++ts) {
+                // tap (kd,kh,kw): with NSTAGE > 1 the stage index is kd
+                const int kd = (NSTAGE == 1) ? ts / (KS * KS) : s;
+                const int kh = (NSTAGE == 1) ? (ts / KS) % KS : ts / KS;
+                const int kw = ts % KS;
+                const int toff = ((kd * HH + kh) * HW + kw) * VS;
+                float2 b[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    b[nt] = *reinterpret_cast<const float2*>(&sW[(ts * NT + nt) * 128 + bbase]);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const float2 a = *reinterpret_cast<const float2*>(&sA[abase[mt] + toff]);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[nt].x, acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[nt].y, acc[mt][nt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: bias, store, BatchNorm partial statistics
+    const int q = kq;
+    float s1[NT], s2[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { s1[nt] = 0.f; s2[nt] = 0.f; }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int co = (by * NT + nt) * 16 + m;
+        const bool cok = co < p.nout_p;
+        const float bv = (cok && p.bias) ? p.bias[co] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int vt = (wave * MT + mt) * 16 + q * 4 + r;
+                const int tw = vt % TW, th = (vt / TW) % TH, td = vt / (TW * TH);
+                const int gd = d0 + td, gh = h0 + th, gw = w0 + tw;
+                if (cok && gd < p.D && gh < p.H && gw < p.W) {
+                    const float v = acc[mt][nt][r] + bv;
+                    const size_t vox = (((size_t)n_img * p.D + gd) * p.H + gh) * p.W + gw;
+                    p.out[vox * p.out_cs + co] = v;
+                    s1[nt] += v;
+                    s2[nt] += v * v;
+                }
+            }
+        }
+    }
+    if (p.stats) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            float a = s1[nt], b = s2[nt];
+            a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
+            b += __shfl_xor(b, 16); b += __shfl_xor(b, 32);
+            if (q == 0) {
+                sRed[((wave * NT + nt) * 16 + m) * 2 + 0] = a;
+                sRed[((wave * NT + nt) * 16 + m) * 2 + 1] = b;
+            }
+        }
+        __syncthreads();
+        if (tid < NT * 16) {
+            const int co = by * NT * 16 + tid;
+            if (co < p.nout_p) {
+                float a = 0.f, b = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    a += sRed[((w * NT) * 16 + tid) * 2 + 0];
+                    b += sRed[((w * NT) * 16 + tid) * 2 + 1];
+                }
+                float* row = p.stats + (size_t)blockIdx.x * 2 * p.nout_p;
+                row[co] = a;
+                row[p.nout_p + co] = b;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ packing
+// wp index for (y-block, chunk c, stage s, tap-in-stage ts, nt, kq, n, j)
+template <int KS>
+__device__ __forceinline__ size_t wp_index(int rp, int np, int t, int nchunk, int NT) {
+    constexpr int STAPS = Taps<KS>::STAPS, NSTAGE = Taps<KS>::NSTAGE;
+    const int c = rp >> 3, kq = (rp & 7) >> 1, j = rp & 1;
+    const int yb = np / (16 * NT), nt = (np / 16) % NT, n = np & 15;
+    const int s = t / STAPS, ts = t % STAPS;
+    return ((((size_t)(yb * nchunk + c) * NSTAGE + s) * STAPS + ts) * NT + nt) * 128 + kq * 32 + n * 2 + j;
+}
+
+template <int KS>
+__global__ void pack_conv_w_kernel(const float* __restrict__ w, float* __restrict__ wp, int Co, int Ci,
+                                   const int32_t* __restrict__ imap, int rin_p, int NT, int mode) {
+    constexpr int TAPS = Taps<KS>::TAPS;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Co * Ci * TAPS) return;
+    const int t = idx % TAPS, ci = (idx / TAPS) % Ci, co = idx / (TAPS * Ci);
+    const int cip = imap ? imap[ci] : ci;
+    int rp, np, tt;
+    if (mode == 0) { rp = cip; np = co; tt = t; }
+    else { rp = co; np = cip; tt = TAPS - 1 - t; }
+    wp[wp_index<KS>(rp, np, tt, rin_p >> 3, NT)] = w[idx];
+}
+
+inline int pick_nt(int nout_p) {
+    const int n16 = (nout_p + 15) / 16;
+    return n16 == 1 ? 1 : (n16 == 2 ? 2 : 4);
+}
+
+// ------------------------------------------------------------------ weight gradient
+struct WgP {
+    const float* in;
+    const float* in_scale;
+    const float* in_shift;
+    const float* g;
+    float* ws;
+    int in_cs, cin_p, in_relu, g_cs, cout_p;
+    int N, D, H, W;
+    int tiles_d, tiles_h, tiles_w, ntiles;
+    int n_ci_t, n_co_t;
+};
+
+// One block: one (ci-tile of 16, co-tile of 16) pair, KDS kd-planes of taps, a strided set of
+// spatial tiles.  MFMA view: M = 16 input channels, N = 16 output channels, K = voxels.
+template <int KS, int KDS, int TD, int TH, int TW>
+__global__ __launch_bounds__(256) void conv3d_wgrad_kernel(WgP p) {
+    constexpr int PAD = (KS - 1) / 2;
+    constexpr int HD = TD + KDS - 1, HH = TH + KS - 1, HW = TW + KS - 1;
+    constexpr int HV = HD * HH * HW;
+    constexpr int NVOX = TD * TH * TW;
+    constexpr int BT = KDS * KS * KS;          // taps handled by this block
+    constexpr int KSTEPS = NVOX / 4;           // MFMA K-steps per tile
+    constexpr int KPW = KSTEPS / 4;            // per wave
+    static_assert(TW % 4 == 0 && KSTEPS % 4 == 0, "tile shape");
+
+    __shared__ __attribute__((aligned(16))) float sA[HV * 16];
+    __shared__ __attribute__((aligned(16))) float sG[NVOX * 16];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, kq = lane >> 4;
+    const int cit = blockIdx.y % p.n_ci_t, cot = blockIdx.y / p.n_ci_t;
+    const int kd0 = blockIdx.z * KDS;
+    const int ci0 = cit * 16, co0 = cot * 16;
+
+    f32x4 acc[BT];
+#pragma unroll
+    for (int t = 0; t < BT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // staging roles: 4 threads cover the 16 channels of one voxel
+    const int quad = tid & 3;
+    const bool a_ok = (ci0 + quad * 4) < p.cin_p, g_ok = (co0 + quad * 4) < p.cout_p;
+    const bool has_xf = p.in_scale != nullptr;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (has_xf && a_ok) {
+        sc = *reinterpret_cast<const float4*>(p.in_scale + ci0 + quad * 4);
+        sh = *reinterpret_cast<const float4*>(p.in_shift + ci0 + quad * 4);
+    }
+
+    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+        int bx = tile;
+        const int tx = bx % p.tiles_w; bx /= p.tiles_w;
+        const int ty = bx % p.tiles_h; bx /= p.tiles_h;
+        const int tz = bx % p.tiles_d; bx /= p.tiles_d;
+        const int n_img = bx;
+        const int d0 = tz * TD, h0 = ty * TH, w0 = tx * TW;
+        __syncthreads();
+        for (int it = tid; it < HV * 4; it += 256) {
+            const int v = it >> 2;
+            const int pw = v % HW, t2 = v / HW, ph = t2 % HH, pd = t2 / HH;
+            const int gd = d0 + pd + kd0 - PAD, gh = h0 + ph - PAD, gw = w0 + pw - PAD;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a_ok && (unsigned)gd < (unsigned)p.D && (unsigned)gh < (unsigned)p.H &&
+                (unsigned)gw < (unsigned)p.W) {
+                const size_t vox = (((size_t)n_img * p.D + gd) * p.H + gh) * p.W + gw;
+                val = *reinterpret_cast<const float4*>(p.in + vox * p.in_cs + ci0 + quad * 4);
+                if (has_xf) val = xform4(val, sc, sh, p.in_relu);
+            }
+            *reinterpret_cast<float4*>(&sA[v * 16 + quad * 4]) = val;
+        }
+        for (int it = tid; it < NVOX * 4; it += 256) {
+            const int v = it >> 2;
+            const int tw = v % TW, th = (v / TW) % TH, td = v / (TW * TH);
+            const int gd = d0 + td, gh = h0 + th, gw = w0 + tw;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (g_ok && gd < p.D && gh < p.H && gw < p.W) {
+                const size_t vox = (((size_t)n_img * p.D + gd) * p.H + gh) * p.W + gw;
+                val = *reinterpret_cast<const float4*>(p.g + vox * p.g_cs + co0 + quad * 4);
+            }
+            *reinterpret_cast<float4*>(&sG[v * 16 + quad * 4]) = val;
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int ks = 0; ks < KPW; ++ks) {
+            const int vt = (wave * KPW + ks) * 4 + kq;
+            const int tw = vt % TW, th = (vt / TW) % TH, td = vt / (TW * TH);
+            const float b = sG[vt * 16 + i];
+            const int ab = ((td * HH + th) * HW + tw) * 16 + i;
+#pragma unroll
+            for (int t = 0; t < BT; ++t) {
+                const int kd = t / (KS * KS), kh = (t / KS) % KS, kw = t % KS;
+                const float a = sA[ab + ((kd * HH + kh) * HW + kw) * 16];
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
+            }
+        }
+    }
+    // per-wave partial slab [BT][16 ci][16 co]
+    const size_t slab = ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave;
+    float* dst = p.ws + slab * (BT * 256);
+#pragma unroll
+    for (int t = 0; t < BT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[t * 256 + (kq * 4 + r) * 16 + i] = acc[t][r];
+}
+
+// dW[co][ci][t] = sum over slabs.  One thread per (t, ci, co), co fastest.
+template <int KS, int KDS>
+__global__ void conv3d_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Co, int Ci,
+                                           const int32_t* __restrict__ imap, int n_ci_t, int n_pairs, int gx) {
+    constexpr int TAPS = KS * KS * KS, BT = KDS * KS * KS;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Co * Ci * TAPS) return;
+    const int co = idx % Co, ci = (idx / Co) % Ci, t = idx / (Co * Ci);
+    const int cip = imap ? imap[ci] : ci;
+    const int cit = cip >> 4, i = cip & 15, cot = co >> 4, j = co & 15;
+    const int z = t / BT, tl = t % BT;
+    const int pair = cot * n_ci_t + cit;
+    const float* src = ws + ((size_t)(z * n_pairs + pair) * gx * 4) * (BT * 256) + tl * 256 + i * 16 + j;
+    float s = 0.f;
+    const int ns = gx * 4;
+    for (int k = 0; k < ns; ++k) s += src[(size_t)k * (BT * 256)];
+    dw[((size_t)co * Ci + ci) * TAPS + t] = s;
+}
+
+inline int wgrad_gx(int ntiles, int pairs_z) {
+    int gx = 768 / pairs_z;
+    if (gx < 1) gx = 1;
+    if (gx > ntiles) gx = ntiles;
+    return gx;
+}
+
+}  // namespace
+
+// =================================================================== C ABI
+extern "C" size_t ctu_conv3d_packed_floats(int k, int rin_p, int nout_p) {
+    if ((k != 3 && k != 5) || rin_p <= 0 || nout_p <= 0) return 0;
+    const int NT = pick_nt(nout_p);
+    const int ny = ceil_div(nout_p, 16 * NT);
+    return (size_t)ny * (rin_p / 8) * k * k * k * NT * 128;
+}
+
+extern "C" int ctu_conv3d_num_blocks(int N, int D, int H, int W) {
+    int td, th, tw;
+    pick_tile(W, &td, &th, &tw);
+    return N * ceil_div(D, td) * ceil_div(H, th) * ceil_div(W, tw);
+}
+
+extern "C" int ctu_pack_conv3d_weight(const float* w, float* wp, int Co, int Ci, int k, const int32_t* imap,
+                                      int rin_p, int nout_p, int mode, void* stream) {
+    CTU_REQUIRE(k == 3 || k == 5, "pack_conv3d_weight: k=%d unsupported (3 or 5)", k);
+    CTU_REQUIRE(rin_p % 8 == 0 && nout_p % 8 == 0, "pack_conv3d_weight: padded channels must be multiples of 8");
+    CTU_REQUIRE(w && wp && Co > 0 && Ci > 0, "pack_conv3d_weight: null/empty argument");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t nfl = ctu_conv3d_packed_floats(k, rin_p, nout_p);
+    if (hipMemsetAsync(wp, 0, nfl * sizeof(float), st) != hipSuccess) {
+        ctu_set_error("pack_conv3d_weight: memset failed");
+        return CTU_ELAUNCH;
+    }
+    const int NT = pick_nt(nout_p);
+    const int total = Co * Ci * k * k * k;
+    const int nb = ceil_div(total, 256);
+    if (k == 3) pack_conv_w_kernel<3><<<nb, 256, 0, st>>>(w, wp, Co, Ci, imap, rin_p, NT, mode);
+    else pack_conv_w_kernel<5><<<nb, 256, 0, st>>>(w, wp, Co, Ci, imap, rin_p, NT, mode);
+    CTU_CHECK_LAUNCH("pack_conv3d_weight");
+    return CTU_OK;
+}
+
+template <int KS, int NT>
+static int launch_fwd(const ConvP& p0, hipStream_t st) {
+    ConvP p = p0;
+    int td, th, tw;
+    pick_tile(p.W, &td, &th, &tw);
+    p.tiles_d = ceil_div(p.D, td); p.tiles_h = ceil_div(p.H, th); p.tiles_w = ceil_div(p.W, tw);
+    dim3 grid(p.N * p.tiles_d * p.tiles_h * p.tiles_w, ceil_div(p.nout_p, 16 * NT));
+    if (tw == 16) conv3d_fwd_kernel<KS, NT, 4, 4, 16><<<grid, 256, 0, st>>>(p);
+    else if (tw == 8) conv3d_fwd_kernel<KS, NT, 4, 8, 8><<<grid, 256, 0, st>>>(p);
+    else conv3d_fwd_kernel<KS, NT, 4, 4, 4><<<grid, 256, 0, st>>>(p);
+    CTU_CHECK_LAUNCH("conv3d_fwd");
+    return CTU_OK;
+}
+
+extern "C" int ctu_conv3d_fwd(const float* in, int in_cs, int rin_p, const float* in_scale, const float* in_shift,
+                              int in_relu, const float* wp, const float* bias, float* out, int out_cs, int nout_p,
+                              float* stats, int N, int D, int H, int W, int k, void* stream) {
+    CTU_REQUIRE(k == 3 || k == 5, "conv3d_fwd: k=%d unsupported (3 or 5)", k);
+    CTU_REQUIRE(in && wp && out, "conv3d_fwd: null pointer");
+    CTU_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0, "conv3d_fwd: empty volume %dx%dx%dx%d", N, D, H, W);
+    CTU_REQUIRE(rin_p > 0 && rin_p % 8 == 0 && nout_p > 0 && nout_p % 8 == 0,
+                "conv3d_fwd: channel counts must be positive multiples of 8 (rin_p=%d nout_p=%d)", rin_p, nout_p);
+    CTU_REQUIRE(in_cs >= rin_p && in_cs % 4 == 0 && out_cs >= nout_p, "conv3d_fwd: bad channel stride");
+    CTU_REQUIRE(((uintptr_t)in & 15) == 0 && ((uintptr_t)wp & 15) == 0, "conv3d_fwd: in/wp must be 16-byte aligned");
+    CTU_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv3d_fwd: scale/shift must come together");
+    ConvP p;
+    p.in = in; p.in_scale = in_scale; p.in_shift = in_shift; p.wp = wp; p.bias = bias; p.out = out; p.stats = stats;
+    p.in_cs = in_cs; p.rin_p = rin_p; p.in_relu = in_relu; p.out_cs = out_cs; p.nout_p = nout_p;
+    p.N = N; p.D = D; p.H = H; p.W = W;
+    hipStream_t st = (hipStream_t)stream;
+    const int NT = pick_nt(nout_p);
+    if (k == 3) {
+        if (NT == 1) return launch_fwd<3, 1>(p, st);
+        if (NT == 2) return launch_fwd<3, 2>(p, st);
+        return launch_fwd<3, 4>(p, st);
+    }
+    if (NT == 1) return launch_fwd<5, 1>(p, st);
+    if (NT == 2) return launch_fwd<5, 2>(p, st);
+    return launch_fwd<5, 4>(p, st);
+}
+
+static void wgrad_geom(int N, int D, int H, int W, int k, int cin_p, int cout_p, int* ntiles, int* n_ci_t,
+                       int* n_co_t, int* gz, int* gx, int* bt) {
+    int td, th, tw;
+    pick_tile(W, &td, &th, &tw);
+    *ntiles = N * ceil_div(D, td) * ceil_div(H, th) * ceil_div(W, tw);
+    *n_ci_t = ceil_div(cin_p, 16);
+    *n_co_t = ceil_div(cout_p, 16);
+    *gz = (k == 3) ? 1 : 5;
+    *bt = (k == 3) ? 27 : 25;
+    *gx = wgrad_gx(*ntiles, (*n_ci_t) * (*n_co_t) * (*gz));
+}
+
+extern "C" int ctu_channel_sum_num_blocks(int64_t nvox);
+
+extern "C" size_t ctu_conv3d_wgrad_ws_floats(int N, int D, int H, int W, int k, int cin_p, int cout_p) {
+    if (k != 3 && k != 5) return 0;
+    int ntiles, nci, nco, gz, gx, bt;
+    wgrad_geom(N, D, H, W, k, cin_p, cout_p, &ntiles, &nci, &nco, &gz, &gx, &bt);
+    const size_t slabs = (size_t)gz * nci * nco * gx * 4 * bt * 256;
+    const size_t bsum = (size_t)ctu_channel_sum_num_blocks((int64_t)N * D * H * W) * cout_p;
+    return slabs > bsum ? slabs : bsum;
+}
+
+template <int KS, int KDS>
+static int launch_wgrad(WgP p, float* dw, int Co, int Ci, const int32_t* imap, int gz, int gx, hipStream_t st) {
+    int td, th, tw;
+    pick_tile(p.W, &td, &th, &tw);
+    p.tiles_d = ceil_div(p.D, td); p.tiles_h = ceil_div(p.H, th); p.tiles_w = ceil_div(p.W, tw);
+    dim3 grid(gx, p.n_ci_t * p.n_co_t, gz);
+    if (tw == 16) conv3d_wgrad_kernel<KS, KDS, 4, 4, 16><<<grid, 256, 0, st>>>(p);
+    else if (tw == 8) conv3d_wgrad_kernel<KS, KDS, 4, 8, 8><<<grid, 256, 0, st>>>(p);
+    else conv3d_wgrad_kernel<KS, KDS, 4, 4, 4><<<grid, 256, 0, st>>>(p);
+    CTU_CHECK_LAUNCH("conv3d_wgrad");
+    const int total = Co * Ci * KS * KS * KS;
+    conv3d_wgrad_reduce_kernel<KS, KDS><<<ceil_div(total, 256), 256, 0, st>>>(p.ws, dw, Co, Ci, imap, p.n_ci_t,
+                                                                            p.n_ci_t * p.n_co_t, gx);
+    CTU_CHECK_LAUNCH("conv3d_wgrad_reduce");
+    return CTU_OK;
+}
+
+extern "C" int ctu_conv3d_wgrad(const float* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
+                                int in_relu, const float* gout, int g_cs, int cout_p, float* dw, float* dbias, int Co,
+                                int Ci, const int32_t* imap, float* ws, int N, int D, int H, int W, int k,
+                                void* stream) {
+    CTU_REQUIRE(k == 3 || k == 5, "conv3d_wgrad: k=%d unsupported (3 or 5)", k);
+    CTU_REQUIRE(in && gout && dw && ws, "conv3d_wgrad: null pointer");
+    CTU_REQUIRE(cin_p % 8 == 0 && cout_p % 8 == 0 && cin_p > 0 && cout_p > 0, "conv3d_wgrad: padded channels");
+    CTU_REQUIRE(in_cs >= cin_p && in_cs % 4 == 0 && g_cs >= cout_p && g_cs % 4 == 0, "conv3d_wgrad: bad stride");
+    CTU_REQUIRE(Co <= cout_p && Co > 0 && Ci > 0, "conv3d_wgrad: Co/Ci");
+    CTU_REQUIRE(((uintptr_t)in & 15) == 0 && ((uintptr_t)gout & 15) == 0, "conv3d_wgrad: 16-byte alignment");
+    hipStream_t st = (hipStream_t)stream;
+    WgP p;
+    p.in = in; p.in_scale = in_scale; p.in_shift = in_shift; p.g = gout; p.ws = ws;
+    p.in_cs = in_cs; p.cin_p = cin_p; p.in_relu = in_relu; p.g_cs = g_cs; p.cout_p = cout_p;
+    p.N = N; p.D = D; p.H = H; p.W = W;
+    int gz, gx, bt;
+    wgrad_geom(N, D, H, W, k, cin_p, cout_p, &p.ntiles, &p.n_ci_t, &p.n_co_t, &gz, &gx, &bt);
+    int rc = (k == 3) ? launch_wgrad<3, 3>(p, dw, Co, Ci, imap, gz, gx, st)
+                      : launch_wgrad<5, 1>(p, dw, Co, Ci, imap, gz, gx, st);
+    if (rc != CTU_OK) return rc;
+    if (dbias) return ctu_channel_sum(gout, g_cs, cout_p, (int64_t)N * D * H * W, ws, dbias, Co, stream);
+    return CTU_OK;
+}

@@ -1,0 +1,341 @@
+// ConvTranspose3d(kernel 2, stride 2, bias) for gfx950 -- replaces nn.ConvTranspose3d at
+// ctunet/pytorch/models.py:37 and :427-429 and its autograd backward.
+//
+// With kernel == stride every output voxel receives exactly one tap, so the op is a plain GEMM
+//   [input voxels x Ci] . [Ci x (8 taps x Co)]  followed by a scatter to (2d+i, 2h+j, 2w+l).
+// A block owns 64 consecutive input voxels (4 waves x one 16-voxel M-tile), keeps their
+// activated channels in LDS (row stride Ci+4 floats -> conflict-free ds_read_b64) and walks the
+// 8 taps, staging one tap's packed weights at a time.  v_mfma_f32_16x16x4_f32, exact fp32.
+// The op is HBM-bound (the 8x larger output stream), see DESIGN.md.
+#include "common.h"
+
+namespace {
+
+struct CtP {
+    const float* in;         // fwd: input [V][in_cs]; bwd-data: gout on the 2x grid
+    const float* in_scale;
+    const float* in_shift;
+    const float* wp;
+    const float* bias;
+    float* out;              // fwd: output on the 2x grid; bwd-data: gin [V][out_cs]
+    int in_cs, rin_p, in_relu, out_cs, nout_p;
+    int N, D, H, W;          // coarse (input-side) grid
+    int64_t nvox;            // N*D*H*W
+};
+
+__device__ __forceinline__ size_t fine_vox(int64_t v, int D, int H, int W, int tap) {
+    const int w = (int)(v % W); int64_t t = v / W;
+    const int h = (int)(t % H); t /= H;
+    const int d = (int)(t % D);
+    const int64_t n = t / D;
+    return (((size_t)n * (2 * D) + 2 * d + (tap >> 2)) * (2 * H) + 2 * h + ((tap >> 1) & 1)) * (2 * W) + 2 * w +
+           (tap & 1);
+}
+
+// MODE 0: forward (A staged once, one store per tap).  MODE 1: data gradient (A gathered per tap
+// from the fine grid, accumulated over the 8 taps, one store).
+template <int NTT, int MODE>
+__global__ __launch_bounds__(256) void convt2_kernel(CtP p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int AS = p.rin_p + 4;                       // LDS row stride (floats)
+    float* sA = smem;                                 // [64][AS]
+    float* sW = smem + 64 * AS;                       // [rin_p/8][NTT][128]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, kq = lane >> 4;
+    const int64_t v0 = (int64_t)blockIdx.x * 64;
+    const int ng = p.rin_p >> 3;
+    const int nq = p.rin_p >> 2;                      // float4 per voxel
+    const bool has_xf = p.in_scale != nullptr;
+    const int wfl = ng * NTT * 128;
+
+    f32x4 acc[NTT];
+#pragma unroll
+    for (int nt = 0; nt < NTT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int tap = 0; tap < 8; ++tap) {
+        __syncthreads();
+        if (MODE == 1 || tap == 0) {
+            for (int it = tid; it < 64 * nq; it += 256) {
+                const int vl = it / nq, qd = it % nq;
+                const int64_t v = v0 + vl;
+                float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (v < p.nvox) {
+                    const size_t src = (MODE == 0) ? (size_t)v : fine_vox(v, p.D, p.H, p.W, tap);
+                    val = *reinterpret_cast<const float4*>(p.in + src * p.in_cs + qd * 4);
+                    if (has_xf) {
+                        const float4 sc = *reinterpret_cast<const float4*>(p.in_scale + qd * 4);
+                        const float4 sh = *reinterpret_cast<const float4*>(p.in_shift + qd * 4);
+                        val = xform4(val, sc, sh, p.in_relu);
+                    }
+                }
+                *reinterpret_cast<float4*>(&sA[vl * AS + qd * 4]) = val;
+            }
+        }
+        const float* wsrc = p.wp + (size_t)tap * wfl;
+        for (int i = tid * 4; i < wfl; i += 1024)
+            *reinterpret_cast<float4*>(&sW[i]) = *reinterpret_cast<const float4*>(wsrc + i);
+        __syncthreads();
+        if (MODE == 0) {
+#pragma unroll
+            for (int nt = 0; nt < NTT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const float* arow = &sA[(wave * 16 + m) * AS + kq * 2];
+        const float* brow = &sW[kq * 32 + m * 2];
+        for (int g = 0; g < ng; ++g) {
+            const float2 a = *reinterpret_cast<const float2*>(arow + g * 8);
+#pragma unroll
+            for (int nt = 0; nt < NTT; ++nt) {
+                const float2 b = *reinterpret_cast<const float2*>(brow + (g * NTT + nt) * 128);
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[nt], 0, 0, 0);
+            }
+        }
+        if (MODE == 0) {
+#pragma unroll
+            for (int nt = 0; nt < NTT; ++nt) {
+                const int co = nt * 16 + m;
+                if (co < p.nout_p) {
+                    const float bv = p.bias ? p.bias[co] : 0.f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int64_t v = v0 + wave * 16 + kq * 4 + r;
+                        if (v < p.nvox) p.out[fine_vox(v, p.D, p.H, p.W, tap) * p.out_cs + co] = acc[nt][r] + bv;
+                    }
+                }
+            }
+        }
+    }
+    if (MODE == 1) {
+#pragma unroll
+        for (int nt = 0; nt < NTT; ++nt) {
+            const int co = nt * 16 + m;
+            if (co < p.nout_p) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t v = v0 + wave * 16 + kq * 4 + r;
+                    if (v < p.nvox) p.out[(size_t)v * p.out_cs + co] = acc[nt][r];
+                }
+            }
+        }
+    }
+}
+
+inline int pick_ntt(int nout_p) {
+    const int n16 = (nout_p + 15) / 16;
+    return n16 <= 1 ? 1 : (n16 <= 2 ? 2 : (n16 <= 4 ? 4 : 8));
+}
+
+// wp[tap][g][nt][kq][n][j]
+__global__ void pack_convt_w_kernel(const float* __restrict__ w, float* __restrict__ wp, int Ci, int Co,
+                                    const int32_t* __restrict__ imap, int rin_p, int NTT, int mode) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Ci * Co * 8) return;
+    const int tap = idx & 7, co = (idx >> 3) % Co, ci = idx / (8 * Co);
+    const int cip = imap ? imap[ci] : ci;
+    const int rp = (mode == 0) ? cip : co, np = (mode == 0) ? co : cip;
+    const int g = rp >> 3, kq = (rp & 7) >> 1, j = rp & 1, nt = np >> 4, n = np & 15;
+    const int ng = rin_p >> 3;
+    wp[((size_t)(tap * ng + g) * NTT + nt) * 128 + kq * 32 + n * 2 + j] = w[idx];
+}
+
+// ------------------------------------------------------------------ weight gradient
+struct CtWgP {
+    const float* in;
+    const float* in_scale;
+    const float* in_shift;
+    const float* g;
+    float* ws;
+    int in_cs, cin_p, in_relu, g_cs, cout_p;
+    int N, D, H, W;
+    int64_t nvox;
+    int ntiles, n_ci_t;
+};
+
+// M = 16 input channels, N = 16 output channels, K = coarse voxels; one accumulator per tap.
+__global__ __launch_bounds__(256) void convt2_wgrad_kernel(CtWgP p) {
+    __shared__ __attribute__((aligned(16))) float sA[64 * 16];
+    __shared__ __attribute__((aligned(16))) float sG[8 * 64 * 16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, kq = lane >> 4;
+    const int cit = blockIdx.y % p.n_ci_t, cot = blockIdx.y / p.n_ci_t;
+    const int ci0 = cit * 16, co0 = cot * 16;
+    const int quad = tid & 3;
+    const bool a_ok = (ci0 + quad * 4) < p.cin_p, g_ok = (co0 + quad * 4) < p.cout_p;
+    const bool has_xf = p.in_scale != nullptr;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (has_xf && a_ok) {
+        sc = *reinterpret_cast<const float4*>(p.in_scale + ci0 + quad * 4);
+        sh = *reinterpret_cast<const float4*>(p.in_shift + ci0 + quad * 4);
+    }
+    f32x4 acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+        const int64_t v0 = (int64_t)tile * 64;
+        __syncthreads();
+        {
+            const int vl = tid >> 2;
+            const int64_t v = v0 + vl;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a_ok && v < p.nvox) {
+                val = *reinterpret_cast<const float4*>(p.in + (size_t)v * p.in_cs + ci0 + quad * 4);
+                if (has_xf) val = xform4(val, sc, sh, p.in_relu);
+            }
+            *reinterpret_cast<float4*>(&sA[vl * 16 + quad * 4]) = val;
+#pragma unroll
+            for (int tap = 0; tap < 8; ++tap) {
+                float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (g_ok && v < p.nvox)
+                    gv = *reinterpret_cast<const float4*>(p.g + fine_vox(v, p.D, p.H, p.W, tap) * p.g_cs + co0 +
+                                                          quad * 4);
+                *reinterpret_cast<float4*>(&sG[(tap * 64 + vl) * 16 + quad * 4]) = gv;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int vl = (wave * 4 + ks) * 4 + kq;
+            const float a = sA[vl * 16 + i];
+#pragma unroll
+            for (int tap = 0; tap < 8; ++tap) {
+                const float b = sG[(tap * 64 + vl) * 16 + i];
+                acc[tap] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[tap], 0, 0, 0);
+            }
+        }
+    }
+    const size_t slab = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave;
+    float* dst = p.ws + slab * (8 * 256);
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[t * 256 + (kq * 4 + r) * 16 + i] = acc[t][r];
+}
+
+// dw[ci][co][tap]; one thread per (tap, ci, co) with co fastest
+__global__ void convt2_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Ci, int Co,
+                                           const int32_t* __restrict__ imap, int n_ci_t, int gx) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Ci * Co * 8) return;
+    const int co = idx % Co, ci = (idx / Co) % Ci, tap = idx / (Co * Ci);
+    const int cip = imap ? imap[ci] : ci;
+    const int pair = (co >> 4) * n_ci_t + (cip >> 4);
+    const float* src = ws + ((size_t)pair * gx * 4) * (8 * 256) + tap * 256 + (cip & 15) * 16 + (co & 15);
+    float s = 0.f;
+    for (int k = 0; k < gx * 4; ++k) s += src[(size_t)k * (8 * 256)];
+    dw[((size_t)ci * Co + co) * 8 + tap] = s;
+}
+
+inline int ct_wgrad_gx(int ntiles, int pairs) {
+    int gx = 512 / pairs;
+    if (gx < 1) gx = 1;
+    if (gx > ntiles) gx = ntiles;
+    return gx;
+}
+
+template <int MODE>
+int launch_convt(const CtP& p, hipStream_t st, const char* name) {
+    const int ntt = pick_ntt(p.nout_p);
+    const size_t lds = ((size_t)64 * (p.rin_p + 4) + (size_t)(p.rin_p / 8) * ntt * 128) * sizeof(float);
+    CTU_REQUIRE(lds <= 160 * 1024, "%s: rin_p=%d nout_p=%d needs %zu B of LDS", name, p.rin_p, p.nout_p, lds);
+    const unsigned grid = (unsigned)ceil_div64(p.nvox, 64);
+#define CT_LAUNCH(N_)                                                                                             \
+    do {                                                                                                          \
+        if (lds > 64 * 1024)                                                                                      \
+            (void)hipFuncSetAttribute((const void*)convt2_kernel<N_, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      (int)lds);                                                                  \
+        convt2_kernel<N_, MODE><<<grid, 256, lds, st>>>(p);                                                       \
+    } while (0)
+    switch (ntt) {
+        case 1: CT_LAUNCH(1); break;
+        case 2: CT_LAUNCH(2); break;
+        case 4: CT_LAUNCH(4); break;
+        default: CT_LAUNCH(8); break;
+    }
+#undef CT_LAUNCH
+    CTU_CHECK_LAUNCH(name);
+    return CTU_OK;
+}
+
+}  // namespace
+
+// =================================================================== C ABI
+extern "C" size_t ctu_convt_packed_floats(int rin_p, int nout_p) {
+    if (rin_p <= 0 || nout_p <= 0) return 0;
+    return (size_t)8 * (rin_p / 8) * pick_ntt(nout_p) * 128;
+}
+
+extern "C" int ctu_pack_convt_weight(const float* w, float* wp, int Ci, int Co, const int32_t* imap, int rin_p,
+                                     int nout_p, int mode, void* stream) {
+    CTU_REQUIRE(w && wp && Ci > 0 && Co > 0, "pack_convt_weight: null/empty");
+    CTU_REQUIRE(rin_p % 8 == 0 && nout_p % 8 == 0 && nout_p <= 128, "pack_convt_weight: rin_p=%d nout_p=%d", rin_p,
+                nout_p);
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(wp, 0, ctu_convt_packed_floats(rin_p, nout_p) * sizeof(float), st) != hipSuccess) {
+        ctu_set_error("pack_convt_weight: memset failed");
+        return CTU_ELAUNCH;
+    }
+    pack_convt_w_kernel<<<ceil_div(Ci * Co * 8, 256), 256, 0, st>>>(w, wp, Ci, Co, imap, rin_p, pick_ntt(nout_p), mode);
+    CTU_CHECK_LAUNCH("pack_convt_weight");
+    return CTU_OK;
+}
+
+extern "C" int ctu_convt2_fwd(const float* in, int in_cs, int rin_p, const float* in_scale, const float* in_shift,
+                              int in_relu, const float* wp, const float* bias, float* out, int out_cs, int nout_p,
+                              int N, int D, int H, int W, void* stream) {
+    CTU_REQUIRE(in && wp && out, "convt2_fwd: null pointer");
+    CTU_REQUIRE(rin_p > 0 && rin_p % 8 == 0 && nout_p > 0 && nout_p % 8 == 0 && nout_p <= 128,
+                "convt2_fwd: rin_p=%d nout_p=%d", rin_p, nout_p);
+    CTU_REQUIRE(in_cs >= rin_p && in_cs % 4 == 0 && out_cs >= nout_p, "convt2_fwd: bad stride");
+    CTU_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "convt2_fwd: scale/shift must come together");
+    CtP p;
+    p.in = in; p.in_scale = in_scale; p.in_shift = in_shift; p.wp = wp; p.bias = bias; p.out = out;
+    p.in_cs = in_cs; p.rin_p = rin_p; p.in_relu = in_relu; p.out_cs = out_cs; p.nout_p = nout_p;
+    p.N = N; p.D = D; p.H = H; p.W = W; p.nvox = (int64_t)N * D * H * W;
+    return launch_convt<0>(p, (hipStream_t)stream, "convt2_fwd");
+}
+
+extern "C" int ctu_convt2_bwd_data(const float* gout, int g_cs, int rout_p, const float* wp, float* gin, int gin_cs,
+                                   int nin_p, int N, int D, int H, int W, void* stream) {
+    CTU_REQUIRE(gout && wp && gin, "convt2_bwd_data: null pointer");
+    CTU_REQUIRE(rout_p > 0 && rout_p % 8 == 0 && nin_p > 0 && nin_p % 8 == 0 && nin_p <= 128,
+                "convt2_bwd_data: rout_p=%d nin_p=%d", rout_p, nin_p);
+    CTU_REQUIRE(g_cs >= rout_p && g_cs % 4 == 0 && gin_cs >= nin_p, "convt2_bwd_data: bad stride");
+    CtP p;
+    p.in = gout; p.in_scale = nullptr; p.in_shift = nullptr; p.wp = wp; p.bias = nullptr; p.out = gin;
+    p.in_cs = g_cs; p.rin_p = rout_p; p.in_relu = 0; p.out_cs = gin_cs; p.nout_p = nin_p;
+    p.N = N; p.D = D; p.H = H; p.W = W; p.nvox = (int64_t)N * D * H * W;
+    return launch_convt<1>(p, (hipStream_t)stream, "convt2_bwd_data");
+}
+
+extern "C" size_t ctu_convt2_wgrad_ws_floats(int N, int D, int H, int W, int cin_p, int cout_p) {
+    const int64_t nvox = (int64_t)N * D * H * W;
+    const int ntiles = (int)ceil_div64(nvox, 64);
+    const int pairs = ceil_div(cin_p, 16) * ceil_div(cout_p, 16);
+    const size_t slabs = (size_t)pairs * ct_wgrad_gx(ntiles, pairs) * 4 * 8 * 256;
+    const size_t bsum = (size_t)ctu_channel_sum_num_blocks(nvox * 8) * cout_p;
+    return slabs > bsum ? slabs : bsum;
+}
+
+extern "C" int ctu_convt2_wgrad(const float* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
+                                int in_relu, const float* gout, int g_cs, int cout_p, float* dw, float* dbias, int Ci,
+                                int Co, const int32_t* imap, float* ws, int N, int D, int H, int W, void* stream) {
+    CTU_REQUIRE(in && gout && dw && ws, "convt2_wgrad: null pointer");
+    CTU_REQUIRE(cin_p % 8 == 0 && cout_p % 8 == 0 && cin_p > 0 && cout_p > 0, "convt2_wgrad: padded channels");
+    CTU_REQUIRE(in_cs >= cin_p && in_cs % 4 == 0 && g_cs >= cout_p && g_cs % 4 == 0, "convt2_wgrad: bad stride");
+    hipStream_t st = (hipStream_t)stream;
+    CtWgP p;
+    p.in = in; p.in_scale = in_scale; p.in_shift = in_shift; p.g = gout; p.ws = ws;
+    p.in_cs = in_cs; p.cin_p = cin_p; p.in_relu = in_relu; p.g_cs = g_cs; p.cout_p = cout_p;
+    p.N = N; p.D = D; p.H = H; p.W = W; p.nvox = (int64_t)N * D * H * W;
+    p.ntiles = (int)ceil_div64(p.nvox, 64);
+    p.n_ci_t = ceil_div(cin_p, 16);
+    const int pairs = p.n_ci_t * ceil_div(cout_p, 16);
+    const int gx = ct_wgrad_gx(p.ntiles, pairs);
+    convt2_wgrad_kernel<<<dim3(gx, pairs), 256, 0, st>>>(p);
+    CTU_CHECK_LAUNCH("convt2_wgrad");
+    convt2_wgrad_reduce_kernel<<<ceil_div(Ci * Co * 8, 256), 256, 0, st>>>(ws, dw, Ci, Co, imap, p.n_ci_t, gx);
+    CTU_CHECK_LAUNCH("convt2_wgrad_reduce");
+    if (dbias) return ctu_channel_sum(gout, g_cs, cout_p, p.nvox * 8, ws, dbias, Co, stream);
+    return CTU_OK;
+}

@@ -1,0 +1,507 @@
+// HBM-bound kernels of the U-Net path for gfx950: layout conversion, BatchNorm3d statistics
+// finalisation and backward, MaxPool3d(2,2) forward/backward, per-channel sums, fused Adam.
+// All activation accesses are 16-byte (float4) channels-last vectors; reductions are
+// two-stage (per-block partials, then a small finalize kernel) -- no float atomics, so
+// results are bitwise reproducible run to run.
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void ctu_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* ctu_last_error(void) { return g_err; }
+extern "C" int ctu_abi_version(void) { return CTU_ABI_VERSION; }
+extern "C" const char* ctu_arch(void) { return "gfx950"; }
+
+namespace {
+
+constexpr int EW_BLOCK = 256;
+constexpr int MAX_RED_BLOCKS = 1024;
+
+// ------------------------------------------------------------------ layout
+// NCDHW -> NDHWC: one thread per (voxel, channel-quad); reads are coalesced along w per channel.
+__global__ void ncdhw_to_ndhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int64_t V,
+                                      int64_t total_vox, int cp, int cs) {
+    const int nq = cp >> 2;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total_vox * nq) return;
+    // voxel fastest so that each channel plane is read contiguously by consecutive lanes
+    const int64_t vox = idx % total_vox;
+    const int qd = (int)(idx / total_vox);
+    const int64_t n = vox / V, v = vox % V;
+    float4 o;
+    float* op = &o.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = qd * 4 + j;
+        op[j] = (c < C) ? src[(n * C + c) * V + v] : 0.f;
+    }
+    *reinterpret_cast<float4*>(dst + vox * cs + qd * 4) = o;
+}
+
+__global__ void ndhwc_to_ncdhw_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int64_t V,
+                                      int64_t total_vox, int cs) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total_vox * C) return;
+    const int64_t vox = idx % total_vox;
+    const int c = (int)(idx / total_vox);
+    const int64_t n = vox / V, v = vox % V;
+    dst[(n * C + c) * V + v] = src[vox * cs + c];
+}
+
+// ------------------------------------------------------------------ BN finalize
+__global__ void bn_finalize_kernel(const float* __restrict__ stats, int nblocks, int C, int cp, double count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps,
+                                   int n_updates, float* __restrict__ scale, float* __restrict__ shift,
+                                   float* __restrict__ mean_out, float* __restrict__ invstd_out) {
+    const int c = blockIdx.x;
+    __shared__ double r1[EW_BLOCK], r2[EW_BLOCK];
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C) {
+        for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
+            s1 += (double)stats[(size_t)b * 2 * cp + c];
+            s2 += (double)stats[(size_t)b * 2 * cp + cp + c];
+        }
+    }
+    r1[threadIdx.x] = s1; r2[threadIdx.x] = s2;
+    __syncthreads();
+    for (int o = EW_BLOCK / 2; o > 0; o >>= 1) {
+        if (threadIdx.x < o) { r1[threadIdx.x] += r1[threadIdx.x + o]; r2[threadIdx.x] += r2[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (c < C) {
+            const double mean = r1[0] / count;
+            double var = r2[0] / count - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+            const float sc = gamma[c] * invstd;
+            scale[c] = sc;
+            shift[c] = beta[c] - (float)mean * sc;
+            mean_out[c] = (float)mean;
+            invstd_out[c] = invstd;
+            if (rmean && n_updates > 0) {
+                const float unb = (float)(var * (count / (count > 1.0 ? count - 1.0 : 1.0)));
+                float rm = rmean[c], rv = rvar[c];
+                for (int u = 0; u < n_updates; ++u) {
+                    rm = (1.f - momentum) * rm + momentum * (float)mean;
+                    rv = (1.f - momentum) * rv + momentum * unb;
+                }
+                rmean[c] = rm; rvar[c] = rv;
+            }
+        } else {
+            scale[c] = 0.f; shift[c] = 0.f; mean_out[c] = 0.f; invstd_out[c] = 0.f;
+        }
+    }
+}
+
+__global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, const float* rmean, const float* rvar,
+                                      float eps, int C, int cp, float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cp) return;
+    if (c < C) {
+        const float sc = gamma[c] / sqrtf(rvar[c] + eps);
+        scale[c] = sc;
+        shift[c] = beta[c] - rmean[c] * sc;
+    } else {
+        scale[c] = 0.f; shift[c] = 0.f;
+    }
+}
+
+// ------------------------------------------------------------------ BN+ReLU backward
+// thread = (voxel stripe, channel quad); channel quad fixed per thread so its constants sit in registers.
+__global__ void bn_relu_bwd_reduce_kernel(const float* __restrict__ y, int y_cs, const float* __restrict__ ga,
+                                          int g_cs, int cp, const float* __restrict__ scale,
+                                          const float* __restrict__ shift, const float* __restrict__ mean,
+                                          const float* __restrict__ invstd, int64_t nvox,
+                                          float* __restrict__ partials) {
+    const int nq = cp >> 2;
+    const int tpv = EW_BLOCK / nq;                  // voxels per block pass (nq divides 256 or not: extra threads idle)
+    const int qd = threadIdx.x % nq, vl = threadIdx.x / nq;
+    __shared__ float red[EW_BLOCK * 8];
+    float4 a1 = make_float4(0.f, 0.f, 0.f, 0.f), a2 = a1;
+    if (vl < tpv) {
+        const float4 sc = *reinterpret_cast<const float4*>(scale + qd * 4);
+        const float4 sh = *reinterpret_cast<const float4*>(shift + qd * 4);
+        const float4 mu = *reinterpret_cast<const float4*>(mean + qd * 4);
+        const float4 is = *reinterpret_cast<const float4*>(invstd + qd * 4);
+        for (int64_t v = (int64_t)blockIdx.x * tpv + vl; v < nvox; v += (int64_t)gridDim.x * tpv) {
+            const float4 yy = *reinterpret_cast<const float4*>(y + v * y_cs + qd * 4);
+            const float4 gg = *reinterpret_cast<const float4*>(ga + v * g_cs + qd * 4);
+            float gz;
+            gz = (fmaf(yy.x, sc.x, sh.x) > 0.f) ? gg.x : 0.f; a1.x += gz; a2.x += gz * (yy.x - mu.x) * is.x;
+            gz = (fmaf(yy.y, sc.y, sh.y) > 0.f) ? gg.y : 0.f; a1.y += gz; a2.y += gz * (yy.y - mu.y) * is.y;
+            gz = (fmaf(yy.z, sc.z, sh.z) > 0.f) ? gg.z : 0.f; a1.z += gz; a2.z += gz * (yy.z - mu.z) * is.z;
+            gz = (fmaf(yy.w, sc.w, sh.w) > 0.f) ? gg.w : 0.f; a1.w += gz; a2.w += gz * (yy.w - mu.w) * is.w;
+        }
+    }
+    float* r = &red[threadIdx.x * 8];
+    r[0] = a1.x; r[1] = a1.y; r[2] = a1.z; r[3] = a1.w; r[4] = a2.x; r[5] = a2.y; r[6] = a2.z; r[7] = a2.w;
+    __syncthreads();
+    // thread t < cp sums channel t over the voxel lanes (fixed order -> deterministic)
+    if (threadIdx.x < cp) {
+        const int c = threadIdx.x, q = c >> 2, j = c & 3;
+        float s1 = 0.f, s2 = 0.f;
+        for (int l = 0; l < tpv; ++l) {
+            s1 += red[(l * nq + q) * 8 + j];
+            s2 += red[(l * nq + q) * 8 + 4 + j];
+        }
+        partials[(size_t)blockIdx.x * 2 * cp + c] = s1;
+        partials[(size_t)blockIdx.x * 2 * cp + cp + c] = s2;
+    }
+}
+
+// coef[0..cp) = gamma*invstd ; coef[cp..2cp) = dbeta/n ; coef[2cp..3cp) = dgamma/n
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nb, int C, int cp, double count,
+                                       const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                       float* __restrict__ coef) {
+    const int c = blockIdx.x;
+    __shared__ double r1[EW_BLOCK], r2[EW_BLOCK];
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C)
+        for (int b = threadIdx.x; b < nb; b += blockDim.x) {
+            s1 += (double)partials[(size_t)b * 2 * cp + c];
+            s2 += (double)partials[(size_t)b * 2 * cp + cp + c];
+        }
+    r1[threadIdx.x] = s1; r2[threadIdx.x] = s2;
+    __syncthreads();
+    for (int o = EW_BLOCK / 2; o > 0; o >>= 1) {
+        if (threadIdx.x < o) { r1[threadIdx.x] += r1[threadIdx.x + o]; r2[threadIdx.x] += r2[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (c < C) {
+            dbeta[c] = (float)r1[0];
+            dgamma[c] = (float)r2[0];
+            coef[c] = gamma[c] * invstd[c];
+            coef[cp + c] = (float)(r1[0] / count);
+            coef[2 * cp + c] = (float)(r2[0] / count);
+        } else {
+            coef[c] = 0.f; coef[cp + c] = 0.f; coef[2 * cp + c] = 0.f;
+        }
+    }
+}
+
+__global__ void bn_relu_bwd_apply_kernel(const float* __restrict__ y, int y_cs, float* __restrict__ ga, int g_cs,
+                                         int cp, const float* __restrict__ scale, const float* __restrict__ shift,
+                                         const float* __restrict__ mean, const float* __restrict__ invstd,
+                                         const float* __restrict__ coef, int64_t nvox) {
+    const int nq = cp >> 2;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nvox * nq) return;
+    const int qd = (int)(idx % nq);
+    const int64_t v = idx / nq;
+    const float4 sc = *reinterpret_cast<const float4*>(scale + qd * 4);
+    const float4 sh = *reinterpret_cast<const float4*>(shift + qd * 4);
+    const float4 mu = *reinterpret_cast<const float4*>(mean + qd * 4);
+    const float4 is = *reinterpret_cast<const float4*>(invstd + qd * 4);
+    const float4 k0 = *reinterpret_cast<const float4*>(coef + qd * 4);
+    const float4 k1 = *reinterpret_cast<const float4*>(coef + cp + qd * 4);
+    const float4 k2 = *reinterpret_cast<const float4*>(coef + 2 * cp + qd * 4);
+    const float4 yy = *reinterpret_cast<const float4*>(y + v * y_cs + qd * 4);
+    float4 gg = *reinterpret_cast<const float4*>(ga + v * g_cs + qd * 4);
+    float gz;
+    gz = (fmaf(yy.x, sc.x, sh.x) > 0.f) ? gg.x : 0.f; gg.x = k0.x * (gz - k1.x - (yy.x - mu.x) * is.x * k2.x);
+    gz = (fmaf(yy.y, sc.y, sh.y) > 0.f) ? gg.y : 0.f; gg.y = k0.y * (gz - k1.y - (yy.y - mu.y) * is.y * k2.y);
+    gz = (fmaf(yy.z, sc.z, sh.z) > 0.f) ? gg.z : 0.f; gg.z = k0.z * (gz - k1.z - (yy.z - mu.z) * is.z * k2.z);
+    gz = (fmaf(yy.w, sc.w, sh.w) > 0.f) ? gg.w : 0.f; gg.w = k0.w * (gz - k1.w - (yy.w - mu.w) * is.w * k2.w);
+    *reinterpret_cast<float4*>(ga + v * g_cs + qd * 4) = gg;
+}
+
+// ------------------------------------------------------------------ MaxPool3d(2,2)
+__global__ void maxpool2_fwd_kernel(const float* __restrict__ in, int in_cs, int cp, const float* __restrict__ scale,
+                                    const float* __restrict__ shift, int relu, float* __restrict__ out, int out_cs,
+                                    int N, int D, int H, int W) {
+    const int nq = cp >> 2;
+    const int Do = D >> 1, Ho = H >> 1, Wo = W >> 1;
+    const int64_t total = (int64_t)N * Do * Ho * Wo * nq;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int qd = (int)(idx % nq);
+    int64_t o = idx / nq;
+    const int wo = (int)(o % Wo); o /= Wo;
+    const int ho = (int)(o % Ho); o /= Ho;
+    const int dd = (int)(o % Do);
+    const int n = (int)(o / Do);
+    const bool xf = scale != nullptr;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (xf) {
+        sc = *reinterpret_cast<const float4*>(scale + qd * 4);
+        sh = *reinterpret_cast<const float4*>(shift + qd * 4);
+    }
+    float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int d = dd * 2 + (t >> 2), h = ho * 2 + ((t >> 1) & 1), w = wo * 2 + (t & 1);
+        const size_t vox = (((size_t)n * D + d) * H + h) * W + w;
+        float4 v = *reinterpret_cast<const float4*>(in + vox * in_cs + qd * 4);
+        if (xf) v = xform4(v, sc, sh, relu);
+        best.x = fmaxf(best.x, v.x); best.y = fmaxf(best.y, v.y);
+        best.z = fmaxf(best.z, v.z); best.w = fmaxf(best.w, v.w);
+    }
+    const size_t ovox = (((size_t)n * Do + dd) * Ho + ho) * Wo + wo;
+    *reinterpret_cast<float4*>(out + ovox * out_cs + qd * 4) = best;
+}
+
+__global__ void maxpool2_bwd_kernel(const float* __restrict__ in, int in_cs, int cp, const float* __restrict__ scale,
+                                    const float* __restrict__ shift, int relu, const float* __restrict__ gout,
+                                    int gout_cs, float* __restrict__ gin, int gin_cs, int accumulate, int N, int D,
+                                    int H, int W) {
+    const int nq = cp >> 2;
+    const int Do = D >> 1, Ho = H >> 1, Wo = W >> 1;
+    const int64_t total = (int64_t)N * Do * Ho * Wo * nq;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int qd = (int)(idx % nq);
+    int64_t o = idx / nq;
+    const int wo = (int)(o % Wo); o /= Wo;
+    const int ho = (int)(o % Ho); o /= Ho;
+    const int dd = (int)(o % Do);
+    const int n = (int)(o / Do);
+    const bool xf = scale != nullptr;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (xf) {
+        sc = *reinterpret_cast<const float4*>(scale + qd * 4);
+        sh = *reinterpret_cast<const float4*>(shift + qd * 4);
+    }
+    float4 vals[8];
+    float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    int bi[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int d = dd * 2 + (t >> 2), h = ho * 2 + ((t >> 1) & 1), w = wo * 2 + (t & 1);
+        const size_t vox = (((size_t)n * D + d) * H + h) * W + w;
+        float4 v = *reinterpret_cast<const float4*>(in + vox * in_cs + qd * 4);
+        if (xf) v = xform4(v, sc, sh, relu);
+        vals[t] = v;
+        // first maximum in (d,h,w) scan order wins, as ATen's max_pool3d does (strict >)
+        if (v.x > best.x) { best.x = v.x; bi[0] = t; }
+        if (v.y > best.y) { best.y = v.y; bi[1] = t; }
+        if (v.z > best.z) { best.z = v.z; bi[2] = t; }
+        if (v.w > best.w) { best.w = v.w; bi[3] = t; }
+    }
+    const size_t ovox = (((size_t)n * Do + dd) * Ho + ho) * Wo + wo;
+    const float4 g = *reinterpret_cast<const float4*>(gout + ovox * gout_cs + qd * 4);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int d = dd * 2 + (t >> 2), h = ho * 2 + ((t >> 1) & 1), w = wo * 2 + (t & 1);
+        const size_t vox = (((size_t)n * D + d) * H + h) * W + w;
+        float4* gp = reinterpret_cast<float4*>(gin + vox * gin_cs + qd * 4);
+        float4 r = accumulate ? *gp : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bi[0] == t) r.x += g.x;
+        if (bi[1] == t) r.y += g.y;
+        if (bi[2] == t) r.z += g.z;
+        if (bi[3] == t) r.w += g.w;
+        *gp = r;
+    }
+}
+
+// ------------------------------------------------------------------ channel sums
+__global__ void channel_sum_partial_kernel(const float* __restrict__ x, int cs, int cp, int64_t nvox,
+                                           float* __restrict__ partials) {
+    const int nq = cp >> 2;
+    const int tpv = EW_BLOCK / nq;
+    const int qd = threadIdx.x % nq, vl = threadIdx.x / nq;
+    __shared__ float red[EW_BLOCK * 4];
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (vl < tpv)
+        for (int64_t v = (int64_t)blockIdx.x * tpv + vl; v < nvox; v += (int64_t)gridDim.x * tpv) {
+            const float4 t = *reinterpret_cast<const float4*>(x + v * cs + qd * 4);
+            a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+        }
+    float* r = &red[threadIdx.x * 4];
+    r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w;
+    __syncthreads();
+    if (threadIdx.x < cp) {
+        const int c = threadIdx.x, q = c >> 2, j = c & 3;
+        float s = 0.f;
+        for (int l = 0; l < tpv; ++l) s += red[(l * nq + q) * 4 + j];
+        partials[(size_t)blockIdx.x * cp + c] = s;
+    }
+}
+
+__global__ void channel_sum_final_kernel(const float* __restrict__ partials, int nb, int cp, float* __restrict__ out,
+                                         int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int b = 0; b < nb; ++b) s += (double)partials[(size_t)b * cp + c];
+    out[c] = (float)s;
+}
+
+// ------------------------------------------------------------------ Adam(amsgrad)
+__global__ void adam_amsgrad_kernel(void* const* __restrict__ ptrs, const int64_t* __restrict__ sizes, float lr,
+                                    float beta1, float beta2, float eps, float wd, float bc1, float bc2_sqrt) {
+    const int t = blockIdx.y;
+    const int64_t n = sizes[t];
+    float* p = (float*)ptrs[t * 5 + 0];
+    const float* g = (const float*)ptrs[t * 5 + 1];
+    float* m = (float*)ptrs[t * 5 + 2];
+    float* v = (float*)ptrs[t * 5 + 3];
+    float* vm = (float*)ptrs[t * 5 + 4];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float gr = g[i];
+        const float pv = p[i];
+        if (wd != 0.f) gr = fmaf(wd, pv, gr);
+        // torch.optim.Adam single-tensor form: lerp for exp_avg, addcmul for exp_avg_sq
+        const float mi = m[i] + (gr - m[i]) * (1.f - beta1);
+        const float vi = v[i] * beta2 + (1.f - beta2) * gr * gr;
+        const float vmx = fmaxf(vm[i], vi);
+        m[i] = mi; v[i] = vi; vm[i] = vmx;
+        const float denom = sqrtf(vmx) / bc2_sqrt + eps;
+        p[i] = pv - (lr / bc1) * (mi / denom);
+    }
+}
+
+}  // namespace
+
+// =================================================================== C ABI
+extern "C" int ctu_ncdhw_to_ndhwc(const float* src, float* dst, int N, int C, int D, int H, int W, int cp, int cs,
+                                  void* stream) {
+    CTU_REQUIRE(src && dst && N > 0 && C > 0, "ncdhw_to_ndhwc: null/empty");
+    CTU_REQUIRE(cp % 8 == 0 && cp >= C && cs >= cp && cs % 4 == 0, "ncdhw_to_ndhwc: cp=%d cs=%d C=%d", cp, cs, C);
+    const int64_t V = (int64_t)D * H * W, tv = V * N;
+    const int64_t total = tv * (cp >> 2);
+    ncdhw_to_ndhwc_kernel<<<(unsigned)ceil_div64(total, EW_BLOCK), EW_BLOCK, 0, (hipStream_t)stream>>>(src, dst, C, V,
+                                                                                                     tv, cp, cs);
+    CTU_CHECK_LAUNCH("ncdhw_to_ndhwc");
+    return CTU_OK;
+}
+
+extern "C" int ctu_ndhwc_to_ncdhw(const float* src, float* dst, int N, int C, int D, int H, int W, int cs,
+                                  void* stream) {
+    CTU_REQUIRE(src && dst && N > 0 && C > 0 && cs >= C, "ndhwc_to_ncdhw: bad argument");
+    const int64_t V = (int64_t)D * H * W, tv = V * N;
+    ndhwc_to_ncdhw_kernel<<<(unsigned)ceil_div64(tv * C, EW_BLOCK), EW_BLOCK, 0, (hipStream_t)stream>>>(src, dst, C, V,
+                                                                                                      tv, cs);
+    CTU_CHECK_LAUNCH("ndhwc_to_ncdhw");
+    return CTU_OK;
+}
+
+extern "C" int ctu_bn_finalize(const float* stats, int nblocks, int C, int cp, double count, const float* gamma,
+                               const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                               int n_updates, float* scale, float* shift, float* mean_out, float* invstd_out,
+                               void* stream) {
+    CTU_REQUIRE(stats && gamma && beta && scale && shift && mean_out && invstd_out, "bn_finalize: null pointer");
+    CTU_REQUIRE(C > 0 && cp >= C && cp % 8 == 0 && nblocks > 0 && count > 0, "bn_finalize: bad sizes");
+    bn_finalize_kernel<<<cp, EW_BLOCK, 0, (hipStream_t)stream>>>(stats, nblocks, C, cp, count, gamma, beta,
+                                                                running_mean, running_var, momentum, eps, n_updates,
+                                                                scale, shift, mean_out, invstd_out);
+    CTU_CHECK_LAUNCH("bn_finalize");
+    return CTU_OK;
+}
+
+extern "C" int ctu_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
+                                  const float* running_var, float eps, int C, int cp, float* scale, float* shift,
+                                  void* stream) {
+    CTU_REQUIRE(gamma && beta && running_mean && running_var && scale && shift, "bn_eval_affine: null pointer");
+    CTU_REQUIRE(C > 0 && cp >= C && cp % 8 == 0, "bn_eval_affine: bad sizes");
+    bn_eval_affine_kernel<<<ceil_div(cp, 64), 64, 0, (hipStream_t)stream>>>(gamma, beta, running_mean, running_var,
+                                                                           eps, C, cp, scale, shift);
+    CTU_CHECK_LAUNCH("bn_eval_affine");
+    return CTU_OK;
+}
+
+extern "C" int ctu_bn_bwd_num_blocks(int64_t nvox) {
+    int64_t nb = ceil_div64(nvox, 64);
+    if (nb > MAX_RED_BLOCKS) nb = MAX_RED_BLOCKS;
+    if (nb < 1) nb = 1;
+    return (int)nb;
+}
+
+extern "C" int ctu_bn_relu_bwd_reduce(const float* y, int y_cs, const float* ga, int g_cs, int cp, const float* scale,
+                                      const float* shift, const float* mean, const float* invstd, int64_t nvox,
+                                      float* partials, void* stream) {
+    CTU_REQUIRE(y && ga && scale && shift && mean && invstd && partials, "bn_relu_bwd_reduce: null pointer");
+    CTU_REQUIRE(cp % 8 == 0 && cp > 0 && cp <= 256 && y_cs % 4 == 0 && g_cs % 4 == 0, "bn_relu_bwd_reduce: cp=%d", cp);
+    bn_relu_bwd_reduce_kernel<<<ctu_bn_bwd_num_blocks(nvox), EW_BLOCK, 0, (hipStream_t)stream>>>(
+        y, y_cs, ga, g_cs, cp, scale, shift, mean, invstd, nvox, partials);
+    CTU_CHECK_LAUNCH("bn_relu_bwd_reduce");
+    return CTU_OK;
+}
+
+extern "C" int ctu_bn_bwd_finalize(const float* partials, int nb, int C, int cp, double count, const float* gamma,
+                                   const float* invstd, float* dgamma, float* dbeta, float* coef, void* stream) {
+    CTU_REQUIRE(partials && gamma && invstd && dgamma && dbeta && coef, "bn_bwd_finalize: null pointer");
+    bn_bwd_finalize_kernel<<<cp, EW_BLOCK, 0, (hipStream_t)stream>>>(partials, nb, C, cp, count, gamma, invstd, dgamma,
+                                                                    dbeta, coef);
+    CTU_CHECK_LAUNCH("bn_bwd_finalize");
+    return CTU_OK;
+}
+
+extern "C" int ctu_bn_relu_bwd_apply(const float* y, int y_cs, float* ga, int g_cs, int cp, const float* scale,
+                                     const float* shift, const float* mean, const float* invstd, const float* coef,
+                                     int64_t nvox, void* stream) {
+    CTU_REQUIRE(y && ga && scale && shift && mean && invstd && coef, "bn_relu_bwd_apply: null pointer");
+    CTU_REQUIRE(cp % 8 == 0 && cp > 0, "bn_relu_bwd_apply: cp=%d", cp);
+    const int64_t total = nvox * (cp >> 2);
+    bn_relu_bwd_apply_kernel<<<(unsigned)ceil_div64(total, EW_BLOCK), EW_BLOCK, 0, (hipStream_t)stream>>>(
+        y, y_cs, ga, g_cs, cp, scale, shift, mean, invstd, coef, nvox);
+    CTU_CHECK_LAUNCH("bn_relu_bwd_apply");
+    return CTU_OK;
+}
+
+extern "C" int ctu_maxpool2_fwd(const float* in, int in_cs, int cp, const float* in_scale, const float* in_shift,
+                                int in_relu, float* out, int out_cs, int N, int D, int H, int W, void* stream) {
+    CTU_REQUIRE(in && out, "maxpool2_fwd: null pointer");
+    CTU_REQUIRE(cp % 8 == 0 && cp > 0 && D % 2 == 0 && H % 2 == 0 && W % 2 == 0, "maxpool2_fwd: D,H,W must be even");
+    const int64_t total = (int64_t)N * (D / 2) * (H / 2) * (W / 2) * (cp >> 2);
+    maxpool2_fwd_kernel<<<(unsigned)ceil_div64(total, EW_BLOCK), EW_BLOCK, 0, (hipStream_t)stream>>>(
+        in, in_cs, cp, in_scale, in_shift, in_relu, out, out_cs, N, D, H, W);
+    CTU_CHECK_LAUNCH("maxpool2_fwd");
+    return CTU_OK;
+}
+
+extern "C" int ctu_maxpool2_bwd(const float* in, int in_cs, int cp, const float* in_scale, const float* in_shift,
+                                int in_relu, const float* gout, int gout_cs, float* gin, int gin_cs, int accumulate,
+                                int N, int D, int H, int W, void* stream) {
+    CTU_REQUIRE(in && gout && gin, "maxpool2_bwd: null pointer");
+    CTU_REQUIRE(cp % 8 == 0 && cp > 0 && D % 2 == 0 && H % 2 == 0 && W % 2 == 0, "maxpool2_bwd: D,H,W must be even");
+    const int64_t total = (int64_t)N * (D / 2) * (H / 2) * (W / 2) * (cp >> 2);
+    maxpool2_bwd_kernel<<<(unsigned)ceil_div64(total, EW_BLOCK), EW_BLOCK, 0, (hipStream_t)stream>>>(
+        in, in_cs, cp, in_scale, in_shift, in_relu, gout, gout_cs, gin, gin_cs, accumulate, N, D, H, W);
+    CTU_CHECK_LAUNCH("maxpool2_bwd");
+    return CTU_OK;
+}
+
+extern "C" int ctu_channel_sum_num_blocks(int64_t nvox) {
+    int64_t nb = ceil_div64(nvox, 256);
+    if (nb > MAX_RED_BLOCKS) nb = MAX_RED_BLOCKS;
+    if (nb < 1) nb = 1;
+    return (int)nb;
+}
+
+extern "C" int ctu_channel_sum(const float* x, int cs, int cp, int64_t nvox, float* partials, float* out, int C,
+                               void* stream) {
+    CTU_REQUIRE(x && partials && out, "channel_sum: null pointer");
+    CTU_REQUIRE(cp % 8 == 0 && cp > 0 && cp <= 256 && C <= cp && cs % 4 == 0, "channel_sum: cp=%d", cp);
+    const int nb = ctu_channel_sum_num_blocks(nvox);
+    channel_sum_partial_kernel<<<nb, EW_BLOCK, 0, (hipStream_t)stream>>>(x, cs, cp, nvox, partials);
+    CTU_CHECK_LAUNCH("channel_sum_partial");
+    channel_sum_final_kernel<<<ceil_div(C, 64), 64, 0, (hipStream_t)stream>>>(partials, nb, cp, out, C);
+    CTU_CHECK_LAUNCH("channel_sum_final");
+    return CTU_OK;
+}
+
+extern "C" int ctu_adam_amsgrad(void* const* ptrs, const int64_t* sizes, int n, int64_t max_size, double lr,
+                                double beta1, double beta2, double eps, double weight_decay, int64_t step,
+                                void* stream) {
+    CTU_REQUIRE(ptrs && sizes && n > 0 && step > 0, "adam_amsgrad: bad argument");
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
+    int gx = (int)ceil_div64(max_size, EW_BLOCK);
+    if (gx > 64) gx = 64;
+    if (gx < 1) gx = 1;
+    adam_amsgrad_kernel<<<dim3(gx, n), EW_BLOCK, 0, (hipStream_t)stream>>>(ptrs, sizes, (float)lr, (float)beta1,
+                                                                          (float)beta2, (float)eps, (float)weight_decay,
+                                                                          (float)bc1, (float)sqrt(bc2));
+    CTU_CHECK_LAUNCH("adam_amsgrad");
+    return CTU_OK;
+}

@@ -1,0 +1,418 @@
+// 1x1x1 output head (+softmax/sigmoid/SP re-encoding, NCDHW out) and the fused Dice +
+// cross-entropy loss for gfx950.  HBM-bound streaming kernels, one voxel per thread; reductions
+// are two-stage and deterministic.
+//
+// Replaces: nn.Conv3d(lc_in, out, 1) + F.softmax / torch.sigmoid   ctunet/pytorch/models.py:223-224,255-259,507,538
+//           UNetSP/UNetDO/UNetSPSmall re-encoding                   ctunet/pytorch/models.py:317-330,351-365,374-387
+//           dice_loss                                               ctunet/utilities.py:35-50
+//           softmax + nn.CrossEntropyLoss + argmax loss assembly    ctunet/pytorch/ProblemHandler.py:59-88,228-298
+#include "common.h"
+
+namespace {
+
+constexpr int HB = 256;
+constexpr int MAXCO = 4;
+
+struct HeadP {
+    const float* in;
+    const float* in_scale;
+    const float* in_shift;
+    const float* w;
+    const float* bias;
+    const int32_t* imap;
+    int in_cs, in_relu, Ci, Co, act, head_mode, N;
+    int64_t V;
+};
+
+// activated input channels of one voxel -> logits -> y (post softmax/sigmoid)
+template <int CP>
+__device__ __forceinline__ void head_point(const HeadP& p, const float* sWp, const float* sB, int64_t gv,
+                                           float (&a)[CP], float (&lg)[MAXCO], float (&u)[MAXCO],
+                                           float (&y)[MAXCO]) {
+    const float* src = p.in + (size_t)gv * p.in_cs;
+#pragma unroll
+    for (int qd = 0; qd < CP / 4; ++qd) {
+        float4 v = *reinterpret_cast<const float4*>(src + qd * 4);
+        if (p.in_scale) {
+            const float4 sc = *reinterpret_cast<const float4*>(p.in_scale + qd * 4);
+            const float4 sh = *reinterpret_cast<const float4*>(p.in_shift + qd * 4);
+            v = xform4(v, sc, sh, p.in_relu);
+        }
+        a[qd * 4 + 0] = v.x; a[qd * 4 + 1] = v.y; a[qd * 4 + 2] = v.z; a[qd * 4 + 3] = v.w;
+    }
+#pragma unroll
+    for (int co = 0; co < MAXCO; ++co) {
+        float s = 0.f;
+        if (co < p.Co) {
+            // accumulate in logical channel order like a dot product over Ci
+#pragma unroll
+            for (int c = 0; c < CP; ++c) s = fmaf(a[c], sWp[co * CP + c], s);
+            s += sB[co];
+        }
+        lg[co] = s;
+    }
+    if (p.act & 1) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int co = 0; co < MAXCO; ++co) if (co < p.Co) mx = fmaxf(mx, lg[co]);
+        float den = 0.f;
+#pragma unroll
+        for (int co = 0; co < MAXCO; ++co) { u[co] = (co < p.Co) ? expf(lg[co] - mx) : 0.f; den += u[co]; }
+#pragma unroll
+        for (int co = 0; co < MAXCO; ++co) u[co] /= den;
+    } else {
+#pragma unroll
+        for (int co = 0; co < MAXCO; ++co) u[co] = lg[co];
+    }
+#pragma unroll
+    for (int co = 0; co < MAXCO; ++co) y[co] = (p.act & 2) ? 1.f / (1.f + expf(-u[co])) : u[co];
+}
+
+template <int CP>
+__device__ __forceinline__ void head_load_weights(const HeadP& p, float* sWp, float* sB) {
+    for (int i = threadIdx.x; i < MAXCO * CP; i += blockDim.x) sWp[i] = 0.f;
+    if (threadIdx.x < MAXCO) sB[threadIdx.x] = (threadIdx.x < p.Co && p.bias) ? p.bias[threadIdx.x] : 0.f;
+    __syncthreads();
+    for (int i = threadIdx.x; i < p.Co * p.Ci; i += blockDim.x) {
+        const int co = i / p.Ci, ci = i % p.Ci;
+        sWp[co * CP + (p.imap ? p.imap[ci] : ci)] = p.w[i];
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void softmax2(float a, float b, float& sa, float& sb) {
+    const float mx = fmaxf(a, b);
+    const float ea = expf(a - mx), eb = expf(b - mx);
+    sa = ea / (ea + eb); sb = eb / (ea + eb);
+}
+
+template <int CP>
+__global__ __launch_bounds__(HB) void head_fwd_kernel(HeadP p, float* __restrict__ out0, float* __restrict__ out1) {
+    __shared__ float sWp[MAXCO * CP];
+    __shared__ float sB[MAXCO];
+    head_load_weights<CP>(p, sWp, sB);
+    const int64_t total = (int64_t)p.N * p.V;
+    for (int64_t gv = (int64_t)blockIdx.x * HB + threadIdx.x; gv < total; gv += (int64_t)gridDim.x * HB) {
+        float a[CP], lg[MAXCO], u[MAXCO], y[MAXCO];
+        head_point<CP>(p, sWp, sB, gv, a, lg, u, y);
+        const int64_t n = gv / p.V, v = gv % p.V;
+        if (p.head_mode == 0) {
+#pragma unroll
+            for (int co = 0; co < MAXCO; ++co)
+                if (co < p.Co) out0[(n * p.Co + co) * p.V + v] = y[co];
+        } else {
+            float s0 = y[0], s1 = y[1] + y[2], f0 = 1.f - y[1], f1 = y[1];
+            if (p.head_mode == 2) {
+                softmax2(s0, s1, s0, s1);
+                softmax2(f0, f1, f0, f1);
+            }
+            out0[(n * 2 + 0) * p.V + v] = s0; out0[(n * 2 + 1) * p.V + v] = s1;
+            out1[(n * 2 + 0) * p.V + v] = f0; out1[(n * 2 + 1) * p.V + v] = f1;
+        }
+    }
+}
+
+// partial layout per block: [MAXCO*CP dW][MAXCO db]
+template <int CP>
+__global__ __launch_bounds__(HB) void head_bwd_kernel(HeadP p, const float* __restrict__ g0,
+                                                      const float* __restrict__ g1, float* __restrict__ gin,
+                                                      int gin_cs, float* __restrict__ partials) {
+    __shared__ float sWp[MAXCO * CP];
+    __shared__ float sB[MAXCO];
+    __shared__ float sRed[HB / 64][MAXCO * CP + MAXCO];
+    head_load_weights<CP>(p, sWp, sB);
+    float dw[MAXCO][CP], db[MAXCO];
+#pragma unroll
+    for (int co = 0; co < MAXCO; ++co) {
+        db[co] = 0.f;
+#pragma unroll
+        for (int c = 0; c < CP; ++c) dw[co][c] = 0.f;
+    }
+    const int64_t total = (int64_t)p.N * p.V;
+    for (int64_t gv = (int64_t)blockIdx.x * HB + threadIdx.x; gv < total; gv += (int64_t)gridDim.x * HB) {
+        float a[CP], lg[MAXCO], u[MAXCO], y[MAXCO], gy[MAXCO];
+        head_point<CP>(p, sWp, sB, gv, a, lg, u, y);
+        const int64_t n = gv / p.V, v = gv % p.V;
+        if (p.head_mode == 0) {
+#pragma unroll
+            for (int co = 0; co < MAXCO; ++co) gy[co] = (co < p.Co) ? g0[(n * p.Co + co) * p.V + v] : 0.f;
+        } else {
+            float a0 = g0[(n * 2 + 0) * p.V + v], a1 = g0[(n * 2 + 1) * p.V + v];
+            float b0 = g1[(n * 2 + 0) * p.V + v], b1 = g1[(n * 2 + 1) * p.V + v];
+            if (p.head_mode == 2) {
+                float s0, s1, f0, f1;
+                softmax2(y[0], y[1] + y[2], s0, s1);
+                softmax2(1.f - y[1], y[1], f0, f1);
+                const float ds = a0 * s0 + a1 * s1, df = b0 * f0 + b1 * f1;
+                a0 = s0 * (a0 - ds); a1 = s1 * (a1 - ds);
+                b0 = f0 * (b0 - df); b1 = f1 * (b1 - df);
+            }
+            gy[0] = a0; gy[1] = a1 - b0 + b1; gy[2] = a1; gy[3] = 0.f;
+        }
+        float gu[MAXCO], gl[MAXCO];
+#pragma unroll
+        for (int co = 0; co < MAXCO; ++co) gu[co] = (p.act & 2) ? gy[co] * y[co] * (1.f - y[co]) : gy[co];
+        if (p.act & 1) {
+            float dot = 0.f;
+#pragma unroll
+            for (int co = 0; co < MAXCO; ++co) if (co < p.Co) dot += gu[co] * u[co];
+#pragma unroll
+            for (int co = 0; co < MAXCO; ++co) gl[co] = (co < p.Co) ? u[co] * (gu[co] - dot) : 0.f;
+        } else {
+#pragma unroll
+            for (int co = 0; co < MAXCO; ++co) gl[co] = (co < p.Co) ? gu[co] : 0.f;
+        }
+        float* gdst = gin + (size_t)gv * gin_cs;
+#pragma unroll
+        for (int qd = 0; qd < CP / 4; ++qd) {
+            float4 o;
+            float* op = &o.x;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float s = 0.f;
+#pragma unroll
+                for (int co = 0; co < MAXCO; ++co) s = fmaf(gl[co], sWp[co * CP + qd * 4 + j], s);
+                op[j] = s;
+            }
+            *reinterpret_cast<float4*>(gdst + qd * 4) = o;
+        }
+#pragma unroll
+        for (int co = 0; co < MAXCO; ++co) {
+            db[co] += gl[co];
+#pragma unroll
+            for (int c = 0; c < CP; ++c) dw[co][c] = fmaf(gl[co], a[c], dw[co][c]);
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int co = 0; co < MAXCO; ++co) {
+#pragma unroll
+        for (int c = 0; c < CP; ++c) {
+            const float s = wave_sum(dw[co][c]);
+            if (lane == 0) sRed[wave][co * CP + c] = s;
+        }
+        const float s = wave_sum(db[co]);
+        if (lane == 0) sRed[wave][MAXCO * CP + co] = s;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < MAXCO * CP + MAXCO; i += HB) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < HB / 64; ++w) s += sRed[w][i];
+        partials[(size_t)blockIdx.x * (MAXCO * CP + MAXCO) + i] = s;
+    }
+}
+
+template <int CP>
+__global__ void head_bwd_final_kernel(const float* __restrict__ partials, int nb, int Ci, int Co,
+                                      const int32_t* __restrict__ imap, float* __restrict__ dw,
+                                      float* __restrict__ db) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int row = MAXCO * CP + MAXCO;
+    if (i < Co * Ci) {
+        const int co = i / Ci, ci = i % Ci;
+        const int col = co * CP + (imap ? imap[ci] : ci);
+        double s = 0.0;
+        for (int b = 0; b < nb; ++b) s += (double)partials[(size_t)b * row + col];
+        dw[i] = (float)s;
+    } else if (i < Co * Ci + Co) {
+        const int co = i - Co * Ci;
+        double s = 0.0;
+        for (int b = 0; b < nb; ++b) s += (double)partials[(size_t)b * row + MAXCO * CP + co];
+        db[co] = (float)s;
+    }
+}
+
+inline int head_blocks(int64_t total) {
+    int64_t nb = ceil_div64(total, HB);
+    if (nb > 2048) nb = 2048;
+    return (int)(nb < 1 ? 1 : nb);
+}
+
+// ------------------------------------------------------------------ loss
+constexpr int LOSS_BX = 256;   // blocks per batch item
+
+__global__ __launch_bounds__(HB) void loss_fwd_kernel(const float* __restrict__ pred, const float* __restrict__ tgt,
+                                                      int64_t V, int dice_softmax, float* __restrict__ ws) {
+    const int n = blockIdx.y;
+    const float* p0 = pred + (size_t)n * 2 * V;
+    const float* p1 = p0 + V;
+    const float* t0 = tgt + (size_t)n * 2 * V;
+    const float* t1 = t0 + V;
+    float ce = 0.f, num = 0.f, d1 = 0.f, d2 = 0.f;
+    for (int64_t v = (int64_t)blockIdx.x * HB + threadIdx.x; v < V; v += (int64_t)gridDim.x * HB) {
+        const float a = p0[v], b = p1[v], ta = t0[v], tb = t1[v];
+        const float mx = fmaxf(a, b);
+        const float ea = expf(a - mx), eb = expf(b - mx);
+        const float lse = mx + logf(ea + eb);
+        ce += lse - ((tb > ta) ? b : a);          // argmax: first index wins ties
+        float pa = a, pb = b;
+        if (dice_softmax) { pa = ea / (ea + eb); pb = eb / (ea + eb); }
+        num += pa * ta + pb * tb;
+        d1 += pa * pa + pb * pb;
+        d2 += ta * ta + tb * tb;
+    }
+    __shared__ float red[HB / 64][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    ce = wave_sum(ce); num = wave_sum(num); d1 = wave_sum(d1); d2 = wave_sum(d2);
+    if (lane == 0) { red[wave][0] = ce; red[wave][1] = num; red[wave][2] = d1; red[wave][3] = d2; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < HB / 64; ++w) s += red[w][threadIdx.x];
+        ws[((size_t)n * gridDim.x + blockIdx.x) * 4 + threadIdx.x] = s;
+    }
+}
+
+// ws tail: [N][2] = (num+eps, den+eps) per item, used by backward
+__global__ void loss_final_kernel(float* __restrict__ ws, int N, int nbx, int64_t V, float ce_lambda,
+                                  float dice_lambda, float* __restrict__ terms) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double eps = 0.0000001;
+    double ce = 0.0, dsum = 0.0;
+    float* tail = ws + (size_t)N * nbx * 4;
+    for (int n = 0; n < N; ++n) {
+        double c = 0.0, num = 0.0, d1 = 0.0, d2 = 0.0;
+        for (int b = 0; b < nbx; ++b) {
+            const float* r = ws + ((size_t)n * nbx + b) * 4;
+            c += r[0]; num += r[1]; d1 += r[2]; d2 += r[3];
+        }
+        ce += c;
+        dsum += (num + eps) / (d1 + d2 + eps);
+        tail[n * 2 + 0] = (float)(num + eps);
+        tail[n * 2 + 1] = (float)(d1 + d2 + eps);
+    }
+    terms[0] = ce_lambda != 0.f ? (float)(ce_lambda * ce / ((double)N * (double)V)) : 0.f;
+    terms[1] = dice_lambda != 0.f ? (float)(dice_lambda * (1.0 - 2.0 * dsum / N)) : 0.f;
+}
+
+__global__ __launch_bounds__(HB) void loss_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ tgt,
+                                                      int N, int64_t V, float ce_lambda, float dice_lambda,
+                                                      int dice_softmax, const float* __restrict__ tail,
+                                                      const float* __restrict__ gscale, float* __restrict__ gpred,
+                                                      int accumulate) {
+    const int n = blockIdx.y;
+    const float gs = gscale ? gscale[0] : 1.f;
+    const float kce = gs * ce_lambda / ((float)N * (float)V);
+    const float nume = tail[n * 2 + 0], dene = tail[n * 2 + 1];
+    const float kd = gs * dice_lambda * (-2.f / (float)N);
+    const float kd_t = kd / dene, kd_p = kd * nume * 2.f / (dene * dene);
+    const size_t base = (size_t)n * 2 * V;
+    for (int64_t v = (int64_t)blockIdx.x * HB + threadIdx.x; v < V; v += (int64_t)gridDim.x * HB) {
+        const float a = pred[base + v], b = pred[base + V + v];
+        const float ta = tgt[base + v], tb = tgt[base + V + v];
+        const float mx = fmaxf(a, b);
+        const float ea = expf(a - mx), eb = expf(b - mx);
+        const float sa = ea / (ea + eb), sb = eb / (ea + eb);
+        const bool cls1 = tb > ta;
+        float ga = kce * (sa - (cls1 ? 0.f : 1.f));
+        float gb = kce * (sb - (cls1 ? 1.f : 0.f));
+        if (dice_lambda != 0.f) {
+            const float pa = dice_softmax ? sa : a, pb = dice_softmax ? sb : b;
+            float da = kd_t * ta - kd_p * pa, db = kd_t * tb - kd_p * pb;
+            if (dice_softmax) {
+                const float dot = da * sa + db * sb;
+                da = sa * (da - dot); db = sb * (db - dot);
+            }
+            ga += da; gb += db;
+        }
+        if (accumulate) { ga += gpred[base + v]; gb += gpred[base + V + v]; }
+        gpred[base + v] = ga;
+        gpred[base + V + v] = gb;
+    }
+}
+
+}  // namespace
+
+// =================================================================== C ABI
+static int fill_head(HeadP& p, const float* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
+                     int in_relu, const float* w, const float* bias, const int32_t* imap, int Ci, int Co, int act,
+                     int head_mode, int N, int64_t V, const char* name) {
+    CTU_REQUIRE(in && w, "%s: null pointer", name);
+    CTU_REQUIRE(cin_p == 8 || cin_p == 16 || cin_p == 32, "%s: cin_p=%d unsupported (8, 16 or 32)", name, cin_p);
+    CTU_REQUIRE(Co >= 1 && Co <= MAXCO && Ci >= 1 && Ci <= cin_p, "%s: Co=%d Ci=%d", name, Co, Ci);
+    CTU_REQUIRE(head_mode == 0 || Co == 3, "%s: SP re-encoding needs 3 output channels", name);
+    CTU_REQUIRE(head_mode >= 0 && head_mode <= 2, "%s: head_mode=%d", name, head_mode);
+    CTU_REQUIRE(in_cs >= cin_p && in_cs % 4 == 0, "%s: bad stride", name);
+    CTU_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "%s: scale/shift must come together", name);
+    p.in = in; p.in_scale = in_scale; p.in_shift = in_shift; p.w = w; p.bias = bias; p.imap = imap;
+    p.in_cs = in_cs; p.in_relu = in_relu; p.Ci = Ci; p.Co = Co; p.act = act; p.head_mode = head_mode; p.N = N; p.V = V;
+    return CTU_OK;
+}
+
+extern "C" int ctu_head_fwd(const float* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
+                            int in_relu, const float* w, const float* bias, const int32_t* imap, int Ci, int Co, int act,
+                            int head_mode, float* out0, float* out1, int N, int64_t nvox_per_item, void* stream) {
+    HeadP p;
+    int rc = fill_head(p, in, in_cs, cin_p, in_scale, in_shift, in_relu, w, bias, imap, Ci, Co, act, head_mode, N,
+                       nvox_per_item, "head_fwd");
+    if (rc != CTU_OK) return rc;
+    CTU_REQUIRE(out0 && (head_mode == 0 || out1), "head_fwd: null output");
+    const int nb = head_blocks((int64_t)N * nvox_per_item);
+    hipStream_t st = (hipStream_t)stream;
+    if (cin_p == 8) head_fwd_kernel<8><<<nb, HB, 0, st>>>(p, out0, out1);
+    else if (cin_p == 16) head_fwd_kernel<16><<<nb, HB, 0, st>>>(p, out0, out1);
+    else head_fwd_kernel<32><<<nb, HB, 0, st>>>(p, out0, out1);
+    CTU_CHECK_LAUNCH("head_fwd");
+    return CTU_OK;
+}
+
+extern "C" size_t ctu_head_bwd_ws_floats(int N, int64_t nvox_per_item, int cin_p, int Co) {
+    (void)Co;
+    return (size_t)head_blocks((int64_t)N * nvox_per_item) * (MAXCO * cin_p + MAXCO);
+}
+
+extern "C" int ctu_head_bwd(const float* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
+                            int in_relu, const float* w, const float* bias, const int32_t* imap, int Ci, int Co, int act,
+                            int head_mode, const float* g0, const float* g1, float* gin, int gin_cs, float* dw,
+                            float* db, float* ws, int N, int64_t nvox_per_item, void* stream) {
+    HeadP p;
+    int rc = fill_head(p, in, in_cs, cin_p, in_scale, in_shift, in_relu, w, bias, imap, Ci, Co, act, head_mode, N,
+                       nvox_per_item, "head_bwd");
+    if (rc != CTU_OK) return rc;
+    CTU_REQUIRE(g0 && (head_mode == 0 || g1) && gin && dw && db && ws, "head_bwd: null pointer");
+    CTU_REQUIRE(gin_cs >= cin_p && gin_cs % 4 == 0, "head_bwd: bad gin stride");
+    const int nb = head_blocks((int64_t)N * nvox_per_item);
+    hipStream_t st = (hipStream_t)stream;
+    const int nfin = ceil_div(Co * Ci + Co, 64);
+    if (cin_p == 8) {
+        head_bwd_kernel<8><<<nb, HB, 0, st>>>(p, g0, g1, gin, gin_cs, ws);
+        head_bwd_final_kernel<8><<<nfin, 64, 0, st>>>(ws, nb, Ci, Co, imap, dw, db);
+    } else if (cin_p == 16) {
+        head_bwd_kernel<16><<<nb, HB, 0, st>>>(p, g0, g1, gin, gin_cs, ws);
+        head_bwd_final_kernel<16><<<nfin, 64, 0, st>>>(ws, nb, Ci, Co, imap, dw, db);
+    } else {
+        head_bwd_kernel<32><<<nb, HB, 0, st>>>(p, g0, g1, gin, gin_cs, ws);
+        head_bwd_final_kernel<32><<<nfin, 64, 0, st>>>(ws, nb, Ci, Co, imap, dw, db);
+    }
+    CTU_CHECK_LAUNCH("head_bwd");
+    return CTU_OK;
+}
+
+extern "C" size_t ctu_loss_ws_floats(int N, int64_t V) {
+    (void)V;
+    return (size_t)N * LOSS_BX * 4 + (size_t)N * 2;
+}
+
+extern "C" int ctu_loss_fwd(const float* pred, const float* target, int N, int64_t V, float ce_lambda,
+                            float dice_lambda, int dice_softmax, float* terms, float* ws, void* stream) {
+    CTU_REQUIRE(pred && target && terms && ws && N > 0 && V > 0, "loss_fwd: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    loss_fwd_kernel<<<dim3(LOSS_BX, N), HB, 0, st>>>(pred, target, V, dice_softmax, ws);
+    CTU_CHECK_LAUNCH("loss_fwd");
+    loss_final_kernel<<<1, 64, 0, st>>>(ws, N, LOSS_BX, V, ce_lambda, dice_lambda, terms);
+    CTU_CHECK_LAUNCH("loss_final");
+    return CTU_OK;
+}
+
+extern "C" int ctu_loss_bwd(const float* pred, const float* target, int N, int64_t V, float ce_lambda,
+                            float dice_lambda, int dice_softmax, const float* ws, const float* gscale, float* gpred,
+                            int accumulate, void* stream) {
+    CTU_REQUIRE(pred && target && ws && gpred && N > 0 && V > 0, "loss_bwd: bad argument");
+    loss_bwd_kernel<<<dim3(LOSS_BX, N), HB, 0, (hipStream_t)stream>>>(pred, target, N, V, ce_lambda, dice_lambda,
+                                                                      dice_softmax, ws + (size_t)N * LOSS_BX * 4,
+                                                                      gscale, gpred, accumulate);
+    CTU_CHECK_LAUNCH("loss_bwd");
+    return CTU_OK;
+}

@@ -1,0 +1,91 @@
+"""ctypes binding of libctunet_hip.so (the C ABI declared in include/ctunet_hip.h).
+
+There is no fallback: if the library is missing or a symbol cannot be resolved the import of
+the product path fails with a clear message.  Build with ``python __graft_entry__.py`` or
+``make -C ct-unet_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libctunet_hip.so")
+
+P = C.c_void_p          # device pointer / stream
+I = C.c_int
+L = C.c_int64
+F = C.c_float
+D = C.c_double
+Z = C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/ctunet_hip.h one to one
+SIGNATURES = {
+    "ctu_last_error": (C.c_char_p, []),
+    "ctu_abi_version": (I, []),
+    "ctu_arch": (C.c_char_p, []),
+    "ctu_ncdhw_to_ndhwc": (I, [P, P, I, I, I, I, I, I, I, P]),
+    "ctu_ndhwc_to_ncdhw": (I, [P, P, I, I, I, I, I, I, P]),
+    "ctu_conv3d_packed_floats": (Z, [I, I, I]),
+    "ctu_conv3d_num_blocks": (I, [I, I, I, I]),
+    "ctu_pack_conv3d_weight": (I, [P, P, I, I, I, P, I, I, I, P]),
+    "ctu_conv3d_fwd": (I, [P, I, I, P, P, I, P, P, P, I, I, P, I, I, I, I, I, P]),
+    "ctu_conv3d_wgrad_ws_floats": (Z, [I, I, I, I, I, I, I]),
+    "ctu_conv3d_wgrad": (I, [P, I, I, P, P, I, P, I, I, P, P, I, I, P, P, I, I, I, I, I, P]),
+    "ctu_bn_finalize": (I, [P, I, I, I, D, P, P, P, P, F, F, I, P, P, P, P, P]),
+    "ctu_bn_eval_affine": (I, [P, P, P, P, F, I, I, P, P, P]),
+    "ctu_bn_bwd_num_blocks": (I, [L]),
+    "ctu_bn_relu_bwd_reduce": (I, [P, I, P, I, I, P, P, P, P, L, P, P]),
+    "ctu_bn_bwd_finalize": (I, [P, I, I, I, D, P, P, P, P, P, P]),
+    "ctu_bn_relu_bwd_apply": (I, [P, I, P, I, I, P, P, P, P, P, L, P]),
+    "ctu_maxpool2_fwd": (I, [P, I, I, P, P, I, P, I, I, I, I, I, P]),
+    "ctu_maxpool2_bwd": (I, [P, I, I, P, P, I, P, I, P, I, I, I, I, I, I, P]),
+    "ctu_convt_packed_floats": (Z, [I, I]),
+    "ctu_pack_convt_weight": (I, [P, P, I, I, P, I, I, I, P]),
+    "ctu_convt2_fwd": (I, [P, I, I, P, P, I, P, P, P, I, I, I, I, I, I, P]),
+    "ctu_convt2_bwd_data": (I, [P, I, I, P, P, I, I, I, I, I, I, P]),
+    "ctu_convt2_wgrad_ws_floats": (Z, [I, I, I, I, I, I]),
+    "ctu_convt2_wgrad": (I, [P, I, I, P, P, I, P, I, I, P, P, I, I, P, P, I, I, I, I, P]),
+    "ctu_head_fwd": (I, [P, I, I, P, P, I, P, P, P, I, I, I, I, P, P, I, L, P]),
+    "ctu_head_bwd_ws_floats": (Z, [I, L, I, I]),
+    "ctu_head_bwd": (I, [P, I, I, P, P, I, P, P, P, I, I, I, I, P, P, P, I, P, P, P, I, L, P]),
+    "ctu_loss_ws_floats": (Z, [I, L]),
+    "ctu_loss_fwd": (I, [P, P, I, L, F, F, I, P, P, P]),
+    "ctu_loss_bwd": (I, [P, P, I, L, F, F, I, P, P, P, I, P]),
+    "ctu_channel_sum_num_blocks": (I, [L]),
+    "ctu_channel_sum": (I, [P, I, I, L, P, P, I, P]),
+    "ctu_adam_amsgrad": (I, [P, P, I, L, D, D, D, D, D, L, P]),
+}
+
+_lib = None
+
+
+class CtuError(RuntimeError):
+    """A libctunet_hip.so entry point returned a non-zero status."""
+
+
+def load() -> C.CDLL:
+    """Load the shared library once and attach the prototypes.  Raises if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the MI355X kernels are not built. Run `python __graft_entry__.py` "
+            "(or `make -C ct-unet_amd/csrc`). There is no CPU fallback for this path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise ImportError(f"{LIB_PATH} does not export {name}; rebuild the library") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = load().ctu_last_error().decode("utf-8", "replace")
+        raise CtuError(f"{what} failed (status {status}): {msg}")

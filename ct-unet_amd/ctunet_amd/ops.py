@@ -1,0 +1,329 @@
+"""Thin tensor-level wrappers over the C ABI (include/ctunet_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; every computation is a call into
+libctunet_hip.so.  All functions require CUDA (ROCm) tensors and raise otherwise -- there is no
+CPU path.
+
+``CL`` describes a channels-last activation: a slice ``[c0, c0+cp)`` of the channels of a
+contiguous ``[N, D, H, W, cs]`` fp32 buffer plus its lazy-BN transform (``scale``/``shift`` over
+the slice, ``relu``): consumers see ``relu(raw * scale + shift)``.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+
+def pad8(c: int) -> int:
+    return (c + 7) // 8 * 8
+
+
+def _need_cuda(t: torch.Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f"ctunet_amd: {name} must live on the GPU (MI355X); this path has no CPU fallback")
+    if t.dtype != torch.float32 and t.dtype != torch.int32:
+        raise RuntimeError(f"ctunet_amd: {name} must be float32, got {t.dtype}")
+
+
+def _ptr(t: Optional[torch.Tensor], off_floats: int = 0):
+    if t is None:
+        return None
+    return t.data_ptr() + 4 * off_floats
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+@dataclass
+class CL:
+    buf: torch.Tensor                       # [N, D, H, W, cs] contiguous fp32
+    c0: int = 0
+    cp: int = 0                             # padded channels of this slice (multiple of 8)
+    scale: Optional[torch.Tensor] = None    # [cp] (already sliced) or None
+    shift: Optional[torch.Tensor] = None
+    relu: bool = False
+
+    def __post_init__(self):
+        if self.cp == 0:
+            self.cp = self.buf.shape[-1] - self.c0
+        assert self.buf.dim() == 5 and self.buf.is_contiguous()
+        assert self.cp % 8 == 0 and self.c0 % 4 == 0 and self.c0 + self.cp <= self.buf.shape[-1]
+
+    @property
+    def cs(self) -> int:
+        return self.buf.shape[-1]
+
+    @property
+    def dims(self) -> Tuple[int, int, int, int]:
+        n, d, h, w, _ = self.buf.shape
+        return n, d, h, w
+
+    @property
+    def nvox(self) -> int:
+        n, d, h, w = self.dims
+        return n * d * h * w
+
+    @property
+    def ptr(self):
+        return _ptr(self.buf, self.c0)
+
+    def slice(self, c0: int, cp: int) -> "CL":
+        sc = None if self.scale is None else self.scale[c0:c0 + cp]
+        sh = None if self.shift is None else self.shift[c0:c0 + cp]
+        return CL(self.buf, self.c0 + c0, cp, sc, sh, self.relu)
+
+    def raw(self) -> "CL":
+        return CL(self.buf, self.c0, self.cp)
+
+    def with_xf(self, scale, shift, relu=True) -> "CL":
+        return CL(self.buf, self.c0, self.cp, scale, shift, relu)
+
+
+def new_cl(n, d, h, w, cs, device, zero=False) -> torch.Tensor:
+    f = torch.zeros if zero else torch.empty
+    return f((n, d, h, w, cs), dtype=torch.float32, device=device)
+
+
+# ---------------------------------------------------------------------------- layout
+def ncdhw_to_cl(x: torch.Tensor, cp: Optional[int] = None) -> CL:
+    _need_cuda(x, "input")
+    x = x.contiguous()
+    n, c, d, h, w = x.shape
+    cp = cp or pad8(c)
+    out = new_cl(n, d, h, w, cp, x.device)
+    lib = _lib.load()
+    _lib.check(lib.ctu_ncdhw_to_ndhwc(x.data_ptr(), out.data_ptr(), n, c, d, h, w, cp, cp, _stream()), "ncdhw_to_ndhwc")
+    return CL(out, 0, cp)
+
+
+def cl_to_ncdhw(a: CL, c: int) -> torch.Tensor:
+    n, d, h, w = a.dims
+    out = torch.empty((n, c, d, h, w), dtype=torch.float32, device=a.buf.device)
+    lib = _lib.load()
+    _lib.check(lib.ctu_ndhwc_to_ncdhw(a.ptr, out.data_ptr(), n, c, d, h, w, a.cs, _stream()), "ndhwc_to_ncdhw")
+    return out
+
+
+# ---------------------------------------------------------------------------- conv3d
+def pack_conv_w(w: torch.Tensor, imap: Optional[torch.Tensor], rin_p: int, nout_p: int, mode: int) -> torch.Tensor:
+    _need_cuda(w, "conv weight")
+    co, ci, k = w.shape[0], w.shape[1], w.shape[2]
+    lib = _lib.load()
+    n = lib.ctu_conv3d_packed_floats(k, rin_p, nout_p)
+    wp = torch.empty(n, dtype=torch.float32, device=w.device)
+    _lib.check(lib.ctu_pack_conv3d_weight(w.contiguous().data_ptr(), wp.data_ptr(), co, ci, k, _ptr(imap), rin_p,
+                                          nout_p, mode, _stream()), "pack_conv3d_weight")
+    return wp
+
+
+def conv_num_blocks(dims) -> int:
+    n, d, h, w = dims
+    return _lib.load().ctu_conv3d_num_blocks(n, d, h, w)
+
+
+def conv3d_fwd(x: CL, wp: torch.Tensor, bias_p: Optional[torch.Tensor], out: CL, k: int,
+               stats: Optional[torch.Tensor] = None) -> None:
+    n, d, h, w = x.dims
+    assert out.dims == x.dims
+    lib = _lib.load()
+    _lib.check(lib.ctu_conv3d_fwd(x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), wp.data_ptr(),
+                                  _ptr(bias_p), out.ptr, out.cs, out.cp, _ptr(stats), n, d, h, w, k, _stream()),
+               "conv3d_fwd")
+
+
+def conv3d_wgrad(x: CL, g: CL, co: int, ci: int, k: int, imap: Optional[torch.Tensor], ws: torch.Tensor,
+                 want_bias: bool) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    n, d, h, w = x.dims
+    lib = _lib.load()
+    need = lib.ctu_conv3d_wgrad_ws_floats(n, d, h, w, k, x.cp, g.cp)
+    assert ws.numel() >= need, (ws.numel(), need)
+    dw = torch.empty((co, ci, k, k, k), dtype=torch.float32, device=x.buf.device)
+    db = torch.empty(co, dtype=torch.float32, device=x.buf.device) if want_bias else None
+    _lib.check(lib.ctu_conv3d_wgrad(x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), g.ptr, g.cs, g.cp,
+                                    dw.data_ptr(), _ptr(db), co, ci, _ptr(imap), ws.data_ptr(), n, d, h, w, k,
+                                    _stream()), "conv3d_wgrad")
+    return dw, db
+
+
+def conv3d_wgrad_ws(dims, k, cin_p, cout_p) -> int:
+    n, d, h, w = dims
+    return _lib.load().ctu_conv3d_wgrad_ws_floats(n, d, h, w, k, cin_p, cout_p)
+
+
+# ---------------------------------------------------------------------------- batch norm
+def bn_finalize(stats, nblocks, c, cp, count, gamma, beta, rmean, rvar, momentum, eps, n_updates):
+    dev = stats.device
+    vec = torch.empty((4, cp), dtype=torch.float32, device=dev)     # scale, shift, mean, invstd
+    lib = _lib.load()
+    _lib.check(lib.ctu_bn_finalize(stats.data_ptr(), nblocks, c, cp, float(count), gamma.data_ptr(), beta.data_ptr(),
+                                   _ptr(rmean), _ptr(rvar), momentum, eps, n_updates, vec[0].data_ptr(),
+                                   vec[1].data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(), _stream()), "bn_finalize")
+    return vec
+
+
+def bn_eval_affine(gamma, beta, rmean, rvar, eps, c, cp):
+    vec = torch.empty((2, cp), dtype=torch.float32, device=gamma.device)
+    lib = _lib.load()
+    _lib.check(lib.ctu_bn_eval_affine(gamma.data_ptr(), beta.data_ptr(), rmean.data_ptr(), rvar.data_ptr(), eps, c, cp,
+                                      vec[0].data_ptr(), vec[1].data_ptr(), _stream()), "bn_eval_affine")
+    return vec
+
+
+def bn_relu_bwd(y: CL, ga: CL, vec: torch.Tensor, gamma: torch.Tensor, c: int, partials: torch.Tensor):
+    """In place: ga <- gradient w.r.t. the raw conv output y.  Returns (dgamma, dbeta)."""
+    lib = _lib.load()
+    nvox = y.nvox
+    cp = y.cp
+    nb = lib.ctu_bn_bwd_num_blocks(nvox)
+    assert partials.numel() >= nb * 2 * cp
+    sc, sh, mu, istd = (vec[i].data_ptr() for i in range(4))
+    st = _stream()
+    _lib.check(lib.ctu_bn_relu_bwd_reduce(y.ptr, y.cs, ga.ptr, ga.cs, cp, sc, sh, mu, istd, nvox, partials.data_ptr(),
+                                          st), "bn_relu_bwd_reduce")
+    dgb = torch.empty((2, c), dtype=torch.float32, device=y.buf.device)
+    coef = torch.empty((3, cp), dtype=torch.float32, device=y.buf.device)
+    _lib.check(lib.ctu_bn_bwd_finalize(partials.data_ptr(), nb, c, cp, float(nvox), gamma.data_ptr(), istd,
+                                       dgb[0].data_ptr(), dgb[1].data_ptr(), coef.data_ptr(), st), "bn_bwd_finalize")
+    _lib.check(lib.ctu_bn_relu_bwd_apply(y.ptr, y.cs, ga.ptr, ga.cs, cp, sc, sh, mu, istd, coef.data_ptr(), nvox, st),
+               "bn_relu_bwd_apply")
+    return dgb[0], dgb[1]
+
+
+def bn_bwd_partials_floats(nvox: int, cp: int) -> int:
+    return _lib.load().ctu_bn_bwd_num_blocks(nvox) * 2 * cp
+
+
+# ---------------------------------------------------------------------------- pool
+def maxpool_fwd(x: CL, out: CL) -> None:
+    n, d, h, w = x.dims
+    lib = _lib.load()
+    _lib.check(lib.ctu_maxpool2_fwd(x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), out.ptr, out.cs,
+                                    n, d, h, w, _stream()), "maxpool2_fwd")
+
+
+def maxpool_bwd(x: CL, gout: CL, gin: CL, accumulate: bool) -> None:
+    n, d, h, w = x.dims
+    lib = _lib.load()
+    _lib.check(lib.ctu_maxpool2_bwd(x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), gout.ptr, gout.cs,
+                                    gin.ptr, gin.cs, int(accumulate), n, d, h, w, _stream()), "maxpool2_bwd")
+
+
+# ---------------------------------------------------------------------------- conv transpose
+def pack_convt_w(w: torch.Tensor, imap, rin_p: int, nout_p: int, mode: int) -> torch.Tensor:
+    _need_cuda(w, "convT weight")
+    ci, co = w.shape[0], w.shape[1]
+    lib = _lib.load()
+    wp = torch.empty(lib.ctu_convt_packed_floats(rin_p, nout_p), dtype=torch.float32, device=w.device)
+    _lib.check(lib.ctu_pack_convt_weight(w.contiguous().data_ptr(), wp.data_ptr(), ci, co, _ptr(imap), rin_p, nout_p,
+                                         mode, _stream()), "pack_convt_weight")
+    return wp
+
+
+def convt_fwd(x: CL, wp: torch.Tensor, bias_p: Optional[torch.Tensor], out: CL) -> None:
+    n, d, h, w = x.dims
+    lib = _lib.load()
+    _lib.check(lib.ctu_convt2_fwd(x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), wp.data_ptr(),
+                                  _ptr(bias_p), out.ptr, out.cs, out.cp, n, d, h, w, _stream()), "convt2_fwd")
+
+
+def convt_bwd_data(gout: CL, wp: torch.Tensor, gin: CL) -> None:
+    n, d, h, w = gin.dims
+    lib = _lib.load()
+    _lib.check(lib.ctu_convt2_bwd_data(gout.ptr, gout.cs, gout.cp, wp.data_ptr(), gin.ptr, gin.cs, gin.cp, n, d, h, w,
+                                       _stream()), "convt2_bwd_data")
+
+
+def convt_wgrad(x: CL, g: CL, ci: int, co: int, imap, ws: torch.Tensor):
+    n, d, h, w = x.dims
+    lib = _lib.load()
+    assert ws.numel() >= lib.ctu_convt2_wgrad_ws_floats(n, d, h, w, x.cp, g.cp)
+    dw = torch.empty((ci, co, 2, 2, 2), dtype=torch.float32, device=x.buf.device)
+    db = torch.empty(co, dtype=torch.float32, device=x.buf.device)
+    _lib.check(lib.ctu_convt2_wgrad(x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), g.ptr, g.cs, g.cp,
+                                    dw.data_ptr(), db.data_ptr(), ci, co, _ptr(imap), ws.data_ptr(), n, d, h, w,
+                                    _stream()), "convt2_wgrad")
+    return dw, db
+
+
+def convt_wgrad_ws(dims, cin_p, cout_p) -> int:
+    n, d, h, w = dims
+    return _lib.load().ctu_convt2_wgrad_ws_floats(n, d, h, w, cin_p, cout_p)
+
+
+# ---------------------------------------------------------------------------- head
+def head_fwd(x: CL, w: torch.Tensor, b: torch.Tensor, imap, act: int, head_mode: int):
+    n, d, h, w_ = x.dims
+    co, ci = w.shape[0], w.shape[1]
+    v = d * h * w_
+    dev = x.buf.device
+    lib = _lib.load()
+    if head_mode == 0:
+        out0 = torch.empty((n, co, d, h, w_), dtype=torch.float32, device=dev)
+        out1 = None
+    else:
+        out0 = torch.empty((n, 2, d, h, w_), dtype=torch.float32, device=dev)
+        out1 = torch.empty((n, 2, d, h, w_), dtype=torch.float32, device=dev)
+    _lib.check(lib.ctu_head_fwd(x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), w.data_ptr(),
+                                b.data_ptr(), _ptr(imap), ci, co, act, head_mode, out0.data_ptr(), _ptr(out1), n, v,
+                                _stream()), "head_fwd")
+    return out0, out1
+
+
+def head_bwd(x: CL, w: torch.Tensor, b: torch.Tensor, imap, act: int, head_mode: int, g0: torch.Tensor,
+             g1: Optional[torch.Tensor], gin: CL):
+    n, d, h, w_ = x.dims
+    co, ci = w.shape[0], w.shape[1]
+    v = d * h * w_
+    dev = x.buf.device
+    lib = _lib.load()
+    ws = torch.empty(lib.ctu_head_bwd_ws_floats(n, v, x.cp, co), dtype=torch.float32, device=dev)
+    dw = torch.empty_like(w)
+    db = torch.empty_like(b)
+    _lib.check(lib.ctu_head_bwd(x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), w.data_ptr(),
+                                b.data_ptr(), _ptr(imap), ci, co, act, head_mode, g0.data_ptr(), _ptr(g1), gin.ptr,
+                                gin.cs, dw.data_ptr(), db.data_ptr(), ws.data_ptr(), n, v, _stream()), "head_bwd")
+    return dw, db
+
+
+# ---------------------------------------------------------------------------- loss
+def loss_fwd(pred: torch.Tensor, target: torch.Tensor, ce_lambda: float, dice_lambda: float, dice_softmax: bool):
+    _need_cuda(pred, "prediction")
+    _need_cuda(target, "target")
+    assert pred.shape == target.shape and pred.shape[1] == 2, "loss kernel handles 2-channel maps"
+    pred, target = pred.contiguous(), target.contiguous()
+    n = pred.shape[0]
+    v = pred[0, 0].numel()
+    lib = _lib.load()
+    ws = torch.empty(lib.ctu_loss_ws_floats(n, v), dtype=torch.float32, device=pred.device)
+    terms = torch.empty(2, dtype=torch.float32, device=pred.device)
+    _lib.check(lib.ctu_loss_fwd(pred.data_ptr(), target.data_ptr(), n, v, ce_lambda, dice_lambda, int(dice_softmax),
+                                terms.data_ptr(), ws.data_ptr(), _stream()), "loss_fwd")
+    return terms, ws
+
+
+def loss_bwd(pred, target, ce_lambda, dice_lambda, dice_softmax, ws, gscale: Optional[torch.Tensor],
+             out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    pred, target = pred.contiguous(), target.contiguous()
+    n = pred.shape[0]
+    v = pred[0, 0].numel()
+    g = out if out is not None else torch.empty_like(pred)
+    lib = _lib.load()
+    _lib.check(lib.ctu_loss_bwd(pred.data_ptr(), target.data_ptr(), n, v, ce_lambda, dice_lambda, int(dice_softmax),
+                                ws.data_ptr(), _ptr(gscale), g.data_ptr(), int(accumulate), _stream()), "loss_bwd")
+    return g
+
+
+# ---------------------------------------------------------------------------- misc
+def channel_sum(x: CL, c: int) -> torch.Tensor:
+    lib = _lib.load()
+    nb = lib.ctu_channel_sum_num_blocks(x.nvox)
+    part = torch.empty(nb * x.cp, dtype=torch.float32, device=x.buf.device)
+    out = torch.empty(c, dtype=torch.float32, device=x.buf.device)
+    _lib.check(lib.ctu_channel_sum(x.ptr, x.cs, x.cp, x.nvox, part.data_ptr(), out.data_ptr(), c, _stream()),
+               "channel_sum")
+    return out

@@ -1,0 +1,223 @@
+/*
+ * ctunet_hip.h -- C ABI of libctunet_hip.so: the MI355X (gfx950) kernels behind the
+ * ctunet 3D U-Net hot path.
+ *
+ * The reference (vfmatzkin/ct-unet) has no FFI of its own: every device operation is a
+ * stock torch.nn call inside ctunet/pytorch/models.py, utilities.py and ProblemHandler.py.
+ * Each entry point below replaces one such call site (cited per function, paths relative
+ * to the reference root).  The host side (ct-unet_amd/ctunet_amd) binds these with ctypes.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, no torch types.  All pointers are DEVICE
+ *    pointers unless a parameter says "host".
+ *  - Ownership: the library never allocates or frees tensor memory.  Outputs, saved
+ *    statistics and workspaces are caller allocations.
+ *  - Streams: kernels are enqueued on `stream` (a hipStream_t passed as void*) and the
+ *    call returns without synchronising; calls are safe under stream capture.
+ *  - Errors: return 0 on success, a negative CTU_E* code otherwise; ctu_last_error()
+ *    returns a thread-local message for the last failing call on this thread.
+ *  - Activations are fp32, channels-last-3d ("NDHWC") with a CHANNEL STRIDE `cs`
+ *    (number of floats between consecutive voxels), so a tensor may be a channel slice
+ *    of a wider buffer (the skip-concat buffers).  Channel counts `*_p` are padded to a
+ *    multiple of 8; padded channels hold zeros.  Only ctu_ncdhw_to_ndhwc / ctu_head_*
+ *    / ctu_loss_* touch the caller-visible NCDHW layout.
+ *  - "Lazy BatchNorm": a conv writes its RAW output plus per-block sum / sum-of-squares
+ *    partials; ctu_bn_finalize turns those into per-channel scale/shift; every consumer
+ *    applies  a = relu(raw*scale + shift)  while loading (`in_scale`,`in_shift`,
+ *    `in_relu`; NULL scale = identity).  Raw tensors are what backward re-reads.
+ */
+#ifndef CTUNET_HIP_H
+#define CTUNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CTU_OK 0
+#define CTU_EINVAL (-1)   /* bad argument / unsupported shape */
+#define CTU_ELAUNCH (-2)  /* HIP launch or runtime error       */
+
+const char* ctu_last_error(void);
+/* Library/ABI version (bumped on any signature change). */
+int ctu_abi_version(void);
+/* Name of the code object target this library was compiled for ("gfx950"). */
+const char* ctu_arch(void);
+
+/* ---------------------------------------------------------------- layout ---- */
+/* NCDHW [N,C,D,H,W] -> NDHWC [N,D,H,W,cs], channels C..cp-1 zero-filled.
+ * Host boundary of Model.forward_pass (ctunet/pytorch/Model.py:343-352). */
+int ctu_ncdhw_to_ndhwc(const float* src, float* dst, int N, int C, int D, int H, int W,
+                       int cp, int cs, void* stream);
+/* NDHWC (channel stride cs) -> NCDHW, first C channels. */
+int ctu_ndhwc_to_ncdhw(const float* src, float* dst, int N, int C, int D, int H, int W,
+                       int cs, void* stream);
+
+/* ------------------------------------------------------- conv3d (k=3 / k=5) ---- */
+/* Geometry helpers: packed-weight size (floats) and number of spatial blocks (= rows of
+ * the stats-partials buffer) for a conv call. */
+size_t ctu_conv3d_packed_floats(int k, int rin_p, int nout_p);
+int ctu_conv3d_num_blocks(int N, int D, int H, int W);
+
+/* Re-layout a torch Conv3d weight [Co,Ci,k,k,k] for the implicit-GEMM kernels.
+ *  mode 0 (forward): reduction channel = imap[ci], output channel = co.
+ *  mode 1 (data gradient): reduction channel = co, output channel = imap[ci], taps flipped.
+ * imap (int32[Ci], device, may be NULL = identity) maps a logical input channel to its
+ * position in the padded channels-last buffer.  rin_p / nout_p: padded channel counts of
+ * the reduction and output sides of THIS packing (multiples of 8).
+ * nn.Conv3d weights: ctunet/pytorch/models.py:26,29,38,41,71,76,403,407,430,434,482-488. */
+int ctu_pack_conv3d_weight(const float* w, float* wp, int Co, int Ci, int k,
+                           const int32_t* imap, int rin_p, int nout_p, int mode, void* stream);
+
+/* Implicit-GEMM 3D convolution on MFMA (v_mfma_f32_16x16x4_f32), stride 1, zero padding
+ * (k-1)/2, NDHWC.  out[v, o] = bias[o] + sum_{tap,r} A(in[v+tap, r]) * wp[tap, r, o] with
+ * A() the lazy-BN input transform.  Used for nn.Conv3d forward (models.py call sites
+ * above) and, with a mode-1 packing, for its data gradient.
+ *  in/in_cs/rin_p ...... input tensor, channel stride, channels to contract (mult. of 8)
+ *  in_scale/in_shift ... per-channel transform of `in` (NULL = identity); in_relu 0/1
+ *  bias ................ [nout_p] or NULL
+ *  out/out_cs/nout_p ... output tensor (channel slice base), stride, channels written
+ *  stats ............... NULL or [ctu_conv3d_num_blocks()][2][nout_p]: per-block sum and
+ *                        sum of squares of the written output (train-mode BatchNorm3d,
+ *                        models.py:27,31,39,43,74,79,405,409,432,436,485,490) */
+int ctu_conv3d_fwd(const float* in, int in_cs, int rin_p,
+                   const float* in_scale, const float* in_shift, int in_relu,
+                   const float* wp, const float* bias,
+                   float* out, int out_cs, int nout_p, float* stats,
+                   int N, int D, int H, int W, int k, void* stream);
+
+/* Weight gradient of nn.Conv3d: dW[co,ci,tap] = sum_v A(in[v+tap, imap[ci]]) * gout[v, co].
+ * ws: workspace of ctu_conv3d_wgrad_ws_floats() floats (per-wave partial slabs, reduced
+ * deterministically by a second kernel; no float atomics).  dw: torch layout [Co,Ci,k,k,k].
+ * dbias: NULL or [Co] = sum_v gout[v,co]. */
+size_t ctu_conv3d_wgrad_ws_floats(int N, int D, int H, int W, int k, int cin_p, int cout_p);
+int ctu_conv3d_wgrad(const float* in, int in_cs, int cin_p,
+                     const float* in_scale, const float* in_shift, int in_relu,
+                     const float* gout, int g_cs, int cout_p,
+                     float* dw, float* dbias, int Co, int Ci, const int32_t* imap,
+                     float* ws, int N, int D, int H, int W, int k, void* stream);
+
+/* ------------------------------------------------------------ BatchNorm3d ---- */
+/* Train mode: reduce the per-block partials written by ctu_conv3d_fwd into batch
+ * statistics and the lazy transform.  count = N*D*H*W.  C logical channels, cp padded.
+ *  scale = gamma*invstd, shift = beta - mean*scale (0 for padded channels)
+ *  running_mean/var updated `n_updates` times with momentum (unbiased var), as
+ *  nn.BatchNorm3d does; n_updates = 2 reproduces the double update that
+ *  torch.utils.checkpoint causes (models.py:232-255).  num_batches_tracked is the host's.
+ * mean_out/invstd_out [cp] are saved for backward. */
+int ctu_bn_finalize(const float* stats, int nblocks, int C, int cp, double count,
+                    const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, float momentum, float eps,
+                    int n_updates, float* scale, float* shift, float* mean_out,
+                    float* invstd_out, void* stream);
+/* Eval mode: scale/shift from the running statistics. */
+int ctu_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
+                       const float* running_var, float eps, int C, int cp,
+                       float* scale, float* shift, void* stream);
+
+/* Backward of  a = relu(bn(y))  for one conv output.
+ * Pass 1: partials[nb][2][cp] of  sum(gz)  and  sum(gz * yhat),  gz = ga * (a > 0).
+ * Pass 2 (after ctu_bn_bwd_finalize): gy = gamma*invstd*(gz - dbeta/n - yhat*dgamma/n),
+ * written IN PLACE over ga.  y/ga are channels-last with strides.  */
+int ctu_bn_bwd_num_blocks(int64_t nvox);
+int ctu_bn_relu_bwd_reduce(const float* y, int y_cs, const float* ga, int g_cs, int cp,
+                           const float* scale, const float* shift, const float* mean,
+                           const float* invstd, int64_t nvox, float* partials, void* stream);
+int ctu_bn_bwd_finalize(const float* partials, int nb, int C, int cp, double count,
+                        const float* gamma, const float* invstd,
+                        float* dgamma, float* dbeta, float* coef, void* stream);
+int ctu_bn_relu_bwd_apply(const float* y, int y_cs, float* ga, int g_cs, int cp,
+                          const float* scale, const float* shift, const float* mean,
+                          const float* invstd, const float* coef, int64_t nvox, void* stream);
+
+/* -------------------------------------------------------------- MaxPool3d ---- */
+/* nn.MaxPool3d(2, stride 2) (models.py:190-191,233,469-470) of a = A(in); writes the
+ * pooled ACTIVATED values (no transform needed downstream). */
+int ctu_maxpool2_fwd(const float* in, int in_cs, int cp, const float* in_scale,
+                     const float* in_shift, int in_relu, float* out, int out_cs,
+                     int N, int D, int H, int W, void* stream);
+/* Backward: routes gout (pooled grid) to the first max of each 2x2x2 window of A(in)
+ * (recomputed, no stored indices) and ADDS it into gin (full grid, stride gin_cs). */
+int ctu_maxpool2_bwd(const float* in, int in_cs, int cp, const float* in_scale,
+                     const float* in_shift, int in_relu, const float* gout, int gout_cs,
+                     float* gin, int gin_cs, int accumulate, int N, int D, int H, int W,
+                     void* stream);
+
+/* -------------------------------------------------- ConvTranspose3d k2 s2 ---- */
+/* nn.ConvTranspose3d(C, C, 2, 2) with bias (models.py:37,427-429):
+ * out[2v+tap, o] = b[o] + sum_r A(in[v, r]) * w[r, o, tap];  w torch layout [Ci,Co,2,2,2].
+ * Packing: mode 0 forward (reduction = imap[ci], output = co),
+ *          mode 1 data gradient (reduction = co, output = imap[ci]). */
+size_t ctu_convt_packed_floats(int rin_p, int nout_p);
+int ctu_pack_convt_weight(const float* w, float* wp, int Ci, int Co, const int32_t* imap,
+                          int rin_p, int nout_p, int mode, void* stream);
+int ctu_convt2_fwd(const float* in, int in_cs, int rin_p, const float* in_scale,
+                   const float* in_shift, int in_relu, const float* wp, const float* bias,
+                   float* out, int out_cs, int nout_p, int N, int D, int H, int W,
+                   void* stream);      /* D,H,W: INPUT grid; output grid is 2D,2H,2W */
+/* gin[v, r] = sum_{tap,o} gout[2v+tap, o] * w[r, o, tap]  (wp from mode 1). */
+int ctu_convt2_bwd_data(const float* gout, int g_cs, int rout_p, const float* wp,
+                        float* gin, int gin_cs, int nin_p, int N, int D, int H, int W,
+                        void* stream);
+/* dw[ci,co,tap] = sum_v A(in[v, imap[ci]]) * gout[2v+tap, co];  dbias[co] = sum gout. */
+size_t ctu_convt2_wgrad_ws_floats(int N, int D, int H, int W, int cin_p, int cout_p);
+int ctu_convt2_wgrad(const float* in, int in_cs, int cin_p, const float* in_scale,
+                     const float* in_shift, int in_relu, const float* gout, int g_cs,
+                     int cout_p, float* dw, float* dbias, int Ci, int Co,
+                     const int32_t* imap, float* ws, int N, int D, int H, int W, void* stream);
+
+/* ------------------------------------------------------------------- head ---- */
+/* last_conv 1x1x1 + bias, optional softmax(dim=1), optional sigmoid, optional SP
+ * re-encoding, written NCDHW (models.py:223-224,255-259,317-330,364-365,507,538).
+ *  w [Co,Ci] torch layout, imap as above, act: bit0 softmax, bit1 sigmoid.  Co <= 4.
+ *  head_mode 0: out0 = y [N,Co,...].
+ *  head_mode 1 (UNetSP/UNetDO): out0 = [y0, y1+y2], out1 = [1-y1, y1]  (Co must be 3).
+ *  head_mode 2 (UNetSPSmall): mode 1 followed by softmax of each pair. */
+int ctu_head_fwd(const float* in, int in_cs, int cin_p, const float* in_scale,
+                 const float* in_shift, int in_relu, const float* w, const float* bias,
+                 const int32_t* imap, int Ci, int Co, int act, int head_mode,
+                 float* out0, float* out1, int N, int64_t nvox_per_item, void* stream);
+/* Backward of the head; the forward values are recomputed from `in` (nothing saved).
+ * g0/g1: gradients of out0/out1 (NCDHW, g1 NULL for mode 0).  Produces gin (channels-last,
+ * stride gin_cs, cin_p channels = gradient w.r.t. the ACTIVATED input), dw [Co,Ci], db [Co].
+ * ws: workspace of ctu_head_bwd_ws_floats() floats. */
+size_t ctu_head_bwd_ws_floats(int N, int64_t nvox_per_item, int cin_p, int Co);
+int ctu_head_bwd(const float* in, int in_cs, int cin_p, const float* in_scale,
+                 const float* in_shift, int in_relu, const float* w, const float* bias,
+                 const int32_t* imap, int Ci, int Co, int act, int head_mode,
+                 const float* g0, const float* g1, float* gin, int gin_cs,
+                 float* dw, float* db, float* ws, int N, int64_t nvox_per_item, void* stream);
+
+/* ------------------------------------------------------------------- loss ---- */
+/* Fused Dice + cross-entropy on one 2-channel NCDHW map (utilities.py:35-50,
+ * ProblemHandler.py:59-88,228-298).  pred/target [N,2,V].
+ *  ce term   = ce_lambda   * CrossEntropy(pred as logits, argmax(target,1)), mean over N*V
+ *  dice term = dice_lambda * dice_loss(P, target), P = softmax(pred,1) if dice_softmax else pred
+ * terms (device, float[2]) = {ce term, dice term}.  ws: ctu_loss_ws_floats(N, V) floats,
+ * kept until ctu_loss_bwd, which writes gpred = gscale[0] * d(ce term + dice term)/dpred
+ * (gscale NULL = 1; accumulate != 0: gpred += ). */
+size_t ctu_loss_ws_floats(int N, int64_t V);
+int ctu_loss_fwd(const float* pred, const float* target, int N, int64_t V, float ce_lambda,
+                 float dice_lambda, int dice_softmax, float* terms, float* ws, void* stream);
+int ctu_loss_bwd(const float* pred, const float* target, int N, int64_t V, float ce_lambda,
+                 float dice_lambda, int dice_softmax, const float* ws, const float* gscale,
+                 float* gpred, int accumulate, void* stream);
+
+/* -------------------------------------------------------------- utilities ---- */
+/* Per-channel sum over voxels of a channels-last tensor: out[c] = sum_v x[v,c] (bias grads). */
+int ctu_channel_sum_num_blocks(int64_t nvox);
+int ctu_channel_sum(const float* x, int cs, int cp, int64_t nvox, float* partials,
+                    float* out, int C, void* stream);
+/* Fused multi-tensor Adam with amsgrad (torch.optim.Adam(amsgrad=True), Model.py:514-520).
+ * ptrs: device array of 5*n pointers {param, grad, exp_avg, exp_avg_sq, max_exp_avg_sq};
+ * sizes: device int64[n].  step is the 1-based step count. */
+int ctu_adam_amsgrad(void* const* ptrs, const int64_t* sizes, int n, int64_t max_size,
+                     double lr, double beta1, double beta2, double eps, double weight_decay,
+                     int64_t step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CTUNET_HIP_H */

@@ -1,0 +1,366 @@
+"""Per-op parity of the HIP kernels (through the C ABI) against the oracle's building blocks
+(torch.nn.functional on CPU, fp32).  Tolerances: the MFMA path is an exact fp32 fma chain, so
+differences are summation-order only; gates are 1e-4 relative to the output scale, two orders
+tighter than the north star's 1e-3."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from ctunet_amd import ops
+    return ops
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def to_cl(x, cs=None, c0=0, cp=None):
+    """CPU NCDHW -> GPU channels-last buffer [N,D,H,W,cs] with x at channels [c0, c0+C), rest NaN-free garbage=0."""
+    ops = _ops()
+    n, c, d, h, w = x.shape
+    cp = cp or ops.pad8(c)
+    cs = cs or cp
+    buf = torch.zeros(n, d, h, w, cs)
+    buf[..., c0:c0 + c] = x.permute(0, 2, 3, 4, 1)
+    return ops.CL(buf.cuda(), c0, cp)
+
+
+def from_cl(a, c):
+    return a.buf[..., a.c0:a.c0 + c].permute(0, 4, 1, 2, 3).cpu()
+
+
+def rel_err(a, b):
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
+
+
+def xf_vectors(c, cp, seed):
+    sc = torch.zeros(cp); sh = torch.zeros(cp)
+    sc[:c] = torch.rand(c, generator=g(seed)) * 2 - 0.5
+    sh[:c] = torch.randn(c, generator=g(seed + 1)) * 0.3
+    return sc, sh
+
+
+CONV_CASES = [
+    # N, Ci, Co, D, H, W, k, xf, bias
+    (1, 8, 8, 8, 8, 16, 3, False, False),
+    (1, 1, 8, 16, 16, 16, 3, False, False),
+    (2, 8, 16, 8, 12, 20, 3, True, False),     # ragged: H, W not multiples of the tile
+    (1, 32, 8, 8, 8, 16, 3, True, False),      # the dominant decoder shape
+    (1, 16, 32, 8, 8, 8, 3, True, False),      # 8-wide tile
+    (1, 64, 64, 4, 4, 4, 3, True, False),      # 4-wide tile, NT=4
+    (1, 64, 128, 4, 4, 4, 3, False, False),    # two y-blocks
+    (1, 7, 14, 8, 8, 8, 3, True, False),       # UNetSP widths
+    (1, 3, 6, 2, 2, 2, 3, False, False),       # volume smaller than every tile
+    (1, 8, 8, 8, 8, 16, 5, False, True),       # legacy k5 + bias
+    (1, 2, 7, 6, 10, 18, 5, True, True),
+    (1, 16, 64, 4, 4, 8, 5, True, True),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv3d_fwd_and_stats(case):
+    ops = _ops()
+    n, ci, co, d, h, w, k, xf, bias = case
+    x = torch.randn(n, ci, d, h, w, generator=g(1))
+    wt = torch.randn(co, ci, k, k, k, generator=g(2)) * 0.2
+    b = torch.randn(co, generator=g(3)) if bias else None
+    cip, cop = ops.pad8(ci), ops.pad8(co)
+    xa = x
+    xc = to_cl(x)
+    if xf:
+        sc, sh = xf_vectors(ci, cip, 5)
+        xa = F.relu(x * sc[:ci].view(1, -1, 1, 1, 1) + sh[:ci].view(1, -1, 1, 1, 1))
+        xc = xc.with_xf(sc.cuda(), sh.cuda(), True)
+    ref = F.conv3d(xa, wt, b, 1, (k - 1) // 2)
+    wp = ops.pack_conv_w(wt.cuda(), None, cip, cop, 0)
+    bp = None
+    if bias:
+        bp = torch.zeros(cop); bp[:co] = b; bp = bp.cuda()
+    # write into a channel slice of a wider buffer to exercise strides
+    obuf = torch.full((n, d, h, w, cop + 8), 7.0, device="cuda")
+    out = ops.CL(obuf, 8, cop)
+    nb = ops.conv_num_blocks((n, d, h, w))
+    stats = torch.zeros(nb, 2, cop, device="cuda")
+    ops.conv3d_fwd(xc, wp, bp, out, k, stats)
+    torch.cuda.synchronize()
+    got = from_cl(out, co)
+    assert rel_err(got, ref) < 1e-4
+    assert torch.all(obuf[..., :8] == 7.0)                      # neighbouring slice untouched
+    if cop > co:
+        assert torch.all(out.buf[..., out.c0 + co:out.c0 + cop] == 0)   # padded channels are zero
+    s = stats.sum(0).cpu().double()
+    ref_s1 = ref.double().sum((0, 2, 3, 4)); ref_s2 = (ref.double() ** 2).sum((0, 2, 3, 4))
+    assert torch.allclose(s[0, :co], ref_s1, rtol=1e-4, atol=1e-3 * ref_s2.max().sqrt().item())
+    assert torch.allclose(s[1, :co], ref_s2, rtol=1e-4)
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv3d_backward(case):
+    """dgrad through the mode-1 packing of the same forward kernel, wgrad kernel, bias grad."""
+    ops = _ops()
+    n, ci, co, d, h, w, k, xf, bias = case
+    x = torch.randn(n, ci, d, h, w, generator=g(11))
+    wt = (torch.randn(co, ci, k, k, k, generator=g(12)) * 0.2).requires_grad_(True)
+    gy = torch.randn(n, co, d, h, w, generator=g(13))
+    cip, cop = ops.pad8(ci), ops.pad8(co)
+    xc = to_cl(x)
+    xa = x.clone()
+    if xf:
+        sc, sh = xf_vectors(ci, cip, 15)
+        xa = F.relu(x * sc[:ci].view(1, -1, 1, 1, 1) + sh[:ci].view(1, -1, 1, 1, 1))
+        xc = xc.with_xf(sc.cuda(), sh.cuda(), True)
+    xa = xa.detach().requires_grad_(True)
+    b = torch.zeros(co, requires_grad=True)
+    y = F.conv3d(xa, wt, b, 1, (k - 1) // 2)
+    y.backward(gy)
+    gc = to_cl(gy)
+    # data gradient
+    wpd = ops.pack_conv_w(wt.detach().cuda(), None, cop, cip, 1)
+    gin = ops.CL(torch.empty(n, d, h, w, cip, device="cuda"), 0, cip)
+    ops.conv3d_fwd(gc, wpd, None, gin, k, None)
+    # weight gradient
+    ws = torch.empty(ops.conv3d_wgrad_ws((n, d, h, w), k, cip, cop), device="cuda")
+    dw, db = ops.conv3d_wgrad(xc, gc, co, ci, k, None, ws, True)
+    torch.cuda.synchronize()
+    assert rel_err(from_cl(gin, ci), xa.grad) < 1e-4
+    assert rel_err(dw.cpu(), wt.grad) < 1e-4
+    assert rel_err(db.cpu(), b.grad) < 1e-4
+
+
+def test_conv3d_imap_concat():
+    """Input channels scattered in a padded concat buffer (UNetSP: 7+pad | 7+pad)."""
+    ops = _ops()
+    n, d, h, w, k = 1, 8, 8, 8, 3
+    xa, xb = torch.randn(n, 7, d, h, w, generator=g(1)), torch.randn(n, 7, d, h, w, generator=g(2))
+    wt = torch.randn(5, 14, k, k, k, generator=g(3)) * 0.2
+    ref = F.conv3d(torch.cat((xa, xb), 1), wt, None, 1, 1)
+    buf = torch.zeros(n, d, h, w, 16)
+    buf[..., 0:7] = xa.permute(0, 2, 3, 4, 1); buf[..., 8:15] = xb.permute(0, 2, 3, 4, 1)
+    xc = ops.CL(buf.cuda(), 0, 16)
+    imap = torch.tensor(list(range(7)) + list(range(8, 15)), dtype=torch.int32).cuda()
+    wp = ops.pack_conv_w(wt.cuda(), imap, 16, 8, 0)
+    out = ops.CL(torch.empty(n, d, h, w, 8, device="cuda"), 0, 8)
+    ops.conv3d_fwd(xc, wp, None, out, k, None)
+    assert rel_err(from_cl(out, 5), ref) < 1e-4
+    gy = torch.randn(n, 5, d, h, w, generator=g(4))
+    ws = torch.empty(ops.conv3d_wgrad_ws((n, d, h, w), k, 16, 8), device="cuda")
+    dw, _ = ops.conv3d_wgrad(xc, to_cl(gy), 5, 14, k, imap, ws, False)
+    xcat = torch.cat((xa, xb), 1).requires_grad_(True)
+    wr = wt.clone().requires_grad_(True)
+    F.conv3d(xcat, wr, None, 1, 1).backward(gy)
+    assert rel_err(dw.cpu(), wr.grad) < 1e-4
+    wpd = ops.pack_conv_w(wt.cuda(), imap, 8, 16, 1)
+    gin = ops.CL(torch.empty(n, d, h, w, 16, device="cuda"), 0, 16)
+    ops.conv3d_fwd(to_cl(gy), wpd, None, gin, k, None)
+    got = gin.buf.cpu()
+    assert rel_err(got[..., 0:7].permute(0, 4, 1, 2, 3), xcat.grad[:, :7]) < 1e-4
+    assert rel_err(got[..., 8:15].permute(0, 4, 1, 2, 3), xcat.grad[:, 7:]) < 1e-4
+    assert torch.all(got[..., 7] == 0) and torch.all(got[..., 15] == 0)
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 8, 8, 8), (1, 7, 4, 6, 10), (1, 64, 4, 4, 4), (1, 112, 2, 2, 2)])
+def test_batchnorm_train_fwd_bwd(shape):
+    """conv stats -> finalize -> lazy transform; then BN+ReLU backward, vs F.batch_norm/relu autograd."""
+    ops = _ops()
+    n, c, d, h, w = shape
+    cp = ops.pad8(c)
+    y = (torch.randn(shape, generator=g(1)) * 1.7 + 0.4)
+    gamma = torch.rand(c, generator=g(2)) * 1.5 - 0.25
+    beta = torch.randn(c, generator=g(3)) * 0.2
+    rm, rv = torch.randn(c, generator=g(4)) * 0.1, torch.rand(c, generator=g(5)) + 0.5
+    # reference
+    yr = y.clone().requires_grad_(True); gr = gamma.clone().requires_grad_(True); br = beta.clone().requires_grad_(True)
+    rm_r, rv_r = rm.clone(), rv.clone()
+    a = F.relu(F.batch_norm(yr, rm_r, rv_r, gr, br, True, 0.1, 1e-5))
+    ga = torch.randn(shape, generator=g(6))
+    a.backward(ga)
+    # ours: identity 1x1-free path -- build stats with the channel-sum style partial layout via a conv of k=3 delta kernel
+    yc = to_cl(y)
+    wt = torch.zeros(c, c, 3, 3, 3); wt[range(c), range(c), 1, 1, 1] = 1.0
+    wp = ops.pack_conv_w(wt.cuda(), None, cp, cp, 0)
+    out = ops.CL(torch.empty(n, d, h, w, cp, device="cuda"), 0, cp)
+    nb = ops.conv_num_blocks((n, d, h, w))
+    stats = torch.zeros(nb, 2, cp, device="cuda")
+    ops.conv3d_fwd(yc, wp, None, out, 3, stats)
+    rm_g, rv_g = rm.cuda(), rv.cuda()
+    vec = ops.bn_finalize(stats, nb, c, cp, n * d * h * w, gamma.cuda(), beta.cuda(), rm_g, rv_g, 0.1, 1e-5, 1)
+    torch.cuda.synchronize()
+    assert torch.allclose(rm_g.cpu(), rm_r, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(rv_g.cpu(), rv_r, rtol=1e-5, atol=1e-6)
+    act = from_cl(out, c) * vec[0, :c].cpu().view(1, -1, 1, 1, 1) + vec[1, :c].cpu().view(1, -1, 1, 1, 1)
+    assert rel_err(F.relu(act), a.detach()) < 1e-4
+    assert torch.all(vec[:, c:] == 0)
+    gac = to_cl(ga)
+    part = torch.empty(ops.bn_bwd_partials_floats(n * d * h * w, cp), device="cuda")
+    dgam, dbet = ops.bn_relu_bwd(out, gac, vec, gamma.cuda(), c, part)
+    torch.cuda.synchronize()
+    assert rel_err(dgam.cpu(), gr.grad) < 1e-4
+    assert rel_err(dbet.cpu(), br.grad) < 1e-4
+    assert rel_err(from_cl(gac, c), yr.grad) < 2e-4
+
+
+def test_batchnorm_double_update_and_eval():
+    ops = _ops()
+    c, cp = 5, 8
+    stats = torch.zeros(3, 2, cp); stats[:, 0, :c] = torch.rand(3, c, generator=g(1)) * 10
+    stats[:, 1, :c] = torch.rand(3, c, generator=g(2)) * 50 + 40
+    count = 100.0
+    mean = stats[:, 0, :c].sum(0) / count; var = stats[:, 1, :c].sum(0) / count - mean ** 2
+    gamma, beta = torch.rand(c) + 0.5, torch.randn(c)
+    rm, rv = torch.zeros(c), torch.ones(c)
+    exp_rm, exp_rv = rm.clone(), rv.clone()
+    for _ in range(2):
+        exp_rm = 0.9 * exp_rm + 0.1 * mean
+        exp_rv = 0.9 * exp_rv + 0.1 * var * count / (count - 1)
+    rm_g, rv_g = rm.cuda(), rv.cuda()
+    ops.bn_finalize(stats.cuda(), 3, c, cp, count, gamma.cuda(), beta.cuda(), rm_g, rv_g, 0.1, 1e-5, 2)
+    assert torch.allclose(rm_g.cpu(), exp_rm, rtol=1e-5) and torch.allclose(rv_g.cpu(), exp_rv, rtol=1e-5)
+    vec = ops.bn_eval_affine(gamma.cuda(), beta.cuda(), rm_g, rv_g, 1e-5, c, cp).cpu()
+    sc = gamma / torch.sqrt(exp_rv + 1e-5)
+    assert torch.allclose(vec[0, :c], sc, rtol=1e-5) and torch.allclose(vec[1, :c], beta - exp_rm * sc, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("shape,xf", [((1, 8, 8, 8, 8), False), ((2, 7, 4, 6, 10), True), ((1, 64, 2, 2, 2), True)])
+def test_maxpool_fwd_bwd(shape, xf):
+    ops = _ops()
+    n, c, d, h, w = shape
+    cp = ops.pad8(c)
+    x = torch.randn(shape, generator=g(1))
+    xc = to_cl(x)
+    xa = x
+    if xf:
+        sc, sh = xf_vectors(c, cp, 3)
+        xa = F.relu(x * sc[:c].view(1, -1, 1, 1, 1) + sh[:c].view(1, -1, 1, 1, 1))
+        xc = xc.with_xf(sc.cuda(), sh.cuda(), True)
+    xa = xa.detach().requires_grad_(True)
+    ref = F.max_pool3d(xa, 2, 2)
+    out = ops.CL(torch.empty(n, d // 2, h // 2, w // 2, cp, device="cuda"), 0, cp)
+    ops.maxpool_fwd(xc, out)
+    # identity transform: bit exact; with the transform the kernel uses one fused fma (1 ulp vs mul+add)
+    assert torch.equal(from_cl(out, c), ref.detach()) if not xf else torch.allclose(from_cl(out, c), ref.detach(), rtol=1e-6, atol=1e-7)
+    gy = torch.randn(ref.shape, generator=g(2))
+    ref.backward(gy)
+    base = torch.randn(shape, generator=g(4))
+    gin = to_cl(base)
+    ops.maxpool_bwd(xc, to_cl(gy), gin, True)
+    got = from_cl(gin, c)
+    if xf:
+        # ties at 0 after ReLU route to the first element; ReLU's own backward zeroes them, so compare where a > 0
+        mask = (xa.detach() > 0)
+        assert torch.allclose((got - base)[mask], xa.grad[mask])
+    else:
+        assert torch.allclose(got - base, xa.grad)
+
+
+@pytest.mark.parametrize("case", [(1, 8, 8, 4, 4, 4, False), (2, 32, 32, 4, 6, 10, True), (1, 14, 14, 4, 4, 4, True),
+                                  (1, 128, 128, 2, 2, 2, True), (1, 6, 6, 1, 1, 1, False)])
+def test_convtranspose(case):
+    ops = _ops()
+    n, ci, co, d, h, w, xf = case
+    cip, cop = ops.pad8(ci), ops.pad8(co)
+    x = torch.randn(n, ci, d, h, w, generator=g(1))
+    wt = (torch.randn(ci, co, 2, 2, 2, generator=g(2)) * 0.3).requires_grad_(True)
+    b = torch.randn(co, generator=g(3)).requires_grad_(True)
+    xc = to_cl(x)
+    xa = x
+    if xf:
+        sc, sh = xf_vectors(ci, cip, 4)
+        xa = F.relu(x * sc[:ci].view(1, -1, 1, 1, 1) + sh[:ci].view(1, -1, 1, 1, 1))
+        xc = xc.with_xf(sc.cuda(), sh.cuda(), True)
+    xa = xa.detach().requires_grad_(True)
+    ref = F.conv_transpose3d(xa, wt, b, stride=2)
+    gy = torch.randn(ref.shape, generator=g(5))
+    ref.backward(gy)
+    wp = ops.pack_convt_w(wt.detach().cuda(), None, cip, cop, 0)
+    bp = torch.zeros(cop); bp[:co] = b.detach(); bp = bp.cuda()
+    out = ops.CL(torch.empty(n, 2 * d, 2 * h, 2 * w, cop, device="cuda"), 0, cop)
+    ops.convt_fwd(xc, wp, bp, out)
+    assert rel_err(from_cl(out, co), ref.detach()) < 1e-4
+    gc = to_cl(gy)
+    wpd = ops.pack_convt_w(wt.detach().cuda(), None, cop, cip, 1)
+    gin = ops.CL(torch.empty(n, d, h, w, cip, device="cuda"), 0, cip)
+    ops.convt_bwd_data(gc, wpd, gin)
+    assert rel_err(from_cl(gin, ci), xa.grad) < 1e-4
+    ws = torch.empty(ops.convt_wgrad_ws((n, d, h, w), cip, cop), device="cuda")
+    dw, db = ops.convt_wgrad(xc, gc, ci, co, None, ws)
+    assert rel_err(dw.cpu(), wt.grad) < 1e-4
+    assert rel_err(db.cpu(), b.grad) < 1e-4
+
+
+@pytest.mark.parametrize("co,act,mode", [(2, 2, 0), (2, 1, 0), (3, 2, 1), (3, 2, 2), (3, 3, 0), (1, 0, 0)])
+def test_head_fwd_bwd(co, act, mode):
+    ops = _ops()
+    n, d, h, w = 2, 4, 6, 10
+    xa_, xb_ = torch.randn(n, 7, d, h, w, generator=g(1)), torch.randn(n, 7, d, h, w, generator=g(2))
+    buf = torch.zeros(n, d, h, w, 16)
+    buf[..., 0:7] = xa_.permute(0, 2, 3, 4, 1); buf[..., 8:15] = xb_.permute(0, 2, 3, 4, 1)
+    sc, sh = torch.rand(16, generator=g(3)) + 0.2, torch.randn(16, generator=g(4)) * 0.3
+    xc = ops.CL(buf.cuda(), 0, 16, sc.cuda(), sh.cuda(), True)
+    imap_l = list(range(7)) + list(range(8, 15))
+    imap = torch.tensor(imap_l, dtype=torch.int32).cuda()
+    xcat = torch.cat((xa_, xb_), 1)
+    a = F.relu(xcat * sc[imap_l].view(1, -1, 1, 1, 1) + sh[imap_l].view(1, -1, 1, 1, 1)).requires_grad_(True)
+    wt = (torch.randn(co, 14, generator=g(5)) * 0.4).requires_grad_(True)
+    b = torch.randn(co, generator=g(6)).requires_grad_(True)
+    lc = F.conv3d(a, wt.view(co, 14, 1, 1, 1), b)
+    y = F.softmax(lc, 1) if act & 1 else lc
+    y = torch.sigmoid(y) if act & 2 else y
+    if mode == 0:
+        refs = (y,)
+    else:
+        sk = torch.cat((y[:, 0:1], y[:, 1:2] + y[:, 2:3]), 1); fl = torch.cat((1 - y[:, 1:2], y[:, 1:2]), 1)
+        refs = (F.softmax(sk, 1), F.softmax(fl, 1)) if mode == 2 else (sk, fl)
+    gs = [torch.randn(r.shape, generator=g(7 + i)) for i, r in enumerate(refs)]
+    torch.autograd.backward(refs, gs)
+    o0, o1 = ops.head_fwd(xc, wt.detach().cuda(), b.detach().cuda(), imap, act, mode)
+    assert rel_err(o0.cpu(), refs[0].detach()) < 1e-5
+    if mode:
+        assert rel_err(o1.cpu(), refs[1].detach()) < 1e-5
+    gin = ops.CL(torch.empty(n, d, h, w, 16, device="cuda"), 0, 16)
+    dw, db = ops.head_bwd(xc, wt.detach().cuda(), b.detach().cuda(), imap, act, mode, gs[0].cuda(),
+                          gs[1].cuda() if mode else None, gin)
+    got = gin.buf.cpu()[..., imap_l].permute(0, 4, 1, 2, 3)
+    assert rel_err(got, a.grad) < 1e-4
+    assert rel_err(dw.cpu(), wt.grad) < 1e-4
+    assert rel_err(db.cpu(), b.grad) < 1e-4
+
+
+@pytest.mark.parametrize("ce,dice,sm", [(1.0, 1.0, False), (1.0, 1.0, True), (0.0, 1.0, True), (1.0, 0.0, False),
+                                        (0.5, 2.0, True)])
+def test_loss_fwd_bwd(ce, dice, sm):
+    import sys
+    from oracle import unet_oracle as O
+    ops = _ops()
+    p = torch.rand(2, 2, 6, 8, 10, generator=g(1)).requires_grad_(True)
+    m = (torch.rand(2, 6, 8, 10, generator=g(2)) < 0.3).long()
+    t = F.one_hot(m, 2).movedim(4, 1).float().contiguous()
+    terms = []
+    if ce:
+        terms.append(ce * O.cross_entropy(p, t))
+    if dice:
+        terms.append(dice * O.dice_loss(F.softmax(p, 1) if sm else p, t))
+    total = sum(terms)
+    total.backward()
+    tg, ws = ops.loss_fwd(p.detach().cuda(), t.cuda(), ce, dice, sm)
+    assert abs(tg.sum().item() - total.item()) < 1e-5 * max(1.0, abs(total.item()))
+    gp = ops.loss_bwd(p.detach().cuda(), t.cuda(), ce, dice, sm, ws, None)
+    assert rel_err(gp.cpu(), p.grad) < 1e-4
+    gp2 = ops.loss_bwd(p.detach().cuda(), t.cuda(), ce, dice, sm, ws, torch.tensor([2.0]).cuda(), gp.clone(), True)
+    assert rel_err(gp2.cpu(), 3 * p.grad) < 1e-4
+
+
+def test_layout_roundtrip_and_errors():
+    ops = _ops()
+    from ctunet_amd import _lib
+    x = torch.randn(2, 3, 4, 6, 10, generator=g(1))
+    a = ops.ncdhw_to_cl(x.cuda())
+    assert a.cp == 8 and torch.all(a.buf[..., 3:] == 0)
+    assert torch.equal(ops.cl_to_ncdhw(a, 3).cpu(), x)
+    with pytest.raises(RuntimeError):
+        ops.ncdhw_to_cl(x)                       # CPU tensor: no fallback
+    with pytest.raises(_lib.CtuError):
+        ops.pack_conv_w(torch.zeros(4, 4, 7, 7, 7).cuda(), None, 8, 8, 0)     # k=7 unsupported -> loud error
