@@ -293,10 +293,10 @@ __global__ __launch_bounds__(HB) void loss_bwd_kernel(const float* __restrict__ 
                                                       const float* __restrict__ gscale, float* __restrict__ gpred,
                                                       int accumulate) {
     const int n = blockIdx.y;
-    const float gs = gscale ? gscale[0] : 1.f;
-    const float kce = gs * ce_lambda / ((float)N * (float)V);
+    const float gs_ce = gscale ? gscale[0] : 1.f, gs_d = gscale ? gscale[1] : 1.f;
+    const float kce = gs_ce * ce_lambda / ((float)N * (float)V);
     const float nume = tail[n * 2 + 0], dene = tail[n * 2 + 1];
-    const float kd = gs * dice_lambda * (-2.f / (float)N);
+    const float kd = gs_d * dice_lambda * (-2.f / (float)N);
     const float kd_t = kd / dene, kd_p = kd * nume * 2.f / (dene * dene);
     const size_t base = (size_t)n * 2 * V;
     for (int64_t v = (int64_t)blockIdx.x * HB + threadIdx.x; v < V; v += (int64_t)gridDim.x * HB) {

@@ -1,0 +1,421 @@
+"""Kernel sequencing for the U-Net forward / backward on MI355X.
+
+``UNetEngine`` turns a ``NetPlan`` (the channel plan of one of the reference's model classes)
+into the sequence of libctunet_hip.so calls that computes ``UNet.forward``
+(/root/reference/ctunet/pytorch/models.py:226-261, legacy :509-538) and its backward.  It is
+the analogue of torch autograd + ATen dispatch for this one graph; all arithmetic happens in the
+HIP kernels (``ops``), torch only owns memory and the stream.
+
+Data flow (DESIGN.md has the picture):
+  * activations are channels-last fp32, channels padded to 8;
+  * every conv stores its RAW output and BatchNorm+ReLU is applied lazily by the consumer
+    (per-channel scale/shift from ``bn_finalize``), so BN/ReLU never cost an HBM pass forward;
+  * the skip concat is free: the decoder's second conv writes channels [0, Cp) and the encoder's
+    second conv writes channels [Cp, 2Cp) of one buffer per resolution level
+    (``torch.cat((ubl, d), 1)``, models.py:249 -- upsampled first, skip second);
+  * backward re-reads the raw tensors and recomputes activations/pool argmax on the fly; nothing
+    but raw conv outputs and per-channel statistics is saved.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import ops
+from .ops import CL, pad8
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+@dataclass
+class BlockPlan:
+    prefix: str          # state_dict prefix of the Sequential, e.g. "d_blocks.0.block"
+    first: int           # index of the first Conv3d in it (1 when a ConvTranspose3d sits at 0)
+    cin: int             # logical input channels of the first conv (= ConvTranspose channels for up blocks)
+    cout: int
+
+
+@dataclass
+class NetPlan:
+    k: int
+    conv_bias: bool
+    in_ch: int
+    out_ch: int
+    enc: List[BlockPlan]
+    center: BlockPlan
+    center_live: bool    # False: generic UNet drops the centre block's output (models.py:241)
+    dec: List[BlockPlan]
+    head: str
+    act: int             # bit0 softmax, bit1 sigmoid
+    head_mode: int       # 0 plain, 1 SP re-encoding, 2 SP + softmax
+
+
+class _ConvRec:
+    """What one conv+BN stage leaves behind for backward."""
+    __slots__ = ("x", "y", "vec", "stats", "nblk", "conv", "bn", "cin", "cout", "imap", "bias")
+
+
+class UNetEngine:
+    def __init__(self, plan: NetPlan):
+        self.plan = plan
+        self._pack_cache: Dict[Tuple, Tuple[int, torch.Tensor]] = {}
+        self._imaps: Dict[Tuple, torch.Tensor] = {}
+
+    # ------------------------------------------------------------------ small helpers
+    def _imap(self, segs: Tuple[Tuple[int, int], ...], device) -> Optional[torch.Tensor]:
+        """segs: ((n_logical, padded_start), ...) -> int32 map logical channel -> padded position."""
+        idx: List[int] = []
+        for n, start in segs:
+            idx += list(range(start, start + n))
+        if idx == list(range(len(idx))):
+            return None
+        key = (segs, str(device))
+        t = self._imaps.get(key)
+        if t is None:
+            t = torch.tensor(idx, dtype=torch.int32, device=device)
+            self._imaps[key] = t
+        return t
+
+    def _packed(self, name: str, w: torch.Tensor, kind: str, imap, rin_p: int, nout_p: int, mode: int) -> torch.Tensor:
+        key = (name, kind, mode, rin_p, nout_p)
+        hit = self._pack_cache.get(key)
+        ver = (w._version, w.data_ptr())
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        wd = w.detach()
+        wp = ops.pack_conv_w(wd, imap, rin_p, nout_p, mode) if kind == "conv" else \
+            ops.pack_convt_w(wd, imap, rin_p, nout_p, mode)
+        self._pack_cache[key] = (ver, wp)
+        return wp
+
+    @staticmethod
+    def _pad_vec(v: torch.Tensor, cp: int) -> torch.Tensor:
+        if v.numel() == cp:
+            return v.detach()
+        out = torch.zeros(cp, dtype=torch.float32, device=v.device)
+        out[:v.numel()] = v.detach()
+        return out
+
+    # ------------------------------------------------------------------ forward pieces
+    def _conv_bn(self, P, x: CL, conv: str, bn: str, cin: int, cout: int, imap, out: CL, vec4: torch.Tensor,
+                 training: bool, n_upd: int, save: bool) -> Tuple[CL, Optional[_ConvRec]]:
+        k = self.plan.k
+        w = P[conv + ".weight"]
+        wp = self._packed(conv, w, "conv", imap, x.cp, out.cp, 0)
+        bias = P.get(conv + ".bias")
+        bias_p = self._pad_vec(bias, out.cp) if bias is not None else None
+        dims = x.dims
+        c = cout
+        if training:
+            nblk = ops.conv_num_blocks(dims)
+            stats = torch.empty((nblk, 2, out.cp), dtype=torch.float32, device=x.buf.device)
+            ops.conv3d_fwd(x, wp, bias_p, out, k, stats, (cin, cout))
+            ops.bn_finalize_into(stats, nblk, c, out.cp, x.nvox, P[bn + ".weight"], P[bn + ".bias"],
+                                 P[bn + ".running_mean"], P[bn + ".running_var"], BN_MOMENTUM, BN_EPS, n_upd, vec4)
+            if n_upd:
+                P[bn + ".num_batches_tracked"].add_(n_upd)
+        else:
+            stats, nblk = None, 0
+            ops.conv3d_fwd(x, wp, bias_p, out, k, None, (cin, cout))
+            ops.bn_eval_affine_into(P[bn + ".weight"], P[bn + ".bias"], P[bn + ".running_mean"],
+                                    P[bn + ".running_var"], BN_EPS, c, out.cp, vec4)
+        y = out.with_xf(vec4[0], vec4[1], True)
+        rec = None
+        if save:
+            rec = _ConvRec()
+            rec.x, rec.y, rec.vec, rec.stats, rec.nblk = x, out.raw(), vec4, stats, nblk
+            rec.conv, rec.bn, rec.cin, rec.cout, rec.imap, rec.bias = conv, bn, cin, cout, imap, bias is not None
+        return y, rec
+
+    def forward(self, P: Dict[str, torch.Tensor], x: torch.Tensor, training: bool, save: bool, chk: bool):
+        """Returns (out0, out1 | None, ctx | None)."""
+        plan = self.plan
+        dev = x.device
+        n, cin, d, h, w = x.shape
+        nlev = len(plan.enc)
+        if cin != plan.in_ch:
+            raise RuntimeError(f"ctunet_amd: expected {plan.in_ch} input channels, got {cin}")
+        if any(s % (1 << nlev) for s in (d, h, w)):
+            raise RuntimeError(f"ctunet_amd: spatial size {(d, h, w)} must be divisible by {1 << nlev}")
+        if training and n * (d >> nlev) * (h >> nlev) * (w >> nlev) <= 1:
+            # the reference's BatchNorm3d raises here too ("Expected more than 1 value per channel")
+            raise ValueError("Expected more than 1 value per channel when training (centre block)")
+        ctx = {"recs": {}, "levels": [], "training": training, "chk": chk} if save else None
+        n_upd = 1 if training else 0
+
+        cur = ops.ncdhw_to_cl(x)
+        x_cl = cur
+        cat: List[torch.Tensor] = []     # concat buffer per level
+        xf: List[torch.Tensor] = []      # [4, 2Cp] scale/shift/mean/invstd of the concat buffer
+        pooled: List[CL] = []
+        dskip: List[CL] = []
+        dd, hh, ww = d, h, w
+        recs = {}
+        for i, blk in enumerate(plan.enc):
+            cp = pad8(blk.cout)
+            cat.append(torch.empty((n, dd, hh, ww, 2 * cp), dtype=torch.float32, device=dev))
+            xf.append(torch.zeros((4, 2 * cp), dtype=torch.float32, device=dev))
+            t1 = CL(torch.empty((n, dd, hh, ww, cp), dtype=torch.float32, device=dev), 0, cp)
+            v1 = torch.empty((4, cp), dtype=torch.float32, device=dev)
+            imap = self._imap(((blk.cin, 0),), dev)
+            a1, recs[(blk.prefix, 1)] = self._conv_bn(P, cur, f"{blk.prefix}.{blk.first}", f"{blk.prefix}.{blk.first + 1}",
+                                                      blk.cin, blk.cout, imap, t1, v1, training, n_upd, save)
+            a2, recs[(blk.prefix, 2)] = self._conv_bn(P, a1, f"{blk.prefix}.{blk.first + 3}", f"{blk.prefix}.{blk.first + 4}",
+                                                      blk.cout, blk.cout, None, CL(cat[i], cp, cp), xf[i][:, cp:],
+                                                      training, n_upd, save)
+            dskip.append(a2)
+            dd, hh, ww = dd // 2, hh // 2, ww // 2
+            pl = CL(torch.empty((n, dd, hh, ww, cp), dtype=torch.float32, device=dev), 0, cp)
+            ops.maxpool_fwd(a2, pl)
+            pooled.append(pl)
+            cur = pl
+        # ---- centre block
+        cb = plan.center
+        cpc = pad8(cb.cout)
+        center_out = None
+        if plan.center_live or training:
+            live = plan.center_live
+            c1 = CL(torch.empty((n, dd, hh, ww, cpc), dtype=torch.float32, device=dev), 0, cpc)
+            c2 = CL(torch.empty((n, dd, hh, ww, cpc), dtype=torch.float32, device=dev), 0, cpc)
+            v1 = torch.empty((4, cpc), dtype=torch.float32, device=dev)
+            v2 = torch.empty((4, cpc), dtype=torch.float32, device=dev)
+            a1, r1 = self._conv_bn(P, cur, f"{cb.prefix}.{cb.first}", f"{cb.prefix}.{cb.first + 1}", cb.cin, cb.cout,
+                                   None, c1, v1, training, n_upd, save and live)
+            a2, r2 = self._conv_bn(P, a1, f"{cb.prefix}.{cb.first + 3}", f"{cb.prefix}.{cb.first + 4}", cb.cout, cb.cout,
+                                   None, c2, v2, training, n_upd, save and live)
+            if live:
+                recs[(cb.prefix, 1)], recs[(cb.prefix, 2)] = r1, r2
+                center_out = a2
+        cur = center_out if plan.center_live else pooled[-1]
+        cur_segs = ((cb.cout if plan.center_live else plan.enc[-1].cout, 0),)
+        # ---- decoder
+        dec_in: List[CL] = []
+        ups: List[CL] = []
+        for j, blk in enumerate(plan.dec):
+            i = nlev - 1 - j
+            cp = pad8(blk.cout)
+            dd, hh, ww = dd * 2, hh * 2, ww * 2
+            ct = blk.cin                                  # ConvTranspose3d(C, C)
+            ctp = pad8(ct)
+            imap_t = self._imap(cur_segs, dev)
+            wt = P[f"{blk.prefix}.0.weight"]
+            wpt = self._packed(f"{blk.prefix}.0", wt, "convt", imap_t, cur.cp, ctp, 0)
+            up = CL(torch.empty((n, dd, hh, ww, ctp), dtype=torch.float32, device=dev), 0, ctp)
+            ops.convt_fwd(cur, wpt, self._pad_vec(P[f"{blk.prefix}.0.bias"], ctp), up)
+            dec_in.append(cur)
+            ups.append(up)
+            t1 = CL(torch.empty((n, dd, hh, ww, cp), dtype=torch.float32, device=dev), 0, cp)
+            v1 = torch.empty((4, cp), dtype=torch.float32, device=dev)
+            a1, recs[(blk.prefix, 1)] = self._conv_bn(P, up, f"{blk.prefix}.1", f"{blk.prefix}.2", ct, blk.cout, None, t1,
+                                                      v1, training, n_upd, save)
+            a2, recs[(blk.prefix, 2)] = self._conv_bn(P, a1, f"{blk.prefix}.4", f"{blk.prefix}.5", blk.cout, blk.cout, None,
+                                                      CL(cat[i], 0, cp), xf[i][:, :cp], training, n_upd, save)
+            cur = CL(cat[i], 0, 2 * cp, xf[i][0], xf[i][1], True)
+            cur_segs = ((blk.cout, 0), (blk.cout, cp))
+        # ---- head
+        imap_h = self._imap(cur_segs, dev)
+        wl, bl = P[plan.head + ".weight"], P[plan.head + ".bias"]
+        w2 = wl.detach().reshape(wl.shape[0], wl.shape[1])
+        out0, out1 = ops.head_fwd(cur, w2, bl.detach(), imap_h, plan.act, plan.head_mode)
+        if save:
+            ctx.update(recs=recs, x_cl=x_cl, cat=cat, xf=xf, pooled=pooled, dskip=dskip, dec_in=dec_in, ups=ups,
+                       head_in=cur, imap_h=imap_h, center_out=center_out, dims=(n, d, h, w))
+        return out0, out1, ctx
+
+    # ------------------------------------------------------------------ backward pieces
+    def _conv_bn_bwd(self, P, rec: _ConvRec, ga: CL, gin: Optional[CL], grads: Dict[str, torch.Tensor], ws, part):
+        """ga: gradient w.r.t. the ACTIVATED output (overwritten with the raw-output gradient).
+        gin: where to write the gradient w.r.t. this conv's activated input (None: not needed)."""
+        k = self.plan.k
+        dg, db = ops.bn_relu_bwd(rec.y, ga, rec.vec, P[rec.bn + ".weight"].detach(), rec.cout, part)
+        grads[rec.bn + ".weight"], grads[rec.bn + ".bias"] = dg, db
+        dw, dbias = ops.conv3d_wgrad(rec.x, ga, rec.cout, rec.cin, k, rec.imap, ws, rec.bias)
+        grads[rec.conv + ".weight"] = dw
+        if rec.bias:
+            grads[rec.conv + ".bias"] = dbias
+        if gin is not None:
+            wpd = self._packed(rec.conv, P[rec.conv + ".weight"], "conv", rec.imap, ga.cp, gin.cp, 1)
+            ops.conv3d_fwd(ga, wpd, None, gin, k, None, (rec.cout, rec.cin))
+
+    def backward(self, P: Dict[str, torch.Tensor], ctx, g0: torch.Tensor, g1: Optional[torch.Tensor],
+                 need_dx: bool, sync=None):
+        """sync: optional parallel.GradSync -- receives each block's weight gradients as soon as their
+        kernels are enqueued (head, decoder top->bottom, centre, encoder bottom->top)."""
+        plan = self.plan
+        recs = ctx["recs"]
+        n, d, h, w = ctx["dims"]
+        dev = g0.device
+        nlev = len(plan.enc)
+        grads: Dict[str, torch.Tensor] = {}
+        emitted: set = set()
+
+        def emit():
+            if sync is not None:
+                new = [(nm, g) for nm, g in grads.items() if nm not in emitted]
+                emitted.update(nm for nm, _ in new)
+                sync.push(new)
+        k = plan.k
+        # workspaces sized for the largest layer
+        ws_n, part_n = 1, 1
+        for r in recs.values():
+            if r is None:
+                continue
+            ws_n = max(ws_n, ops.conv3d_wgrad_ws(r.x.dims, k, r.x.cp, r.y.cp))
+            part_n = max(part_n, ops.bn_bwd_partials_floats(r.y.nvox, r.y.cp))
+        for x_in, up in zip(ctx["dec_in"], ctx["ups"]):
+            ws_n = max(ws_n, ops.convt_wgrad_ws(x_in.dims, x_in.cp, up.cp))
+        ws = torch.empty(ws_n, dtype=torch.float32, device=dev)
+        part = torch.empty(part_n, dtype=torch.float32, device=dev)
+
+        # the second running-stat update that torch.utils.checkpoint's recompute performs
+        # (models.py:232-255).  The dead centre block is never recomputed.
+        if ctx["training"] and ctx["chk"]:
+            scratch = {}
+            for r in recs.values():
+                if r is None or r.stats is None:
+                    continue
+                cp = r.y.cp
+                sv = scratch.get(cp)
+                if sv is None:
+                    sv = scratch[cp] = torch.empty((4, cp), dtype=torch.float32, device=dev)
+                ops.bn_finalize_into(r.stats, r.nblk, r.cout, cp, r.y.nvox, P[r.bn + ".weight"], P[r.bn + ".bias"],
+                                     P[r.bn + ".running_mean"], P[r.bn + ".running_var"], BN_MOMENTUM, BN_EPS, 1, sv)
+                P[r.bn + ".num_batches_tracked"].add_(1)
+
+        cat, head_in = ctx["cat"], ctx["head_in"]
+        gcat = [torch.empty_like(c) for c in cat]
+        wl, bl = P[plan.head + ".weight"], P[plan.head + ".bias"]
+        w2 = wl.detach().reshape(wl.shape[0], wl.shape[1])
+        dwl, dbl = ops.head_bwd(head_in, w2, bl.detach(), ctx["imap_h"], plan.act, plan.head_mode, g0.contiguous(),
+                                None if g1 is None else g1.contiguous(), CL(gcat[0], 0, gcat[0].shape[-1]))
+        grads[plan.head + ".weight"], grads[plan.head + ".bias"] = dwl.reshape(wl.shape), dbl
+        emit()
+
+        g_deep: Optional[CL] = None
+        for j in range(nlev - 1, -1, -1):           # decoder blocks, top level first
+            blk = plan.dec[j]
+            i = nlev - 1 - j
+            cp = pad8(blk.cout)
+            r1, r2 = recs[(blk.prefix, 1)], recs[(blk.prefix, 2)]
+            g_u2 = CL(gcat[i], 0, cp)
+            g_u1 = CL(torch.empty_like(r1.y.buf), 0, cp)
+            self._conv_bn_bwd(P, r2, g_u2, g_u1, grads, ws, part)
+            up = ctx["ups"][j]
+            g_up = CL(torch.empty_like(up.buf), 0, up.cp)
+            self._conv_bn_bwd(P, r1, g_u1, g_up, grads, ws, part)
+            x_in = ctx["dec_in"][j]
+            ct = blk.cin
+            segs = ((plan.dec[j - 1].cout, 0), (plan.dec[j - 1].cout, pad8(plan.dec[j - 1].cout))) if j > 0 else \
+                ((ct, 0),)
+            imap_t = self._imap(segs, dev)
+            wt = P[f"{blk.prefix}.0.weight"]
+            dwt, dbt = ops.convt_wgrad(x_in, g_up, ct, ct, imap_t, ws)
+            grads[f"{blk.prefix}.0.weight"], grads[f"{blk.prefix}.0.bias"] = dwt, dbt
+            wpd = self._packed(f"{blk.prefix}.0", wt, "convt", imap_t, g_up.cp, x_in.cp, 1)
+            if j > 0:
+                gin = CL(gcat[i + 1], 0, gcat[i + 1].shape[-1])
+            else:
+                gin = CL(torch.empty_like(x_in.buf), 0, x_in.cp)
+                g_deep = gin
+            ops.convt_bwd_data(g_up, wpd, gin)
+            emit()
+        g_pool = g_deep
+        if plan.center_live:
+            cb = plan.center
+            r1, r2 = recs[(cb.prefix, 1)], recs[(cb.prefix, 2)]
+            g_c1 = CL(torch.empty_like(r1.y.buf), 0, r1.y.cp)
+            self._conv_bn_bwd(P, r2, g_deep, g_c1, grads, ws, part)
+            g_pool = CL(torch.empty_like(ctx["pooled"][-1].buf), 0, ctx["pooled"][-1].cp)
+            self._conv_bn_bwd(P, r1, g_c1, g_pool, grads, ws, part)
+            emit()
+        dx = None
+        for i in range(nlev - 1, -1, -1):           # encoder blocks, deepest first
+            blk = plan.enc[i]
+            cp = pad8(blk.cout)
+            r1, r2 = recs[(blk.prefix, 1)], recs[(blk.prefix, 2)]
+            g_d2 = CL(gcat[i], cp, cp)
+            ops.maxpool_bwd(ctx["dskip"][i], g_pool, g_d2, True)
+            g_d1 = CL(torch.empty_like(r1.y.buf), 0, cp)
+            self._conv_bn_bwd(P, r2, g_d2, g_d1, grads, ws, part)
+            if i > 0:
+                g_pool = CL(torch.empty_like(ctx["pooled"][i - 1].buf), 0, ctx["pooled"][i - 1].cp)
+                self._conv_bn_bwd(P, r1, g_d1, g_pool, grads, ws, part)
+            elif need_dx:
+                g_x = CL(torch.empty_like(ctx["x_cl"].buf), 0, ctx["x_cl"].cp)
+                self._conv_bn_bwd(P, r1, g_d1, g_x, grads, ws, part)
+                dx = ops.cl_to_ncdhw(g_x, plan.in_ch)
+            else:
+                self._conv_bn_bwd(P, r1, g_d1, None, grads, ws, part)
+            emit()
+        if sync is not None:
+            grads.update(sync.finish())
+        return grads, dx
+
+
+# ----------------------------------------------------------------------------- autograd glue
+class _UNetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(fctx, module, engine, names, x_req, x, *params):
+        P = _tensor_dict(module)
+        out0, out1, ctx = engine.forward(P, x, module.training, True, bool(getattr(module, "chk", False)))
+        fctx.engine, fctx.module, fctx.names, fctx.ctx = engine, module, names, ctx
+        fctx.two = out1 is not None
+        fctx.x_req = x_req
+        if out1 is None:
+            return out0
+        return out0, out1
+
+    @staticmethod
+    def backward(fctx, *gouts):
+        if fctx.ctx is None:
+            raise RuntimeError("ctunet_amd: backward through the same forward twice is not supported")
+        g0 = gouts[0]
+        g1 = gouts[1] if fctx.two else None
+        ctx = fctx.ctx
+        if g0 is None:
+            g0 = torch.zeros(_out_shape(ctx, fctx, 0), device=ctx["x_cl"].buf.device)
+        if fctx.two and g1 is None:
+            g1 = torch.zeros_like(g0)
+        P = _tensor_dict(fctx.module)
+        from .parallel import make_sync
+        with torch.no_grad():
+            grads, dx = fctx.engine.backward(P, ctx, g0, g1, fctx.x_req, make_sync(fctx.module))
+        fctx.ctx = None
+        # parameters the graph never touches (the dead centre block, models.py:241) get None,
+        # exactly as torch autograd leaves them in the reference
+        return (None, None, None, None, dx) + tuple(grads.get(nm) for nm in fctx.names)
+
+
+def _out_shape(ctx, fctx, idx):
+    n, d, h, w = ctx["dims"]
+    c = 2 if fctx.two else fctx.engine.plan.out_ch
+    return (n, c, d, h, w)
+
+
+def _tensor_dict(module) -> Dict[str, torch.Tensor]:
+    P = dict(module.named_parameters())
+    P.update(dict(module.named_buffers()))
+    return P
+
+
+def run_network(module, engine: UNetEngine, x: torch.Tensor):
+    if not isinstance(x, torch.Tensor) or x.dim() != 5:
+        raise RuntimeError("ctunet_amd: expected a [N, C, D, H, W] tensor")
+    if not x.is_cuda:
+        raise RuntimeError("ctunet_amd: this model runs on the MI355X only (input is on %s); there is no CPU path"
+                           % x.device)
+    if x.dtype != torch.float32:
+        raise RuntimeError(f"ctunet_amd: fp32 input expected, got {x.dtype}")
+    names, params = zip(*module.named_parameters())
+    for p in params:
+        if p.device != x.device:
+            raise RuntimeError("ctunet_amd: module parameters and input must be on the same GPU (call .to(device))")
+    need_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+    if not need_grad:
+        with torch.no_grad():
+            out0, out1, _ = engine.forward(_tensor_dict(module), x, module.training, False, False)
+        return out0 if out1 is None else (out0, out1)
+    return _UNetFn.apply(module, engine, names, x.requires_grad, x, *params)

@@ -39,6 +39,52 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class KernelTimer:
+    """Optional HIP-event bracketing of individual launches (bench.py's roofline leg).
+
+    Events are recorded on the stream the kernels are launched on (torch's current stream), so they
+    time exactly one launch each.  ``records`` holds (tag, algorithmic_flops, algorithmic_bytes, start, end).
+    """
+
+    def __init__(self):
+        self.records = []
+
+    def begin(self):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
+    def end(self, tag, flops, nbytes, start):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        self.records.append((tag, flops, nbytes, start, ev))
+
+    def summary(self):
+        """{tag: dict(launches, total_ms, avg_ms, flops, bytes)} -- call after a device synchronize."""
+        out = {}
+        for tag, fl, nb, a, b in self.records:
+            d = out.setdefault(tag, dict(launches=0, total_ms=0.0, flops=0.0, bytes=0.0))
+            d["launches"] += 1
+            d["total_ms"] += a.elapsed_time(b)
+            d["flops"] += fl
+            d["bytes"] += nb
+        for d in out.values():
+            d["avg_ms"] = d["total_ms"] / d["launches"]
+        return out
+
+
+TIMER: Optional[KernelTimer] = None      # set by bench.py; None in normal operation
+
+
+def _tile_tag(w: int) -> str:
+    return "4_4_16" if w >= 16 else ("4_8_8" if w >= 8 else "4_4_4")
+
+
+def _nt(nout_p: int) -> int:
+    n16 = (nout_p + 15) // 16
+    return 1 if n16 == 1 else (2 if n16 == 2 else 4)
+
+
 @dataclass
 class CL:
     buf: torch.Tensor                       # [N, D, H, W, cs] contiguous fp32
@@ -127,13 +173,20 @@ def conv_num_blocks(dims) -> int:
 
 
 def conv3d_fwd(x: CL, wp: torch.Tensor, bias_p: Optional[torch.Tensor], out: CL, k: int,
-               stats: Optional[torch.Tensor] = None) -> None:
+               stats: Optional[torch.Tensor] = None, algo_ch: Optional[Tuple[int, int]] = None) -> None:
+    """algo_ch = (logical Cin, logical Cout) -- only used to count algorithmic FLOPs when timing."""
     n, d, h, w = x.dims
     assert out.dims == x.dims
     lib = _lib.load()
+    t0 = TIMER.begin() if TIMER is not None else None
     _lib.check(lib.ctu_conv3d_fwd(x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), wp.data_ptr(),
                                   _ptr(bias_p), out.ptr, out.cs, out.cp, _ptr(stats), n, d, h, w, k, _stream()),
                "conv3d_fwd")
+    if t0 is not None:
+        ci, co = algo_ch if algo_ch is not None else (x.cp, out.cp)
+        vox = n * d * h * w
+        TIMER.end(f"conv3d_fwd_kernel<{k},{_nt(out.cp)},{_tile_tag(w)}>", 2.0 * ci * co * k ** 3 * vox,
+                  4.0 * vox * (ci + co), t0)
 
 
 def conv3d_wgrad(x: CL, g: CL, co: int, ci: int, k: int, imap: Optional[torch.Tensor], ws: torch.Tensor,
@@ -144,9 +197,13 @@ def conv3d_wgrad(x: CL, g: CL, co: int, ci: int, k: int, imap: Optional[torch.Te
     assert ws.numel() >= need, (ws.numel(), need)
     dw = torch.empty((co, ci, k, k, k), dtype=torch.float32, device=x.buf.device)
     db = torch.empty(co, dtype=torch.float32, device=x.buf.device) if want_bias else None
+    t0 = TIMER.begin() if TIMER is not None else None
     _lib.check(lib.ctu_conv3d_wgrad(x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), g.ptr, g.cs, g.cp,
                                     dw.data_ptr(), _ptr(db), co, ci, _ptr(imap), ws.data_ptr(), n, d, h, w, k,
                                     _stream()), "conv3d_wgrad")
+    if t0 is not None:
+        vox = n * d * h * w
+        TIMER.end(f"conv3d_wgrad<{k},{_tile_tag(w)}>(+reduce)", 2.0 * ci * co * k ** 3 * vox, 4.0 * vox * (ci + co), t0)
     return dw, db
 
 
@@ -156,21 +213,29 @@ def conv3d_wgrad_ws(dims, k, cin_p, cout_p) -> int:
 
 
 # ---------------------------------------------------------------------------- batch norm
-def bn_finalize(stats, nblocks, c, cp, count, gamma, beta, rmean, rvar, momentum, eps, n_updates):
-    dev = stats.device
-    vec = torch.empty((4, cp), dtype=torch.float32, device=dev)     # scale, shift, mean, invstd
+def bn_finalize_into(stats, nblocks, c, cp, count, gamma, beta, rmean, rvar, momentum, eps, n_updates, vec4):
+    """vec4: [4, cp] view (rows may be strided) receiving scale, shift, mean, invstd."""
     lib = _lib.load()
     _lib.check(lib.ctu_bn_finalize(stats.data_ptr(), nblocks, c, cp, float(count), gamma.data_ptr(), beta.data_ptr(),
-                                   _ptr(rmean), _ptr(rvar), momentum, eps, n_updates, vec[0].data_ptr(),
-                                   vec[1].data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(), _stream()), "bn_finalize")
+                                   _ptr(rmean), _ptr(rvar), momentum, eps, n_updates, vec4[0].data_ptr(),
+                                   vec4[1].data_ptr(), vec4[2].data_ptr(), vec4[3].data_ptr(), _stream()), "bn_finalize")
+
+
+def bn_finalize(stats, nblocks, c, cp, count, gamma, beta, rmean, rvar, momentum, eps, n_updates):
+    vec = torch.empty((4, cp), dtype=torch.float32, device=stats.device)     # scale, shift, mean, invstd
+    bn_finalize_into(stats, nblocks, c, cp, count, gamma, beta, rmean, rvar, momentum, eps, n_updates, vec)
     return vec
+
+
+def bn_eval_affine_into(gamma, beta, rmean, rvar, eps, c, cp, vec):
+    lib = _lib.load()
+    _lib.check(lib.ctu_bn_eval_affine(gamma.data_ptr(), beta.data_ptr(), rmean.data_ptr(), rvar.data_ptr(), eps, c, cp,
+                                      vec[0].data_ptr(), vec[1].data_ptr(), _stream()), "bn_eval_affine")
 
 
 def bn_eval_affine(gamma, beta, rmean, rvar, eps, c, cp):
     vec = torch.empty((2, cp), dtype=torch.float32, device=gamma.device)
-    lib = _lib.load()
-    _lib.check(lib.ctu_bn_eval_affine(gamma.data_ptr(), beta.data_ptr(), rmean.data_ptr(), rvar.data_ptr(), eps, c, cp,
-                                      vec[0].data_ptr(), vec[1].data_ptr(), _stream()), "bn_eval_affine")
+    bn_eval_affine_into(gamma, beta, rmean, rvar, eps, c, cp, vec)
     return vec
 
 

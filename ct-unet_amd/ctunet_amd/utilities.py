@@ -1,0 +1,64 @@
+"""Host-side mirrors of the ``ctunet.utilities`` helpers the hot path touches.
+
+  set_cfg_params / load_params ... utilities.py:215-256, ctunet/__init__.py:1-2 (ini -> typed dict)
+  hard_segm_from_tensor .......... utilities.py:103-124
+  dice_coeff ..................... utilities.py:53-59 (monai.compute_meandice; PARITY UNPINNED, see below)
+"""
+from __future__ import annotations
+
+import configparser
+import os
+
+import torch
+
+from .losses import dice_loss  # noqa: F401  (same import location as the reference: utils.dice_loss)
+
+
+def set_cfg_params(cfg_file=None, default_dict=None):
+    """INI -> dict; key prefixes ``i_ f_ b_ s_`` select int/float/bool/str and are stripped,
+    sections are flattened, un-prefixed keys stay strings (utilities.py:215-256)."""
+    if cfg_file is None:
+        return None
+    out = default_dict if default_dict is not None else dict()
+    if not os.path.exists(cfg_file):
+        raise FileNotFoundError(f"The provided cfg file does not exist ({cfg_file}).")
+    cfg = configparser.ConfigParser()
+    cfg.read(cfg_file)
+    conv = {"i_": lambda sec, k: sec.getint(k), "f_": lambda sec, k: sec.getfloat(k),
+            "b_": lambda sec, k: sec.getboolean(k), "s_": lambda sec, k: sec[k]}
+    for name in cfg.sections():
+        sec = cfg[name]
+        for key in sec:
+            f = conv.get(key[:2])
+            if f is None:
+                out[key] = sec[key]
+            else:
+                out[key[2:]] = f(sec, key)
+    return out
+
+
+def load_params(cfg_file, default_dict=None):
+    """``ctunet.load_params`` (ctunet/__init__.py): alias of set_cfg_params."""
+    return set_cfg_params(cfg_file, {} if default_dict is None else default_dict)
+
+
+def hard_segm_from_tensor(prob_map, keep_dims=False):
+    """argmax over the class dimension as float (utilities.py:103-124)."""
+    dim = 1 if prob_map.dim() == 5 else 0
+    seg = torch.argmax(prob_map, dim=dim).type(torch.float)
+    return seg.unsqueeze(dim) if keep_dims else seg
+
+
+def dice_coeff(pred, target):
+    """Foreground hard Dice of argmax(pred) against a one-hot target, mean over batch and classes.
+
+    The reference calls ``monai.metrics.compute_meandice(one_hot(argmax(pred,1)), target,
+    include_background=False)`` (utilities.py:53-59).  monai is an unpinned third-party package that
+    is not available here, so this follows its published definition 2|A.B| / (|A| + |B|);
+    empty-vs-empty is defined as 1.0 (monai returns NaN).  PARITY UNPINNED.
+    """
+    c = pred.shape[1]
+    hard = torch.nn.functional.one_hot(torch.argmax(pred, 1), c).movedim(-1, 1).to(target.dtype)
+    a, b = hard[:, 1:].flatten(2), target[:, 1:].flatten(2)
+    inter, tot = (a * b).sum(2), a.sum(2) + b.sum(2)
+    return torch.where(tot > 0, 2 * inter / tot.clamp_min(1), torch.ones_like(tot)).mean()

@@ -196,8 +196,9 @@ int ctu_head_bwd(const float* in, int in_cs, int cin_p, const float* in_scale,
  *  ce term   = ce_lambda   * CrossEntropy(pred as logits, argmax(target,1)), mean over N*V
  *  dice term = dice_lambda * dice_loss(P, target), P = softmax(pred,1) if dice_softmax else pred
  * terms (device, float[2]) = {ce term, dice term}.  ws: ctu_loss_ws_floats(N, V) floats,
- * kept until ctu_loss_bwd, which writes gpred = gscale[0] * d(ce term + dice term)/dpred
- * (gscale NULL = 1; accumulate != 0: gpred += ). */
+ * kept until ctu_loss_bwd, which writes
+ *   gpred = gscale[0] * d(ce term)/dpred + gscale[1] * d(dice term)/dpred
+ * (gscale: device float[2], NULL = {1,1}; accumulate != 0: gpred += ). */
 size_t ctu_loss_ws_floats(int N, int64_t V);
 int ctu_loss_fwd(const float* pred, const float* target, int N, int64_t V, float ce_lambda,
                  float dice_lambda, int dice_softmax, float* terms, float* ws, void* stream);

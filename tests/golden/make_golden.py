@@ -55,7 +55,7 @@ def onehot_target(shape, seed, p=0.3):
 
 
 def to_np(sd):
-    return {k: v.detach().cpu().numpy() for k, v in sd.items()}
+    return {k: v.detach().cpu().numpy().copy() for k, v in sd.items()}
 
 
 class Holder:

@@ -349,7 +349,7 @@ def test_loss_fwd_bwd(ce, dice, sm):
     assert abs(tg.sum().item() - total.item()) < 1e-5 * max(1.0, abs(total.item()))
     gp = ops.loss_bwd(p.detach().cuda(), t.cuda(), ce, dice, sm, ws, None)
     assert rel_err(gp.cpu(), p.grad) < 1e-4
-    gp2 = ops.loss_bwd(p.detach().cuda(), t.cuda(), ce, dice, sm, ws, torch.tensor([2.0]).cuda(), gp.clone(), True)
+    gp2 = ops.loss_bwd(p.detach().cuda(), t.cuda(), ce, dice, sm, ws, torch.tensor([2.0, 2.0]).cuda(), gp.clone(), True)
     assert rel_err(gp2.cpu(), 3 * p.grad) < 1e-4
 
 
