@@ -27,6 +27,7 @@ struct ConvP {
     int in_cs, rin_p, in_relu, out_cs, nout_p;
     int N, D, H, W;
     int tiles_d, tiles_h, tiles_w;
+    int n16;                 // number of 16-wide output-channel tiles in the packed weights
 };
 
 template <int KS>
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(256) void conv3d_fwd_kernel(ConvP p) {
     const int nchunk = p.rin_p >> 3;
     const int half = tid & 1;
     const bool has_xf = p.in_scale != nullptr;
-    const float* wblk = p.wp + (size_t)by * nchunk * NSTAGE * WFL;
+    const int n16 = p.n16;
 
     for (int c = 0; c < nchunk; ++c) {
         float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -126,9 +127,14 @@ __global__ __launch_bounds__(256) void conv3d_fwd_kernel(ConvP p) {
         }
         for (int s = 0; s < NSTAGE; ++s) {
             if (s > 0) __syncthreads();
-            const float* wsrc = wblk + ((size_t)c * NSTAGE + s) * WFL;
-            for (int i = tid * 4; i < WFL; i += 1024)
-                *reinterpret_cast<float4*>(&sW[i]) = *reinterpret_cast<const float4*>(wsrc + i);
+            // packed weights: [chunk][stage][tap][n16 tile][128]; this block takes tiles by*NT .. by*NT+NT-1
+            const float* wsrc = p.wp + ((size_t)c * NSTAGE + s) * STAPS * n16 * 128 + (size_t)by * NT * 128;
+            for (int i = tid * 4; i < WFL; i += 1024) {
+                const int ts = i / (NT * 128), r = i % (NT * 128);
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (by * NT * 128 + r < n16 * 128) v = *reinterpret_cast<const float4*>(wsrc + (size_t)ts * n16 * 128 + r);
+                *reinterpret_cast<float4*>(&sW[i]) = v;
+            }
             __syncthreads();
 #pragma unroll
             for (int ts = 0; ts < STAPS; ++ts) {
@@ -211,19 +217,19 @@ __global__ __launch_bounds__(256) void conv3d_fwd_kernel(ConvP p) {
 }
 
 // ------------------------------------------------------------------ packing
-// wp index for (y-block, chunk c, stage s, tap-in-stage ts, nt, kq, n, j)
+// wp index for (chunk c, stage s, tap-in-stage ts, 16-wide output tile, kq, n, j)
 template <int KS>
-__device__ __forceinline__ size_t wp_index(int rp, int np, int t, int nchunk, int NT) {
+__device__ __forceinline__ size_t wp_index(int rp, int np, int t, int n16) {
     constexpr int STAPS = Taps<KS>::STAPS, NSTAGE = Taps<KS>::NSTAGE;
     const int c = rp >> 3, kq = (rp & 7) >> 1, j = rp & 1;
-    const int yb = np / (16 * NT), nt = (np / 16) % NT, n = np & 15;
+    const int nt = np >> 4, n = np & 15;
     const int s = t / STAPS, ts = t % STAPS;
-    return ((((size_t)(yb * nchunk + c) * NSTAGE + s) * STAPS + ts) * NT + nt) * 128 + kq * 32 + n * 2 + j;
+    return ((((size_t)c * NSTAGE + s) * STAPS + ts) * n16 + nt) * 128 + kq * 32 + n * 2 + j;
 }
 
 template <int KS>
 __global__ void pack_conv_w_kernel(const float* __restrict__ w, float* __restrict__ wp, int Co, int Ci,
-                                   const int32_t* __restrict__ imap, int rin_p, int NT, int mode) {
+                                   const int32_t* __restrict__ imap, int n16, int mode) {
     constexpr int TAPS = Taps<KS>::TAPS;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= Co * Ci * TAPS) return;
@@ -232,12 +238,21 @@ __global__ void pack_conv_w_kernel(const float* __restrict__ w, float* __restric
     int rp, np, tt;
     if (mode == 0) { rp = cip; np = co; tt = t; }
     else { rp = co; np = cip; tt = TAPS - 1 - t; }
-    wp[wp_index<KS>(rp, np, tt, rin_p >> 3, NT)] = w[idx];
+    wp[wp_index<KS>(rp, np, tt, n16)] = w[idx];
 }
 
-inline int pick_nt(int nout_p) {
+// Launch shape: output-channel tiles per block (NT) and spatial tile.  Big volumes take the widest tile
+// and up to 4 N-tiles per block (best operand reuse); small volumes (the 8^3/16^3 bottleneck levels)
+// shrink both so that the grid still covers the 256 CUs.
+inline void pick_launch(int N, int D, int H, int W, int nout_p, int* nt, int* td, int* th, int* tw) {
     const int n16 = (nout_p + 15) / 16;
-    return n16 == 1 ? 1 : (n16 == 2 ? 2 : 4);
+    *nt = n16 == 1 ? 1 : (n16 == 2 ? 2 : 4);
+    pick_tile(W, td, th, tw);
+    auto blocks = [&](int nt_, int td_, int th_, int tw_) {
+        return (long)N * ceil_div(D, td_) * ceil_div(H, th_) * ceil_div(W, tw_) * ceil_div(n16, nt_);
+    };
+    while (blocks(*nt, *td, *th, *tw) < 256 && *nt > 1) *nt >>= 1;
+    if (blocks(*nt, *td, *th, *tw) < 256 && *tw > 4) { *td = 4; *th = 4; *tw = 4; }
 }
 
 // ------------------------------------------------------------------ weight gradient
@@ -336,36 +351,71 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(WgP p) {
             }
         }
     }
-    // per-wave partial slab [BT][16 ci][16 co]
-    const size_t slab = ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave;
+    // sum the 4 waves through LDS (RT taps per round, reusing sA) -> ONE partial slab [BT][16 ci][16 co] per block
+    constexpr int RT = (HV * 16 / 1024) < 8 ? (HV * 16 / 1024) : 8;
+    static_assert(RT >= 1 && 4 * RT * 256 <= HV * 16, "reduction scratch must fit in sA");
+    const size_t slab = (size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     float* dst = p.ws + slab * (BT * 256);
+    for (int t0 = 0; t0 < BT; t0 += RT) {
+        __syncthreads();
 #pragma unroll
-    for (int t = 0; t < BT; ++t)
+        for (int t = 0; t < BT; ++t)
+            if (t >= t0 && t < t0 + RT) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dst[t * 256 + (kq * 4 + r) * 16 + i] = acc[t][r];
+                for (int r = 0; r < 4; ++r) sA[(wave * RT + (t - t0)) * 256 + (kq * 4 + r) * 16 + i] = acc[t][r];
+            }
+        __syncthreads();
+        const int nt = (BT - t0) < RT ? (BT - t0) : RT;
+        for (int e = tid; e < nt * 256; e += 256)
+            dst[t0 * 256 + e] = (sA[e] + sA[RT * 256 + e]) + (sA[2 * RT * 256 + e] + sA[3 * RT * 256 + e]);
+    }
 }
 
-// dW[co][ci][t] = sum over slabs.  One thread per (t, ci, co), co fastest.
+// dW[co][ci][t] = sum over the gx slabs of its (kd-group, ci-tile, co-tile).  A block owns 64 consecutive
+// slab elements (coalesced 256-B reads); 4 thread groups stride over the slabs, combined in a fixed order.
 template <int KS, int KDS>
-__global__ void conv3d_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Co, int Ci,
-                                           const int32_t* __restrict__ imap, int n_ci_t, int n_pairs, int gx) {
+__global__ __launch_bounds__(256) void conv3d_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
+                                                                  int Co, int Ci, const int32_t* __restrict__ pmap,
+                                                                  int n_ci_t, int gx) {
     constexpr int TAPS = KS * KS * KS, BT = KDS * KS * KS;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= Co * Ci * TAPS) return;
-    const int co = idx % Co, ci = (idx / Co) % Ci, t = idx / (Co * Ci);
-    const int cip = imap ? imap[ci] : ci;
-    const int cit = cip >> 4, i = cip & 15, cot = co >> 4, j = co & 15;
-    const int z = t / BT, tl = t % BT;
-    const int pair = cot * n_ci_t + cit;
-    const float* src = ws + ((size_t)(z * n_pairs + pair) * gx * 4) * (BT * 256) + tl * 256 + i * 16 + j;
+    __shared__ float red[4][64];
+    const int e = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int el = blockIdx.x * 64 + e;                 // element inside the [BT][16][16] slab
+    const int pz = blockIdx.y;                          // (z * n_pairs + pair)
     float s = 0.f;
-    const int ns = gx * 4;
-    for (int k = 0; k < ns; ++k) s += src[(size_t)k * (BT * 256)];
-    dw[((size_t)co * Ci + ci) * TAPS + t] = s;
+    if (el < BT * 256) {
+        const float* src = ws + (size_t)pz * gx * (BT * 256) + el;
+        for (int k = part; k < gx; k += 4) s += src[(size_t)k * (BT * 256)];
+    }
+    red[part][e] = s;
+    __syncthreads();
+    if (part == 0 && el < BT * 256) {
+        const float tot = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+        const int n_pairs = gridDim.y / (TAPS / BT);
+        const int z = pz / n_pairs, pair = pz % n_pairs;
+        const int cit = pair % n_ci_t, cot = pair / n_ci_t;
+        const int tl = el >> 8, i = (el >> 4) & 15, j = el & 15;
+        const int cip = cit * 16 + i, co = cot * 16 + j;
+        const int ci = pmap[cip];                      // padded position -> logical channel (or -1)
+        if (ci >= 0 && co < Co) dw[((size_t)co * Ci + ci) * TAPS + z * BT + tl] = tot;
+    }
+}
+
+// inverse of imap: padded input-channel position -> logical channel, -1 for padding
+__global__ void invert_imap_kernel(const int32_t* __restrict__ imap, int Ci, int cin_p16, int32_t* __restrict__ pmap) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= cin_p16) return;
+    int v = -1;
+    if (imap) {
+        for (int c = 0; c < Ci; ++c) if (imap[c] == p) v = c;
+    } else if (p < Ci) {
+        v = p;
+    }
+    pmap[p] = v;
 }
 
 inline int wgrad_gx(int ntiles, int pairs_z) {
-    int gx = 768 / pairs_z;
+    int gx = 512 / pairs_z;
     if (gx < 1) gx = 1;
     if (gx > ntiles) gx = ntiles;
     return gx;
@@ -376,15 +426,12 @@ inline int wgrad_gx(int ntiles, int pairs_z) {
 // =================================================================== C ABI
 extern "C" size_t ctu_conv3d_packed_floats(int k, int rin_p, int nout_p) {
     if ((k != 3 && k != 5) || rin_p <= 0 || nout_p <= 0) return 0;
-    const int NT = pick_nt(nout_p);
-    const int ny = ceil_div(nout_p, 16 * NT);
-    return (size_t)ny * (rin_p / 8) * k * k * k * NT * 128;
+    return (size_t)(rin_p / 8) * k * k * k * ceil_div(nout_p, 16) * 128;
 }
 
 extern "C" int ctu_conv3d_num_blocks(int N, int D, int H, int W) {
-    int td, th, tw;
-    pick_tile(W, &td, &th, &tw);
-    return N * ceil_div(D, td) * ceil_div(H, th) * ceil_div(W, tw);
+    // upper bound over every tile choice of pick_launch (rows beyond the launched grid stay zero)
+    return N * ceil_div(D, 4) * ceil_div(H, 4) * ceil_div(W, 4);
 }
 
 extern "C" int ctu_pack_conv3d_weight(const float* w, float* wp, int Co, int Ci, int k, const int32_t* imap,
@@ -398,20 +445,19 @@ extern "C" int ctu_pack_conv3d_weight(const float* w, float* wp, int Co, int Ci,
         ctu_set_error("pack_conv3d_weight: memset failed");
         return CTU_ELAUNCH;
     }
-    const int NT = pick_nt(nout_p);
+    const int n16 = ceil_div(nout_p, 16);
     const int total = Co * Ci * k * k * k;
     const int nb = ceil_div(total, 256);
-    if (k == 3) pack_conv_w_kernel<3><<<nb, 256, 0, st>>>(w, wp, Co, Ci, imap, rin_p, NT, mode);
-    else pack_conv_w_kernel<5><<<nb, 256, 0, st>>>(w, wp, Co, Ci, imap, rin_p, NT, mode);
+    if (k == 3) pack_conv_w_kernel<3><<<nb, 256, 0, st>>>(w, wp, Co, Ci, imap, n16, mode);
+    else pack_conv_w_kernel<5><<<nb, 256, 0, st>>>(w, wp, Co, Ci, imap, n16, mode);
     CTU_CHECK_LAUNCH("pack_conv3d_weight");
     return CTU_OK;
 }
 
 template <int KS, int NT>
-static int launch_fwd(const ConvP& p0, hipStream_t st) {
+static int launch_fwd(const ConvP& p0, int td, int th, int tw, hipStream_t st) {
     ConvP p = p0;
-    int td, th, tw;
-    pick_tile(p.W, &td, &th, &tw);
+    p.n16 = ceil_div(p.nout_p, 16);
     p.tiles_d = ceil_div(p.D, td); p.tiles_h = ceil_div(p.H, th); p.tiles_w = ceil_div(p.W, tw);
     dim3 grid(p.N * p.tiles_d * p.tiles_h * p.tiles_w, ceil_div(p.nout_p, 16 * NT));
     if (tw == 16) conv3d_fwd_kernel<KS, NT, 4, 4, 16><<<grid, 256, 0, st>>>(p);
@@ -437,15 +483,27 @@ extern "C" int ctu_conv3d_fwd(const float* in, int in_cs, int rin_p, const float
     p.in_cs = in_cs; p.rin_p = rin_p; p.in_relu = in_relu; p.out_cs = out_cs; p.nout_p = nout_p;
     p.N = N; p.D = D; p.H = H; p.W = W;
     hipStream_t st = (hipStream_t)stream;
-    const int NT = pick_nt(nout_p);
-    if (k == 3) {
-        if (NT == 1) return launch_fwd<3, 1>(p, st);
-        if (NT == 2) return launch_fwd<3, 2>(p, st);
-        return launch_fwd<3, 4>(p, st);
+    int NT, td, th, tw;
+    pick_launch(N, D, H, W, nout_p, &NT, &td, &th, &tw);
+    if (stats) {
+        // rows of the partials buffer that this launch's (smaller) grid does not write must read as zero
+        const int rows = ctu_conv3d_num_blocks(N, D, H, W);
+        const int used = N * ceil_div(D, td) * ceil_div(H, th) * ceil_div(W, tw);
+        if (used < rows &&
+            hipMemsetAsync(stats + (size_t)used * 2 * nout_p, 0, (size_t)(rows - used) * 2 * nout_p * sizeof(float), st) !=
+                hipSuccess) {
+            ctu_set_error("conv3d_fwd: memset failed");
+            return CTU_ELAUNCH;
+        }
     }
-    if (NT == 1) return launch_fwd<5, 1>(p, st);
-    if (NT == 2) return launch_fwd<5, 2>(p, st);
-    return launch_fwd<5, 4>(p, st);
+    if (k == 3) {
+        if (NT == 1) return launch_fwd<3, 1>(p, td, th, tw, st);
+        if (NT == 2) return launch_fwd<3, 2>(p, td, th, tw, st);
+        return launch_fwd<3, 4>(p, td, th, tw, st);
+    }
+    if (NT == 1) return launch_fwd<5, 1>(p, td, th, tw, st);
+    if (NT == 2) return launch_fwd<5, 2>(p, td, th, tw, st);
+    return launch_fwd<5, 4>(p, td, th, tw, st);
 }
 
 static void wgrad_geom(int N, int D, int H, int W, int k, int cin_p, int cout_p, int* ntiles, int* n_ci_t,
@@ -466,7 +524,7 @@ extern "C" size_t ctu_conv3d_wgrad_ws_floats(int N, int D, int H, int W, int k, 
     if (k != 3 && k != 5) return 0;
     int ntiles, nci, nco, gz, gx, bt;
     wgrad_geom(N, D, H, W, k, cin_p, cout_p, &ntiles, &nci, &nco, &gz, &gx, &bt);
-    const size_t slabs = (size_t)gz * nci * nco * gx * 4 * bt * 256;
+    const size_t slabs = (size_t)gz * nci * nco * gx * bt * 256 + (size_t)nci * 16;   // + the inverse channel map
     const size_t bsum = (size_t)ctu_channel_sum_num_blocks((int64_t)N * D * H * W) * cout_p;
     return slabs > bsum ? slabs : bsum;
 }
@@ -481,9 +539,13 @@ static int launch_wgrad(WgP p, float* dw, int Co, int Ci, const int32_t* imap, i
     else if (tw == 8) conv3d_wgrad_kernel<KS, KDS, 4, 8, 8><<<grid, 256, 0, st>>>(p);
     else conv3d_wgrad_kernel<KS, KDS, 4, 4, 4><<<grid, 256, 0, st>>>(p);
     CTU_CHECK_LAUNCH("conv3d_wgrad");
-    const int total = Co * Ci * KS * KS * KS;
-    conv3d_wgrad_reduce_kernel<KS, KDS><<<ceil_div(total, 256), 256, 0, st>>>(p.ws, dw, Co, Ci, imap, p.n_ci_t,
-                                                                            p.n_ci_t * p.n_co_t, gx);
+    constexpr int BT = KDS * KS * KS;
+    const int n_pairs = p.n_ci_t * p.n_co_t;
+    int32_t* pmap = reinterpret_cast<int32_t*>(p.ws + (size_t)gz * n_pairs * gx * BT * 256);
+    invert_imap_kernel<<<1, 256, 0, st>>>(imap, Ci, p.n_ci_t * 16, pmap);
+    CTU_CHECK_LAUNCH("invert_imap");
+    conv3d_wgrad_reduce_kernel<KS, KDS><<<dim3(ceil_div(BT * 256, 64), gz * n_pairs), 256, 0, st>>>(p.ws, dw, Co, Ci, pmap,
+                                                                                                 p.n_ci_t, gx);
     CTU_CHECK_LAUNCH("conv3d_wgrad_reduce");
     return CTU_OK;
 }
@@ -496,7 +558,7 @@ extern "C" int ctu_conv3d_wgrad(const float* in, int in_cs, int cin_p, const flo
     CTU_REQUIRE(in && gout && dw && ws, "conv3d_wgrad: null pointer");
     CTU_REQUIRE(cin_p % 8 == 0 && cout_p % 8 == 0 && cin_p > 0 && cout_p > 0, "conv3d_wgrad: padded channels");
     CTU_REQUIRE(in_cs >= cin_p && in_cs % 4 == 0 && g_cs >= cout_p && g_cs % 4 == 0, "conv3d_wgrad: bad stride");
-    CTU_REQUIRE(Co <= cout_p && Co > 0 && Ci > 0, "conv3d_wgrad: Co/Ci");
+    CTU_REQUIRE(Co <= cout_p && Co > 0 && Ci > 0 && cin_p <= 256, "conv3d_wgrad: Co/Ci");
     CTU_REQUIRE(((uintptr_t)in & 15) == 0 && ((uintptr_t)gout & 15) == 0, "conv3d_wgrad: 16-byte alignment");
     hipStream_t st = (hipStream_t)stream;
     WgP p;

@@ -327,13 +327,20 @@ __global__ void channel_sum_partial_kernel(const float* __restrict__ x, int cs, 
     }
 }
 
+// one block per channel, fixed-order tree -> deterministic
 __global__ void channel_sum_final_kernel(const float* __restrict__ partials, int nb, int cp, float* __restrict__ out,
                                          int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    const int c = blockIdx.x;
+    __shared__ double r[EW_BLOCK];
     double s = 0.0;
-    for (int b = 0; b < nb; ++b) s += (double)partials[(size_t)b * cp + c];
-    out[c] = (float)s;
+    for (int b = threadIdx.x; b < nb; b += blockDim.x) s += (double)partials[(size_t)b * cp + c];
+    r[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = EW_BLOCK / 2; o > 0; o >>= 1) {
+        if (threadIdx.x < o) r[threadIdx.x] += r[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[c] = (float)r[0];
 }
 
 // ------------------------------------------------------------------ Adam(amsgrad)
@@ -485,7 +492,7 @@ extern "C" int ctu_channel_sum(const float* x, int cs, int cp, int64_t nvox, flo
     const int nb = ctu_channel_sum_num_blocks(nvox);
     channel_sum_partial_kernel<<<nb, EW_BLOCK, 0, (hipStream_t)stream>>>(x, cs, cp, nvox, partials);
     CTU_CHECK_LAUNCH("channel_sum_partial");
-    channel_sum_final_kernel<<<ceil_div(C, 64), 64, 0, (hipStream_t)stream>>>(partials, nb, cp, out, C);
+    channel_sum_final_kernel<<<C, EW_BLOCK, 0, (hipStream_t)stream>>>(partials, nb, cp, out, C);
     CTU_CHECK_LAUNCH("channel_sum_final");
     return CTU_OK;
 }

@@ -203,23 +203,32 @@ __global__ __launch_bounds__(HB) void head_bwd_kernel(HeadP p, const float* __re
     }
 }
 
+// one block per output (dW element or db element); fixed-order tree over the block partials
 template <int CP>
-__global__ void head_bwd_final_kernel(const float* __restrict__ partials, int nb, int Ci, int Co,
-                                      const int32_t* __restrict__ imap, float* __restrict__ dw,
-                                      float* __restrict__ db) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(HB) void head_bwd_final_kernel(const float* __restrict__ partials, int nb, int Ci, int Co,
+                                                            const int32_t* __restrict__ imap, float* __restrict__ dw,
+                                                            float* __restrict__ db) {
+    const int i = blockIdx.x;
     const int row = MAXCO * CP + MAXCO;
+    int col;
     if (i < Co * Ci) {
         const int co = i / Ci, ci = i % Ci;
-        const int col = co * CP + (imap ? imap[ci] : ci);
-        double s = 0.0;
-        for (int b = 0; b < nb; ++b) s += (double)partials[(size_t)b * row + col];
-        dw[i] = (float)s;
-    } else if (i < Co * Ci + Co) {
-        const int co = i - Co * Ci;
-        double s = 0.0;
-        for (int b = 0; b < nb; ++b) s += (double)partials[(size_t)b * row + MAXCO * CP + co];
-        db[co] = (float)s;
+        col = co * CP + (imap ? imap[ci] : ci);
+    } else {
+        col = MAXCO * CP + (i - Co * Ci);
+    }
+    __shared__ double r[HB];
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nb; b += HB) s += (double)partials[(size_t)b * row + col];
+    r[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = HB / 2; o > 0; o >>= 1) {
+        if (threadIdx.x < o) r[threadIdx.x] += r[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (i < Co * Ci) dw[i] = (float)r[0];
+        else db[i - Co * Ci] = (float)r[0];
     }
 }
 
@@ -375,16 +384,16 @@ extern "C" int ctu_head_bwd(const float* in, int in_cs, int cin_p, const float* 
     CTU_REQUIRE(gin_cs >= cin_p && gin_cs % 4 == 0, "head_bwd: bad gin stride");
     const int nb = head_blocks((int64_t)N * nvox_per_item);
     hipStream_t st = (hipStream_t)stream;
-    const int nfin = ceil_div(Co * Ci + Co, 64);
+    const int nfin = Co * Ci + Co;
     if (cin_p == 8) {
         head_bwd_kernel<8><<<nb, HB, 0, st>>>(p, g0, g1, gin, gin_cs, ws);
-        head_bwd_final_kernel<8><<<nfin, 64, 0, st>>>(ws, nb, Ci, Co, imap, dw, db);
+        head_bwd_final_kernel<8><<<nfin, HB, 0, st>>>(ws, nb, Ci, Co, imap, dw, db);
     } else if (cin_p == 16) {
         head_bwd_kernel<16><<<nb, HB, 0, st>>>(p, g0, g1, gin, gin_cs, ws);
-        head_bwd_final_kernel<16><<<nfin, 64, 0, st>>>(ws, nb, Ci, Co, imap, dw, db);
+        head_bwd_final_kernel<16><<<nfin, HB, 0, st>>>(ws, nb, Ci, Co, imap, dw, db);
     } else {
         head_bwd_kernel<32><<<nb, HB, 0, st>>>(p, g0, g1, gin, gin_cs, ws);
-        head_bwd_final_kernel<32><<<nfin, 64, 0, st>>>(ws, nb, Ci, Co, imap, dw, db);
+        head_bwd_final_kernel<32><<<nfin, HB, 0, st>>>(ws, nb, Ci, Co, imap, dw, db);
     }
     CTU_CHECK_LAUNCH("head_bwd");
     return CTU_OK;

@@ -185,7 +185,7 @@ def conv3d_fwd(x: CL, wp: torch.Tensor, bias_p: Optional[torch.Tensor], out: CL,
     if t0 is not None:
         ci, co = algo_ch if algo_ch is not None else (x.cp, out.cp)
         vox = n * d * h * w
-        TIMER.end(f"conv3d_fwd_kernel<{k},{_nt(out.cp)},{_tile_tag(w)}>", 2.0 * ci * co * k ** 3 * vox,
+        TIMER.end(f"conv3d_fwd_kernel<k{k}>", 2.0 * ci * co * k ** 3 * vox,
                   4.0 * vox * (ci + co), t0)
 
 
@@ -203,7 +203,7 @@ def conv3d_wgrad(x: CL, g: CL, co: int, ci: int, k: int, imap: Optional[torch.Te
                                     _stream()), "conv3d_wgrad")
     if t0 is not None:
         vox = n * d * h * w
-        TIMER.end(f"conv3d_wgrad<{k},{_tile_tag(w)}>(+reduce)", 2.0 * ci * co * k ** 3 * vox, 4.0 * vox * (ci + co), t0)
+        TIMER.end(f"conv3d_wgrad<k{k}>(+reduce)", 2.0 * ci * co * k ** 3 * vox, 4.0 * vox * (ci + co), t0)
     return dw, db
 
 
