@@ -24,7 +24,7 @@ struct ConvP {
     const float* bias;
     float* out;
     float* stats;
-    int in_cs, rin_p, in_relu, out_cs, nout_p;
+    int in_cs, rin_p, in_relu, out_cs, nout_p, nbias;
     int N, D, H, W;
     int tiles_d, tiles_h, tiles_w;
     int n16;                 // number of 16-wide output-channel tiles in the packed weights
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void conv3d_fwd_kernel(ConvP p) {
     for (int nt = 0; nt < NT; ++nt) {
         const int co = (by * NT + nt) * 16 + m;
         const bool cok = co < p.nout_p;
-        const float bv = (cok && p.bias) ? p.bias[co] : 0.f;
+        const float bv = (p.bias && co < p.nbias) ? p.bias[co] : 0.f;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -227,18 +227,32 @@ __device__ __forceinline__ size_t wp_index(int rp, int np, int t, int n16) {
     return ((((size_t)c * NSTAGE + s) * STAPS + ts) * n16 + nt) * 128 + kq * 32 + n * 2 + j;
 }
 
+// One thread per PACKED element (gather): layout [chunk][stage][tap][n16 tile][kq][n][j].
+// cinv maps a padded input-channel position to its logical channel (-1 = padding, NULL = identity).
 template <int KS>
 __global__ void pack_conv_w_kernel(const float* __restrict__ w, float* __restrict__ wp, int Co, int Ci,
-                                   const int32_t* __restrict__ imap, int n16, int mode) {
-    constexpr int TAPS = Taps<KS>::TAPS;
+                                   const int32_t* __restrict__ cinv, int nchunk, int n16, int mode) {
+    constexpr int TAPS = Taps<KS>::TAPS, STAPS = Taps<KS>::STAPS, NSTAGE = Taps<KS>::NSTAGE;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= Co * Ci * TAPS) return;
-    const int t = idx % TAPS, ci = (idx / TAPS) % Ci, co = idx / (TAPS * Ci);
-    const int cip = imap ? imap[ci] : ci;
-    int rp, np, tt;
-    if (mode == 0) { rp = cip; np = co; tt = t; }
-    else { rp = co; np = cip; tt = TAPS - 1 - t; }
-    wp[wp_index<KS>(rp, np, tt, n16)] = w[idx];
+    if (idx >= nchunk * TAPS * n16 * 128) return;
+    int r = idx;
+    const int j = r & 1; r >>= 1;
+    const int n = r & 15; r >>= 4;
+    const int kq = r & 3; r >>= 2;
+    const int nt = r % n16; r /= n16;
+    const int ts = r % STAPS; r /= STAPS;
+    const int s = r % NSTAGE; r /= NSTAGE;
+    const int c = r;
+    const int rp = c * 8 + kq * 2 + j, np = nt * 16 + n, t = s * STAPS + ts;
+    float v = 0.f;
+    if (mode == 0) {
+        const int ci = cinv ? cinv[rp] : (rp < Ci ? rp : -1);
+        if (ci >= 0 && np < Co) v = w[((size_t)np * Ci + ci) * TAPS + t];
+    } else {
+        const int ci = cinv ? cinv[np] : (np < Ci ? np : -1);
+        if (ci >= 0 && rp < Co) v = w[((size_t)rp * Ci + ci) * TAPS + (TAPS - 1 - t)];
+    }
+    wp[idx] = v;
 }
 
 // Launch shape: output-channel tiles per block (NT) and spatial tile.  Big volumes take the widest tile
@@ -376,7 +390,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(WgP p) {
 template <int KS, int KDS>
 __global__ __launch_bounds__(256) void conv3d_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
                                                                   int Co, int Ci, const int32_t* __restrict__ pmap,
-                                                                  int n_ci_t, int gx) {
+                                                                  int cin_p, int n_ci_t, int gx) {
     constexpr int TAPS = KS * KS * KS, BT = KDS * KS * KS;
     __shared__ float red[4][64];
     const int e = threadIdx.x & 63, part = threadIdx.x >> 6;
@@ -396,22 +410,10 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_reduce_kernel(const float* _
         const int cit = pair % n_ci_t, cot = pair / n_ci_t;
         const int tl = el >> 8, i = (el >> 4) & 15, j = el & 15;
         const int cip = cit * 16 + i, co = cot * 16 + j;
-        const int ci = pmap[cip];                      // padded position -> logical channel (or -1)
+        // padded position -> logical channel (or -1)
+        const int ci = (cip < cin_p) ? (pmap ? pmap[cip] : (cip < Ci ? cip : -1)) : -1;
         if (ci >= 0 && co < Co) dw[((size_t)co * Ci + ci) * TAPS + z * BT + tl] = tot;
     }
-}
-
-// inverse of imap: padded input-channel position -> logical channel, -1 for padding
-__global__ void invert_imap_kernel(const int32_t* __restrict__ imap, int Ci, int cin_p16, int32_t* __restrict__ pmap) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= cin_p16) return;
-    int v = -1;
-    if (imap) {
-        for (int c = 0; c < Ci; ++c) if (imap[c] == p) v = c;
-    } else if (p < Ci) {
-        v = p;
-    }
-    pmap[p] = v;
 }
 
 inline int wgrad_gx(int ntiles, int pairs_z) {
@@ -429,27 +431,23 @@ extern "C" size_t ctu_conv3d_packed_floats(int k, int rin_p, int nout_p) {
     return (size_t)(rin_p / 8) * k * k * k * ceil_div(nout_p, 16) * 128;
 }
 
-extern "C" int ctu_conv3d_num_blocks(int N, int D, int H, int W) {
-    // upper bound over every tile choice of pick_launch (rows beyond the launched grid stay zero)
-    return N * ceil_div(D, 4) * ceil_div(H, 4) * ceil_div(W, 4);
+extern "C" int ctu_conv3d_num_blocks(int N, int D, int H, int W, int nout_p) {
+    int nt, td, th, tw;
+    pick_launch(N, D, H, W, nout_p, &nt, &td, &th, &tw);
+    return N * ceil_div(D, td) * ceil_div(H, th) * ceil_div(W, tw);
 }
 
-extern "C" int ctu_pack_conv3d_weight(const float* w, float* wp, int Co, int Ci, int k, const int32_t* imap,
+extern "C" int ctu_pack_conv3d_weight(const float* w, float* wp, int Co, int Ci, int k, const int32_t* cinv,
                                       int rin_p, int nout_p, int mode, void* stream) {
     CTU_REQUIRE(k == 3 || k == 5, "pack_conv3d_weight: k=%d unsupported (3 or 5)", k);
     CTU_REQUIRE(rin_p % 8 == 0 && nout_p % 8 == 0, "pack_conv3d_weight: padded channels must be multiples of 8");
     CTU_REQUIRE(w && wp && Co > 0 && Ci > 0, "pack_conv3d_weight: null/empty argument");
     hipStream_t st = (hipStream_t)stream;
-    const size_t nfl = ctu_conv3d_packed_floats(k, rin_p, nout_p);
-    if (hipMemsetAsync(wp, 0, nfl * sizeof(float), st) != hipSuccess) {
-        ctu_set_error("pack_conv3d_weight: memset failed");
-        return CTU_ELAUNCH;
-    }
     const int n16 = ceil_div(nout_p, 16);
-    const int total = Co * Ci * k * k * k;
+    const int total = (int)ctu_conv3d_packed_floats(k, rin_p, nout_p);
     const int nb = ceil_div(total, 256);
-    if (k == 3) pack_conv_w_kernel<3><<<nb, 256, 0, st>>>(w, wp, Co, Ci, imap, n16, mode);
-    else pack_conv_w_kernel<5><<<nb, 256, 0, st>>>(w, wp, Co, Ci, imap, n16, mode);
+    if (k == 3) pack_conv_w_kernel<3><<<nb, 256, 0, st>>>(w, wp, Co, Ci, cinv, rin_p / 8, n16, mode);
+    else pack_conv_w_kernel<5><<<nb, 256, 0, st>>>(w, wp, Co, Ci, cinv, rin_p / 8, n16, mode);
     CTU_CHECK_LAUNCH("pack_conv3d_weight");
     return CTU_OK;
 }
@@ -468,8 +466,8 @@ static int launch_fwd(const ConvP& p0, int td, int th, int tw, hipStream_t st) {
 }
 
 extern "C" int ctu_conv3d_fwd(const float* in, int in_cs, int rin_p, const float* in_scale, const float* in_shift,
-                              int in_relu, const float* wp, const float* bias, float* out, int out_cs, int nout_p,
-                              float* stats, int N, int D, int H, int W, int k, void* stream) {
+                              int in_relu, const float* wp, const float* bias, int nbias, float* out, int out_cs,
+                              int nout_p, float* stats, int N, int D, int H, int W, int k, void* stream) {
     CTU_REQUIRE(k == 3 || k == 5, "conv3d_fwd: k=%d unsupported (3 or 5)", k);
     CTU_REQUIRE(in && wp && out, "conv3d_fwd: null pointer");
     CTU_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0, "conv3d_fwd: empty volume %dx%dx%dx%d", N, D, H, W);
@@ -481,21 +479,11 @@ extern "C" int ctu_conv3d_fwd(const float* in, int in_cs, int rin_p, const float
     ConvP p;
     p.in = in; p.in_scale = in_scale; p.in_shift = in_shift; p.wp = wp; p.bias = bias; p.out = out; p.stats = stats;
     p.in_cs = in_cs; p.rin_p = rin_p; p.in_relu = in_relu; p.out_cs = out_cs; p.nout_p = nout_p;
+    p.nbias = bias ? nbias : 0;
     p.N = N; p.D = D; p.H = H; p.W = W;
     hipStream_t st = (hipStream_t)stream;
     int NT, td, th, tw;
     pick_launch(N, D, H, W, nout_p, &NT, &td, &th, &tw);
-    if (stats) {
-        // rows of the partials buffer that this launch's (smaller) grid does not write must read as zero
-        const int rows = ctu_conv3d_num_blocks(N, D, H, W);
-        const int used = N * ceil_div(D, td) * ceil_div(H, th) * ceil_div(W, tw);
-        if (used < rows &&
-            hipMemsetAsync(stats + (size_t)used * 2 * nout_p, 0, (size_t)(rows - used) * 2 * nout_p * sizeof(float), st) !=
-                hipSuccess) {
-            ctu_set_error("conv3d_fwd: memset failed");
-            return CTU_ELAUNCH;
-        }
-    }
     if (k == 3) {
         if (NT == 1) return launch_fwd<3, 1>(p, td, th, tw, st);
         if (NT == 2) return launch_fwd<3, 2>(p, td, th, tw, st);
@@ -524,13 +512,13 @@ extern "C" size_t ctu_conv3d_wgrad_ws_floats(int N, int D, int H, int W, int k, 
     if (k != 3 && k != 5) return 0;
     int ntiles, nci, nco, gz, gx, bt;
     wgrad_geom(N, D, H, W, k, cin_p, cout_p, &ntiles, &nci, &nco, &gz, &gx, &bt);
-    const size_t slabs = (size_t)gz * nci * nco * gx * bt * 256 + (size_t)nci * 16;   // + the inverse channel map
+    const size_t slabs = (size_t)gz * nci * nco * gx * bt * 256;
     const size_t bsum = (size_t)ctu_channel_sum_num_blocks((int64_t)N * D * H * W) * cout_p;
     return slabs > bsum ? slabs : bsum;
 }
 
 template <int KS, int KDS>
-static int launch_wgrad(WgP p, float* dw, int Co, int Ci, const int32_t* imap, int gz, int gx, hipStream_t st) {
+static int launch_wgrad(WgP p, float* dw, int Co, int Ci, const int32_t* cinv, int gz, int gx, hipStream_t st) {
     int td, th, tw;
     pick_tile(p.W, &td, &th, &tw);
     p.tiles_d = ceil_div(p.D, td); p.tiles_h = ceil_div(p.H, th); p.tiles_w = ceil_div(p.W, tw);
@@ -541,18 +529,15 @@ static int launch_wgrad(WgP p, float* dw, int Co, int Ci, const int32_t* imap, i
     CTU_CHECK_LAUNCH("conv3d_wgrad");
     constexpr int BT = KDS * KS * KS;
     const int n_pairs = p.n_ci_t * p.n_co_t;
-    int32_t* pmap = reinterpret_cast<int32_t*>(p.ws + (size_t)gz * n_pairs * gx * BT * 256);
-    invert_imap_kernel<<<1, 256, 0, st>>>(imap, Ci, p.n_ci_t * 16, pmap);
-    CTU_CHECK_LAUNCH("invert_imap");
-    conv3d_wgrad_reduce_kernel<KS, KDS><<<dim3(ceil_div(BT * 256, 64), gz * n_pairs), 256, 0, st>>>(p.ws, dw, Co, Ci, pmap,
-                                                                                                 p.n_ci_t, gx);
+    conv3d_wgrad_reduce_kernel<KS, KDS><<<dim3(ceil_div(BT * 256, 64), gz * n_pairs), 256, 0, st>>>(
+        p.ws, dw, Co, Ci, cinv, p.cin_p, p.n_ci_t, gx);
     CTU_CHECK_LAUNCH("conv3d_wgrad_reduce");
     return CTU_OK;
 }
 
 extern "C" int ctu_conv3d_wgrad(const float* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
                                 int in_relu, const float* gout, int g_cs, int cout_p, float* dw, float* dbias, int Co,
-                                int Ci, const int32_t* imap, float* ws, int N, int D, int H, int W, int k,
+                                int Ci, const int32_t* cinv, float* ws, int N, int D, int H, int W, int k,
                                 void* stream) {
     CTU_REQUIRE(k == 3 || k == 5, "conv3d_wgrad: k=%d unsupported (3 or 5)", k);
     CTU_REQUIRE(in && gout && dw && ws, "conv3d_wgrad: null pointer");
@@ -567,8 +552,8 @@ extern "C" int ctu_conv3d_wgrad(const float* in, int in_cs, int cin_p, const flo
     p.N = N; p.D = D; p.H = H; p.W = W;
     int gz, gx, bt;
     wgrad_geom(N, D, H, W, k, cin_p, cout_p, &p.ntiles, &p.n_ci_t, &p.n_co_t, &gz, &gx, &bt);
-    int rc = (k == 3) ? launch_wgrad<3, 3>(p, dw, Co, Ci, imap, gz, gx, st)
-                      : launch_wgrad<5, 1>(p, dw, Co, Ci, imap, gz, gx, st);
+    int rc = (k == 3) ? launch_wgrad<3, 3>(p, dw, Co, Ci, cinv, gz, gx, st)
+                      : launch_wgrad<5, 1>(p, dw, Co, Ci, cinv, gz, gx, st);
     if (rc != CTU_OK) return rc;
     if (dbias) return ctu_channel_sum(gout, g_cs, cout_p, (int64_t)N * D * H * W, ws, dbias, Co, stream);
     return CTU_OK;

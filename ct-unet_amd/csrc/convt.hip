@@ -18,7 +18,7 @@ struct CtP {
     const float* wp;
     const float* bias;
     float* out;              // fwd: output on the 2x grid; bwd-data: gin [V][out_cs]
-    int in_cs, rin_p, in_relu, out_cs, nout_p;
+    int in_cs, rin_p, in_relu, out_cs, nout_p, nbias;
     int N, D, H, W;          // coarse (input-side) grid
     int64_t nvox;            // N*D*H*W
 };
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void convt2_kernel(CtP p) {
             for (int nt = 0; nt < NTT; ++nt) {
                 const int co = nt * 16 + m;
                 if (co < p.nout_p) {
-                    const float bv = p.bias ? p.bias[co] : 0.f;
+                    const float bv = (p.bias && co < p.nbias) ? p.bias[co] : 0.f;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int64_t v = v0 + wave * 16 + kq * 4 + r;
@@ -125,17 +125,30 @@ inline int pick_ntt(int nout_p) {
     return n16 <= 1 ? 1 : (n16 <= 2 ? 2 : (n16 <= 4 ? 4 : 8));
 }
 
-// wp[tap][g][nt][kq][n][j]
+// wp[tap][g][nt][kq][n][j]; one thread per packed element (gather, no memset needed).
+// cinv: padded input-channel position -> logical channel (-1 = padding, NULL = identity).
 __global__ void pack_convt_w_kernel(const float* __restrict__ w, float* __restrict__ wp, int Ci, int Co,
-                                    const int32_t* __restrict__ imap, int rin_p, int NTT, int mode) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= Ci * Co * 8) return;
-    const int tap = idx & 7, co = (idx >> 3) % Co, ci = idx / (8 * Co);
-    const int cip = imap ? imap[ci] : ci;
-    const int rp = (mode == 0) ? cip : co, np = (mode == 0) ? co : cip;
-    const int g = rp >> 3, kq = (rp & 7) >> 1, j = rp & 1, nt = np >> 4, n = np & 15;
+                                    const int32_t* __restrict__ cinv, int rin_p, int NTT, int mode) {
     const int ng = rin_p >> 3;
-    wp[((size_t)(tap * ng + g) * NTT + nt) * 128 + kq * 32 + n * 2 + j] = w[idx];
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 8 * ng * NTT * 128) return;
+    int r = idx;
+    const int j = r & 1; r >>= 1;
+    const int n = r & 15; r >>= 4;
+    const int kq = r & 3; r >>= 2;
+    const int nt = r % NTT; r /= NTT;
+    const int g = r % ng; r /= ng;
+    const int tap = r;
+    const int rp = g * 8 + kq * 2 + j, np = nt * 16 + n;
+    float v = 0.f;
+    if (mode == 0) {
+        const int ci = cinv ? cinv[rp] : (rp < Ci ? rp : -1);
+        if (ci >= 0 && np < Co) v = w[((size_t)ci * Co + np) * 8 + tap];
+    } else {
+        const int ci = cinv ? cinv[np] : (np < Ci ? np : -1);
+        if (ci >= 0 && rp < Co) v = w[((size_t)ci * Co + rp) * 8 + tap];
+    }
+    wp[idx] = v;
 }
 
 // ------------------------------------------------------------------ weight gradient
@@ -218,7 +231,7 @@ __global__ void convt2_wgrad_reduce_kernel(const float* __restrict__ ws, float* 
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= Ci * Co * 8) return;
     const int co = idx % Co, ci = (idx / Co) % Ci, tap = idx / (Co * Ci);
-    const int cip = imap ? imap[ci] : ci;
+    const int cip = imap ? imap[ci] : ci;      // logical -> padded position
     const int pair = (co >> 4) * n_ci_t + (cip >> 4);
     const float* src = ws + ((size_t)pair * gx * 4) * (8 * 256) + tap * 256 + (cip & 15) * 16 + (co & 15);
     float s = 0.f;
@@ -265,24 +278,21 @@ extern "C" size_t ctu_convt_packed_floats(int rin_p, int nout_p) {
     return (size_t)8 * (rin_p / 8) * pick_ntt(nout_p) * 128;
 }
 
-extern "C" int ctu_pack_convt_weight(const float* w, float* wp, int Ci, int Co, const int32_t* imap, int rin_p,
+extern "C" int ctu_pack_convt_weight(const float* w, float* wp, int Ci, int Co, const int32_t* cinv, int rin_p,
                                      int nout_p, int mode, void* stream) {
     CTU_REQUIRE(w && wp && Ci > 0 && Co > 0, "pack_convt_weight: null/empty");
     CTU_REQUIRE(rin_p % 8 == 0 && nout_p % 8 == 0 && nout_p <= 128, "pack_convt_weight: rin_p=%d nout_p=%d", rin_p,
                 nout_p);
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(wp, 0, ctu_convt_packed_floats(rin_p, nout_p) * sizeof(float), st) != hipSuccess) {
-        ctu_set_error("pack_convt_weight: memset failed");
-        return CTU_ELAUNCH;
-    }
-    pack_convt_w_kernel<<<ceil_div(Ci * Co * 8, 256), 256, 0, st>>>(w, wp, Ci, Co, imap, rin_p, pick_ntt(nout_p), mode);
+    const int total = (int)ctu_convt_packed_floats(rin_p, nout_p);
+    pack_convt_w_kernel<<<ceil_div(total, 256), 256, 0, st>>>(w, wp, Ci, Co, cinv, rin_p, pick_ntt(nout_p), mode);
     CTU_CHECK_LAUNCH("pack_convt_weight");
     return CTU_OK;
 }
 
 extern "C" int ctu_convt2_fwd(const float* in, int in_cs, int rin_p, const float* in_scale, const float* in_shift,
-                              int in_relu, const float* wp, const float* bias, float* out, int out_cs, int nout_p,
-                              int N, int D, int H, int W, void* stream) {
+                              int in_relu, const float* wp, const float* bias, int nbias, float* out, int out_cs,
+                              int nout_p, int N, int D, int H, int W, void* stream) {
     CTU_REQUIRE(in && wp && out, "convt2_fwd: null pointer");
     CTU_REQUIRE(rin_p > 0 && rin_p % 8 == 0 && nout_p > 0 && nout_p % 8 == 0 && nout_p <= 128,
                 "convt2_fwd: rin_p=%d nout_p=%d", rin_p, nout_p);
@@ -291,6 +301,7 @@ extern "C" int ctu_convt2_fwd(const float* in, int in_cs, int rin_p, const float
     CtP p;
     p.in = in; p.in_scale = in_scale; p.in_shift = in_shift; p.wp = wp; p.bias = bias; p.out = out;
     p.in_cs = in_cs; p.rin_p = rin_p; p.in_relu = in_relu; p.out_cs = out_cs; p.nout_p = nout_p;
+    p.nbias = bias ? nbias : 0;
     p.N = N; p.D = D; p.H = H; p.W = W; p.nvox = (int64_t)N * D * H * W;
     return launch_convt<0>(p, (hipStream_t)stream, "convt2_fwd");
 }
@@ -303,7 +314,7 @@ extern "C" int ctu_convt2_bwd_data(const float* gout, int g_cs, int rout_p, cons
     CTU_REQUIRE(g_cs >= rout_p && g_cs % 4 == 0 && gin_cs >= nin_p, "convt2_bwd_data: bad stride");
     CtP p;
     p.in = gout; p.in_scale = nullptr; p.in_shift = nullptr; p.wp = wp; p.bias = nullptr; p.out = gin;
-    p.in_cs = g_cs; p.rin_p = rout_p; p.in_relu = 0; p.out_cs = gin_cs; p.nout_p = nin_p;
+    p.in_cs = g_cs; p.rin_p = rout_p; p.in_relu = 0; p.out_cs = gin_cs; p.nout_p = nin_p; p.nbias = 0;
     p.N = N; p.D = D; p.H = H; p.W = W; p.nvox = (int64_t)N * D * H * W;
     return launch_convt<1>(p, (hipStream_t)stream, "convt2_bwd_data");
 }

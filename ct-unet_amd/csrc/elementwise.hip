@@ -21,6 +21,7 @@ extern "C" const char* ctu_arch(void) { return "gfx950"; }
 namespace {
 
 constexpr int EW_BLOCK = 256;
+constexpr int FIN_BLOCK = 1024;   // threads of the per-channel statistics finalisation
 constexpr int MAX_RED_BLOCKS = 1024;
 
 // ------------------------------------------------------------------ layout
@@ -61,17 +62,18 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stats, int nblocks,
                                    int n_updates, float* __restrict__ scale, float* __restrict__ shift,
                                    float* __restrict__ mean_out, float* __restrict__ invstd_out) {
     const int c = blockIdx.x;
-    __shared__ double r1[EW_BLOCK], r2[EW_BLOCK];
+    __shared__ double r1[FIN_BLOCK], r2[FIN_BLOCK];
     double s1 = 0.0, s2 = 0.0;
     if (c < C) {
-        for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
+#pragma unroll 4
+        for (int b = threadIdx.x; b < nblocks; b += FIN_BLOCK) {
             s1 += (double)stats[(size_t)b * 2 * cp + c];
             s2 += (double)stats[(size_t)b * 2 * cp + cp + c];
         }
     }
     r1[threadIdx.x] = s1; r2[threadIdx.x] = s2;
     __syncthreads();
-    for (int o = EW_BLOCK / 2; o > 0; o >>= 1) {
+    for (int o = FIN_BLOCK / 2; o > 0; o >>= 1) {
         if (threadIdx.x < o) { r1[threadIdx.x] += r1[threadIdx.x + o]; r2[threadIdx.x] += r2[threadIdx.x + o]; }
         __syncthreads();
     }
@@ -398,7 +400,7 @@ extern "C" int ctu_bn_finalize(const float* stats, int nblocks, int C, int cp, d
                                void* stream) {
     CTU_REQUIRE(stats && gamma && beta && scale && shift && mean_out && invstd_out, "bn_finalize: null pointer");
     CTU_REQUIRE(C > 0 && cp >= C && cp % 8 == 0 && nblocks > 0 && count > 0, "bn_finalize: bad sizes");
-    bn_finalize_kernel<<<cp, EW_BLOCK, 0, (hipStream_t)stream>>>(stats, nblocks, C, cp, count, gamma, beta,
+    bn_finalize_kernel<<<cp, FIN_BLOCK, 0, (hipStream_t)stream>>>(stats, nblocks, C, cp, count, gamma, beta,
                                                                 running_mean, running_var, momentum, eps, n_updates,
                                                                 scale, shift, mean_out, invstd_out);
     CTU_CHECK_LAUNCH("bn_finalize");

@@ -27,9 +27,9 @@ SIGNATURES = {
     "ctu_ncdhw_to_ndhwc": (I, [P, P, I, I, I, I, I, I, I, P]),
     "ctu_ndhwc_to_ncdhw": (I, [P, P, I, I, I, I, I, I, P]),
     "ctu_conv3d_packed_floats": (Z, [I, I, I]),
-    "ctu_conv3d_num_blocks": (I, [I, I, I, I]),
+    "ctu_conv3d_num_blocks": (I, [I, I, I, I, I]),
     "ctu_pack_conv3d_weight": (I, [P, P, I, I, I, P, I, I, I, P]),
-    "ctu_conv3d_fwd": (I, [P, I, I, P, P, I, P, P, P, I, I, P, I, I, I, I, I, P]),
+    "ctu_conv3d_fwd": (I, [P, I, I, P, P, I, P, P, I, P, I, I, P, I, I, I, I, I, P]),
     "ctu_conv3d_wgrad_ws_floats": (Z, [I, I, I, I, I, I, I]),
     "ctu_conv3d_wgrad": (I, [P, I, I, P, P, I, P, I, I, P, P, I, I, P, P, I, I, I, I, I, P]),
     "ctu_bn_finalize": (I, [P, I, I, I, D, P, P, P, P, F, F, I, P, P, P, P, P]),
@@ -42,7 +42,7 @@ SIGNATURES = {
     "ctu_maxpool2_bwd": (I, [P, I, I, P, P, I, P, I, P, I, I, I, I, I, I, P]),
     "ctu_convt_packed_floats": (Z, [I, I]),
     "ctu_pack_convt_weight": (I, [P, P, I, I, P, I, I, I, P]),
-    "ctu_convt2_fwd": (I, [P, I, I, P, P, I, P, P, P, I, I, I, I, I, I, P]),
+    "ctu_convt2_fwd": (I, [P, I, I, P, P, I, P, P, I, P, I, I, I, I, I, I, P]),
     "ctu_convt2_bwd_data": (I, [P, I, I, P, P, I, I, I, I, I, I, P]),
     "ctu_convt2_wgrad_ws_floats": (Z, [I, I, I, I, I, I]),
     "ctu_convt2_wgrad": (I, [P, I, I, P, P, I, P, I, I, P, P, I, I, P, P, I, I, I, I, P]),

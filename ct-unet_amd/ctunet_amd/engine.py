@@ -65,17 +65,21 @@ class UNetEngine:
         self._imaps: Dict[Tuple, torch.Tensor] = {}
 
     # ------------------------------------------------------------------ small helpers
-    def _imap(self, segs: Tuple[Tuple[int, int], ...], device) -> Optional[torch.Tensor]:
-        """segs: ((n_logical, padded_start), ...) -> int32 map logical channel -> padded position."""
+    def _maps(self, segs: Tuple[Tuple[int, int], ...], cp: int, device):
+        """segs: ((n_logical, padded_start), ...).  Returns (imap, cinv) int32 device tensors:
+        imap[logical] -> padded position, cinv[padded position] -> logical or -1; (None, None) = identity."""
         idx: List[int] = []
         for n, start in segs:
             idx += list(range(start, start + n))
         if idx == list(range(len(idx))):
-            return None
-        key = (segs, str(device))
+            return None, None
+        key = (segs, cp, str(device))
         t = self._imaps.get(key)
         if t is None:
-            t = torch.tensor(idx, dtype=torch.int32, device=device)
+            inv = [-1] * cp
+            for logical, pos in enumerate(idx):
+                inv[pos] = logical
+            t = (torch.tensor(idx, dtype=torch.int32, device=device), torch.tensor(inv, dtype=torch.int32, device=device))
             self._imaps[key] = t
         return t
 
@@ -91,14 +95,6 @@ class UNetEngine:
         self._pack_cache[key] = (ver, wp)
         return wp
 
-    @staticmethod
-    def _pad_vec(v: torch.Tensor, cp: int) -> torch.Tensor:
-        if v.numel() == cp:
-            return v.detach()
-        out = torch.zeros(cp, dtype=torch.float32, device=v.device)
-        out[:v.numel()] = v.detach()
-        return out
-
     # ------------------------------------------------------------------ forward pieces
     def _conv_bn(self, P, x: CL, conv: str, bn: str, cin: int, cout: int, imap, out: CL, vec4: torch.Tensor,
                  training: bool, n_upd: int, save: bool) -> Tuple[CL, Optional[_ConvRec]]:
@@ -106,17 +102,17 @@ class UNetEngine:
         w = P[conv + ".weight"]
         wp = self._packed(conv, w, "conv", imap, x.cp, out.cp, 0)
         bias = P.get(conv + ".bias")
-        bias_p = self._pad_vec(bias, out.cp) if bias is not None else None
+        bias_p = None if bias is None else bias.detach()
         dims = x.dims
         c = cout
         if training:
-            nblk = ops.conv_num_blocks(dims)
+            nblk = ops.conv_num_blocks(dims, out.cp)
             stats = torch.empty((nblk, 2, out.cp), dtype=torch.float32, device=x.buf.device)
             ops.conv3d_fwd(x, wp, bias_p, out, k, stats, (cin, cout))
             ops.bn_finalize_into(stats, nblk, c, out.cp, x.nvox, P[bn + ".weight"], P[bn + ".bias"],
                                  P[bn + ".running_mean"], P[bn + ".running_var"], BN_MOMENTUM, BN_EPS, n_upd, vec4)
             if n_upd:
-                P[bn + ".num_batches_tracked"].add_(n_upd)
+                self._nbt.append(P[bn + ".num_batches_tracked"])
         else:
             stats, nblk = None, 0
             ops.conv3d_fwd(x, wp, bias_p, out, k, None, (cin, cout))
@@ -145,6 +141,7 @@ class UNetEngine:
             raise ValueError("Expected more than 1 value per channel when training (centre block)")
         ctx = {"recs": {}, "levels": [], "training": training, "chk": chk} if save else None
         n_upd = 1 if training else 0
+        self._nbt: List[torch.Tensor] = []
 
         cur = ops.ncdhw_to_cl(x)
         x_cl = cur
@@ -160,7 +157,7 @@ class UNetEngine:
             xf.append(torch.zeros((4, 2 * cp), dtype=torch.float32, device=dev))
             t1 = CL(torch.empty((n, dd, hh, ww, cp), dtype=torch.float32, device=dev), 0, cp)
             v1 = torch.empty((4, cp), dtype=torch.float32, device=dev)
-            imap = self._imap(((blk.cin, 0),), dev)
+            imap = None
             a1, recs[(blk.prefix, 1)] = self._conv_bn(P, cur, f"{blk.prefix}.{blk.first}", f"{blk.prefix}.{blk.first + 1}",
                                                       blk.cin, blk.cout, imap, t1, v1, training, n_upd, save)
             a2, recs[(blk.prefix, 2)] = self._conv_bn(P, a1, f"{blk.prefix}.{blk.first + 3}", f"{blk.prefix}.{blk.first + 4}",
@@ -200,11 +197,11 @@ class UNetEngine:
             dd, hh, ww = dd * 2, hh * 2, ww * 2
             ct = blk.cin                                  # ConvTranspose3d(C, C)
             ctp = pad8(ct)
-            imap_t = self._imap(cur_segs, dev)
+            imap_t, cinv_t = self._maps(cur_segs, cur.cp, dev)
             wt = P[f"{blk.prefix}.0.weight"]
-            wpt = self._packed(f"{blk.prefix}.0", wt, "convt", imap_t, cur.cp, ctp, 0)
+            wpt = self._packed(f"{blk.prefix}.0", wt, "convt", cinv_t, cur.cp, ctp, 0)
             up = CL(torch.empty((n, dd, hh, ww, ctp), dtype=torch.float32, device=dev), 0, ctp)
-            ops.convt_fwd(cur, wpt, self._pad_vec(P[f"{blk.prefix}.0.bias"], ctp), up)
+            ops.convt_fwd(cur, wpt, P[f"{blk.prefix}.0.bias"].detach(), up)
             dec_in.append(cur)
             ups.append(up)
             t1 = CL(torch.empty((n, dd, hh, ww, cp), dtype=torch.float32, device=dev), 0, cp)
@@ -216,7 +213,9 @@ class UNetEngine:
             cur = CL(cat[i], 0, 2 * cp, xf[i][0], xf[i][1], True)
             cur_segs = ((blk.cout, 0), (blk.cout, cp))
         # ---- head
-        imap_h = self._imap(cur_segs, dev)
+        imap_h, _ = self._maps(cur_segs, cur.cp, dev)
+        if self._nbt:
+            torch._foreach_add_(self._nbt, 1)      # one launch for every num_batches_tracked counter
         wl, bl = P[plan.head + ".weight"], P[plan.head + ".bias"]
         w2 = wl.detach().reshape(wl.shape[0], wl.shape[1])
         out0, out1 = ops.head_fwd(cur, w2, bl.detach(), imap_h, plan.act, plan.head_mode)
@@ -274,6 +273,7 @@ class UNetEngine:
         # (models.py:232-255).  The dead centre block is never recomputed.
         if ctx["training"] and ctx["chk"]:
             scratch = {}
+            nbt = []
             for r in recs.values():
                 if r is None or r.stats is None:
                     continue
@@ -283,7 +283,9 @@ class UNetEngine:
                     sv = scratch[cp] = torch.empty((4, cp), dtype=torch.float32, device=dev)
                 ops.bn_finalize_into(r.stats, r.nblk, r.cout, cp, r.y.nvox, P[r.bn + ".weight"], P[r.bn + ".bias"],
                                      P[r.bn + ".running_mean"], P[r.bn + ".running_var"], BN_MOMENTUM, BN_EPS, 1, sv)
-                P[r.bn + ".num_batches_tracked"].add_(1)
+                nbt.append(P[r.bn + ".num_batches_tracked"])
+            if nbt:
+                torch._foreach_add_(nbt, 1)
 
         cat, head_in = ctx["cat"], ctx["head_in"]
         gcat = [torch.empty_like(c) for c in cat]
@@ -310,11 +312,11 @@ class UNetEngine:
             ct = blk.cin
             segs = ((plan.dec[j - 1].cout, 0), (plan.dec[j - 1].cout, pad8(plan.dec[j - 1].cout))) if j > 0 else \
                 ((ct, 0),)
-            imap_t = self._imap(segs, dev)
+            imap_t, cinv_t = self._maps(segs, x_in.cp, dev)
             wt = P[f"{blk.prefix}.0.weight"]
             dwt, dbt = ops.convt_wgrad(x_in, g_up, ct, ct, imap_t, ws)
             grads[f"{blk.prefix}.0.weight"], grads[f"{blk.prefix}.0.bias"] = dwt, dbt
-            wpd = self._packed(f"{blk.prefix}.0", wt, "convt", imap_t, g_up.cp, x_in.cp, 1)
+            wpd = self._packed(f"{blk.prefix}.0", wt, "convt", cinv_t, g_up.cp, x_in.cp, 1)
             if j > 0:
                 gin = CL(gcat[i + 1], 0, gcat[i + 1].shape[-1])
             else:

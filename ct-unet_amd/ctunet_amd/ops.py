@@ -156,23 +156,24 @@ def cl_to_ncdhw(a: CL, c: int) -> torch.Tensor:
 
 
 # ---------------------------------------------------------------------------- conv3d
-def pack_conv_w(w: torch.Tensor, imap: Optional[torch.Tensor], rin_p: int, nout_p: int, mode: int) -> torch.Tensor:
+def pack_conv_w(w: torch.Tensor, cinv: Optional[torch.Tensor], rin_p: int, nout_p: int, mode: int) -> torch.Tensor:
+    """cinv: int32 map padded input-channel position -> logical channel (-1 = padding), None = identity."""
     _need_cuda(w, "conv weight")
     co, ci, k = w.shape[0], w.shape[1], w.shape[2]
     lib = _lib.load()
     n = lib.ctu_conv3d_packed_floats(k, rin_p, nout_p)
     wp = torch.empty(n, dtype=torch.float32, device=w.device)
-    _lib.check(lib.ctu_pack_conv3d_weight(w.contiguous().data_ptr(), wp.data_ptr(), co, ci, k, _ptr(imap), rin_p,
+    _lib.check(lib.ctu_pack_conv3d_weight(w.contiguous().data_ptr(), wp.data_ptr(), co, ci, k, _ptr(cinv), rin_p,
                                           nout_p, mode, _stream()), "pack_conv3d_weight")
     return wp
 
 
-def conv_num_blocks(dims) -> int:
+def conv_num_blocks(dims, nout_p: int) -> int:
     n, d, h, w = dims
-    return _lib.load().ctu_conv3d_num_blocks(n, d, h, w)
+    return _lib.load().ctu_conv3d_num_blocks(n, d, h, w, nout_p)
 
 
-def conv3d_fwd(x: CL, wp: torch.Tensor, bias_p: Optional[torch.Tensor], out: CL, k: int,
+def conv3d_fwd(x: CL, wp: torch.Tensor, bias: Optional[torch.Tensor], out: CL, k: int,
                stats: Optional[torch.Tensor] = None, algo_ch: Optional[Tuple[int, int]] = None) -> None:
     """algo_ch = (logical Cin, logical Cout) -- only used to count algorithmic FLOPs when timing."""
     n, d, h, w = x.dims
@@ -180,8 +181,8 @@ def conv3d_fwd(x: CL, wp: torch.Tensor, bias_p: Optional[torch.Tensor], out: CL,
     lib = _lib.load()
     t0 = TIMER.begin() if TIMER is not None else None
     _lib.check(lib.ctu_conv3d_fwd(x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), wp.data_ptr(),
-                                  _ptr(bias_p), out.ptr, out.cs, out.cp, _ptr(stats), n, d, h, w, k, _stream()),
-               "conv3d_fwd")
+                                  _ptr(bias), 0 if bias is None else bias.numel(), out.ptr, out.cs, out.cp, _ptr(stats),
+                                  n, d, h, w, k, _stream()), "conv3d_fwd")
     if t0 is not None:
         ci, co = algo_ch if algo_ch is not None else (x.cp, out.cp)
         vox = n * d * h * w
@@ -189,7 +190,7 @@ def conv3d_fwd(x: CL, wp: torch.Tensor, bias_p: Optional[torch.Tensor], out: CL,
                   4.0 * vox * (ci + co), t0)
 
 
-def conv3d_wgrad(x: CL, g: CL, co: int, ci: int, k: int, imap: Optional[torch.Tensor], ws: torch.Tensor,
+def conv3d_wgrad(x: CL, g: CL, co: int, ci: int, k: int, cinv: Optional[torch.Tensor], ws: torch.Tensor,
                  want_bias: bool) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     n, d, h, w = x.dims
     lib = _lib.load()
@@ -199,7 +200,7 @@ def conv3d_wgrad(x: CL, g: CL, co: int, ci: int, k: int, imap: Optional[torch.Te
     db = torch.empty(co, dtype=torch.float32, device=x.buf.device) if want_bias else None
     t0 = TIMER.begin() if TIMER is not None else None
     _lib.check(lib.ctu_conv3d_wgrad(x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), g.ptr, g.cs, g.cp,
-                                    dw.data_ptr(), _ptr(db), co, ci, _ptr(imap), ws.data_ptr(), n, d, h, w, k,
+                                    dw.data_ptr(), _ptr(db), co, ci, _ptr(cinv), ws.data_ptr(), n, d, h, w, k,
                                     _stream()), "conv3d_wgrad")
     if t0 is not None:
         vox = n * d * h * w
@@ -279,21 +280,22 @@ def maxpool_bwd(x: CL, gout: CL, gin: CL, accumulate: bool) -> None:
 
 
 # ---------------------------------------------------------------------------- conv transpose
-def pack_convt_w(w: torch.Tensor, imap, rin_p: int, nout_p: int, mode: int) -> torch.Tensor:
+def pack_convt_w(w: torch.Tensor, cinv, rin_p: int, nout_p: int, mode: int) -> torch.Tensor:
     _need_cuda(w, "convT weight")
     ci, co = w.shape[0], w.shape[1]
     lib = _lib.load()
     wp = torch.empty(lib.ctu_convt_packed_floats(rin_p, nout_p), dtype=torch.float32, device=w.device)
-    _lib.check(lib.ctu_pack_convt_weight(w.contiguous().data_ptr(), wp.data_ptr(), ci, co, _ptr(imap), rin_p, nout_p,
+    _lib.check(lib.ctu_pack_convt_weight(w.contiguous().data_ptr(), wp.data_ptr(), ci, co, _ptr(cinv), rin_p, nout_p,
                                          mode, _stream()), "pack_convt_weight")
     return wp
 
 
-def convt_fwd(x: CL, wp: torch.Tensor, bias_p: Optional[torch.Tensor], out: CL) -> None:
+def convt_fwd(x: CL, wp: torch.Tensor, bias: Optional[torch.Tensor], out: CL) -> None:
     n, d, h, w = x.dims
     lib = _lib.load()
     _lib.check(lib.ctu_convt2_fwd(x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), wp.data_ptr(),
-                                  _ptr(bias_p), out.ptr, out.cs, out.cp, n, d, h, w, _stream()), "convt2_fwd")
+                                  _ptr(bias), 0 if bias is None else bias.numel(), out.ptr, out.cs, out.cp, n, d, h, w,
+                                  _stream()), "convt2_fwd")
 
 
 def convt_bwd_data(gout: CL, wp: torch.Tensor, gin: CL) -> None:

@@ -59,17 +59,20 @@ int ctu_ndhwc_to_ncdhw(const float* src, float* dst, int N, int C, int D, int H,
 /* Geometry helpers: packed-weight size (floats) and number of spatial blocks (= rows of
  * the stats-partials buffer) for a conv call. */
 size_t ctu_conv3d_packed_floats(int k, int rin_p, int nout_p);
-int ctu_conv3d_num_blocks(int N, int D, int H, int W);
+int ctu_conv3d_num_blocks(int N, int D, int H, int W, int nout_p);
 
 /* Re-layout a torch Conv3d weight [Co,Ci,k,k,k] for the implicit-GEMM kernels.
- *  mode 0 (forward): reduction channel = imap[ci], output channel = co.
- *  mode 1 (data gradient): reduction channel = co, output channel = imap[ci], taps flipped.
- * imap (int32[Ci], device, may be NULL = identity) maps a logical input channel to its
- * position in the padded channels-last buffer.  rin_p / nout_p: padded channel counts of
- * the reduction and output sides of THIS packing (multiples of 8).
+ *  mode 0 (forward): reduction side = padded input channels, output side = co.
+ *  mode 1 (data gradient): reduction side = co, output side = padded input channels, taps flipped.
+ * Channel maps (int32, device, NULL = identity) come in two directions throughout this header:
+ *   imap[logical channel]   -> position in the padded channels-last buffer
+ *   cinv[padded position]   -> logical channel, -1 for a padding slot
+ * (the concat buffers hold [C real | pad | C real | pad]).  rin_p / nout_p: padded channel
+ * counts of the reduction and output sides of THIS packing (multiples of 8).  Every element of
+ * wp is written (padding slots get 0), no prior memset needed.
  * nn.Conv3d weights: ctunet/pytorch/models.py:26,29,38,41,71,76,403,407,430,434,482-488. */
 int ctu_pack_conv3d_weight(const float* w, float* wp, int Co, int Ci, int k,
-                           const int32_t* imap, int rin_p, int nout_p, int mode, void* stream);
+                           const int32_t* cinv, int rin_p, int nout_p, int mode, void* stream);
 
 /* Implicit-GEMM 3D convolution on MFMA (v_mfma_f32_16x16x4_f32), stride 1, zero padding
  * (k-1)/2, NDHWC.  out[v, o] = bias[o] + sum_{tap,r} A(in[v+tap, r]) * wp[tap, r, o] with
@@ -77,18 +80,19 @@ int ctu_pack_conv3d_weight(const float* w, float* wp, int Co, int Ci, int k,
  * above) and, with a mode-1 packing, for its data gradient.
  *  in/in_cs/rin_p ...... input tensor, channel stride, channels to contract (mult. of 8)
  *  in_scale/in_shift ... per-channel transform of `in` (NULL = identity); in_relu 0/1
- *  bias ................ [nout_p] or NULL
+ *  bias/nbias .......... [nbias] (logical, unpadded) or NULL
  *  out/out_cs/nout_p ... output tensor (channel slice base), stride, channels written
  *  stats ............... NULL or [ctu_conv3d_num_blocks()][2][nout_p]: per-block sum and
  *                        sum of squares of the written output (train-mode BatchNorm3d,
  *                        models.py:27,31,39,43,74,79,405,409,432,436,485,490) */
 int ctu_conv3d_fwd(const float* in, int in_cs, int rin_p,
                    const float* in_scale, const float* in_shift, int in_relu,
-                   const float* wp, const float* bias,
+                   const float* wp, const float* bias, int nbias,
                    float* out, int out_cs, int nout_p, float* stats,
                    int N, int D, int H, int W, int k, void* stream);
 
-/* Weight gradient of nn.Conv3d: dW[co,ci,tap] = sum_v A(in[v+tap, imap[ci]]) * gout[v, co].
+/* Weight gradient of nn.Conv3d: dW[co,ci,tap] = sum_v A(in[v+tap, pos(ci)]) * gout[v, co],
+ * pos = inverse of cinv.
  * ws: workspace of ctu_conv3d_wgrad_ws_floats() floats (per-wave partial slabs, reduced
  * deterministically by a second kernel; no float atomics).  dw: torch layout [Co,Ci,k,k,k].
  * dbias: NULL or [Co] = sum_v gout[v,co]. */
@@ -96,7 +100,7 @@ size_t ctu_conv3d_wgrad_ws_floats(int N, int D, int H, int W, int k, int cin_p, 
 int ctu_conv3d_wgrad(const float* in, int in_cs, int cin_p,
                      const float* in_scale, const float* in_shift, int in_relu,
                      const float* gout, int g_cs, int cout_p,
-                     float* dw, float* dbias, int Co, int Ci, const int32_t* imap,
+                     float* dw, float* dbias, int Co, int Ci, const int32_t* cinv,
                      float* ws, int N, int D, int H, int W, int k, void* stream);
 
 /* ------------------------------------------------------------ BatchNorm3d ---- */
@@ -148,14 +152,14 @@ int ctu_maxpool2_bwd(const float* in, int in_cs, int cp, const float* in_scale,
 /* -------------------------------------------------- ConvTranspose3d k2 s2 ---- */
 /* nn.ConvTranspose3d(C, C, 2, 2) with bias (models.py:37,427-429):
  * out[2v+tap, o] = b[o] + sum_r A(in[v, r]) * w[r, o, tap];  w torch layout [Ci,Co,2,2,2].
- * Packing: mode 0 forward (reduction = imap[ci], output = co),
- *          mode 1 data gradient (reduction = co, output = imap[ci]). */
+ * Packing: mode 0 forward (reduction = padded input channels, output = co),
+ *          mode 1 data gradient (reduction = co, output = padded input channels); cinv as above. */
 size_t ctu_convt_packed_floats(int rin_p, int nout_p);
-int ctu_pack_convt_weight(const float* w, float* wp, int Ci, int Co, const int32_t* imap,
+int ctu_pack_convt_weight(const float* w, float* wp, int Ci, int Co, const int32_t* cinv,
                           int rin_p, int nout_p, int mode, void* stream);
 int ctu_convt2_fwd(const float* in, int in_cs, int rin_p, const float* in_scale,
                    const float* in_shift, int in_relu, const float* wp, const float* bias,
-                   float* out, int out_cs, int nout_p, int N, int D, int H, int W,
+                   int nbias, float* out, int out_cs, int nout_p, int N, int D, int H, int W,
                    void* stream);      /* D,H,W: INPUT grid; output grid is 2D,2H,2W */
 /* gin[v, r] = sum_{tap,o} gout[2v+tap, o] * w[r, o, tap]  (wp from mode 1). */
 int ctu_convt2_bwd_data(const float* gout, int g_cs, int rout_p, const float* wp,

@@ -77,14 +77,12 @@ def test_conv3d_fwd_and_stats(case):
         xc = xc.with_xf(sc.cuda(), sh.cuda(), True)
     ref = F.conv3d(xa, wt, b, 1, (k - 1) // 2)
     wp = ops.pack_conv_w(wt.cuda(), None, cip, cop, 0)
-    bp = None
-    if bias:
-        bp = torch.zeros(cop); bp[:co] = b; bp = bp.cuda()
+    bp = b.cuda() if bias else None          # logical, unpadded bias
     # write into a channel slice of a wider buffer to exercise strides
     obuf = torch.full((n, d, h, w, cop + 8), 7.0, device="cuda")
     out = ops.CL(obuf, 8, cop)
-    nb = ops.conv_num_blocks((n, d, h, w))
-    stats = torch.zeros(nb, 2, cop, device="cuda")
+    nb = ops.conv_num_blocks((n, d, h, w), cop)
+    stats = torch.full((nb, 2, cop), float("nan"), device="cuda")      # every row must be written
     ops.conv3d_fwd(xc, wp, bp, out, k, stats)
     torch.cuda.synchronize()
     got = from_cl(out, co)
@@ -141,19 +139,23 @@ def test_conv3d_imap_concat():
     buf = torch.zeros(n, d, h, w, 16)
     buf[..., 0:7] = xa.permute(0, 2, 3, 4, 1); buf[..., 8:15] = xb.permute(0, 2, 3, 4, 1)
     xc = ops.CL(buf.cuda(), 0, 16)
-    imap = torch.tensor(list(range(7)) + list(range(8, 15)), dtype=torch.int32).cuda()
-    wp = ops.pack_conv_w(wt.cuda(), imap, 16, 8, 0)
+    pos = list(range(7)) + list(range(8, 15))                    # logical channel -> padded position
+    inv = [-1] * 16
+    for logical, p_ in enumerate(pos):
+        inv[p_] = logical
+    cinv = torch.tensor(inv, dtype=torch.int32).cuda()           # padded position -> logical channel
+    wp = ops.pack_conv_w(wt.cuda(), cinv, 16, 8, 0)
     out = ops.CL(torch.empty(n, d, h, w, 8, device="cuda"), 0, 8)
     ops.conv3d_fwd(xc, wp, None, out, k, None)
     assert rel_err(from_cl(out, 5), ref) < 1e-4
     gy = torch.randn(n, 5, d, h, w, generator=g(4))
     ws = torch.empty(ops.conv3d_wgrad_ws((n, d, h, w), k, 16, 8), device="cuda")
-    dw, _ = ops.conv3d_wgrad(xc, to_cl(gy), 5, 14, k, imap, ws, False)
+    dw, _ = ops.conv3d_wgrad(xc, to_cl(gy), 5, 14, k, cinv, ws, False)
     xcat = torch.cat((xa, xb), 1).requires_grad_(True)
     wr = wt.clone().requires_grad_(True)
     F.conv3d(xcat, wr, None, 1, 1).backward(gy)
     assert rel_err(dw.cpu(), wr.grad) < 1e-4
-    wpd = ops.pack_conv_w(wt.cuda(), imap, 8, 16, 1)
+    wpd = ops.pack_conv_w(wt.cuda(), cinv, 8, 16, 1)
     gin = ops.CL(torch.empty(n, d, h, w, 16, device="cuda"), 0, 16)
     ops.conv3d_fwd(to_cl(gy), wpd, None, gin, k, None)
     got = gin.buf.cpu()
@@ -183,7 +185,7 @@ def test_batchnorm_train_fwd_bwd(shape):
     wt = torch.zeros(c, c, 3, 3, 3); wt[range(c), range(c), 1, 1, 1] = 1.0
     wp = ops.pack_conv_w(wt.cuda(), None, cp, cp, 0)
     out = ops.CL(torch.empty(n, d, h, w, cp, device="cuda"), 0, cp)
-    nb = ops.conv_num_blocks((n, d, h, w))
+    nb = ops.conv_num_blocks((n, d, h, w), cp)
     stats = torch.zeros(nb, 2, cp, device="cuda")
     ops.conv3d_fwd(yc, wp, None, out, 3, stats)
     rm_g, rv_g = rm.cuda(), rv.cuda()
@@ -276,7 +278,7 @@ def test_convtranspose(case):
     gy = torch.randn(ref.shape, generator=g(5))
     ref.backward(gy)
     wp = ops.pack_convt_w(wt.detach().cuda(), None, cip, cop, 0)
-    bp = torch.zeros(cop); bp[:co] = b.detach(); bp = bp.cuda()
+    bp = b.detach().cuda()
     out = ops.CL(torch.empty(n, 2 * d, 2 * h, 2 * w, cop, device="cuda"), 0, cop)
     ops.convt_fwd(xc, wp, bp, out)
     assert rel_err(from_cl(out, co), ref.detach()) < 1e-4
