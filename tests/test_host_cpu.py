@@ -1,0 +1,132 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/ctunet_hip.h declares
+(no compute calls -- there is no GPU here), the ctypes table mirrors the header, and the host logic
+of the drop-in classes (names, state_dict, init, error behaviour, ini parsing) matches the reference."""
+import ctypes
+import json
+import os
+import re
+
+import pytest
+import torch
+
+from util import GOLDEN, load_json
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "ctunet_hip.h")
+
+
+def _header_decls():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    decls = {}
+    for m in re.finditer(r"^\s*(?:const\s+char\*|int|size_t)\s+(ctu_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S | re.M):
+        args = m.group(2).strip()
+        n = 0 if args in ("void", "") else len([a for a in args.split(",") if a.strip()])
+        decls[m.group(1)] = n
+    return decls
+
+
+def test_library_exports_every_declared_symbol():
+    from ctunet_amd import _lib
+    decls = _header_decls()
+    assert len(decls) >= 30
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in decls:
+        assert hasattr(lib, name), f"{name} declared in ctunet_hip.h but not exported"
+    # the ctypes prototype table covers the header one to one, with matching arity
+    assert set(_lib.SIGNATURES) == set(decls)
+    for name, n in decls.items():
+        assert len(_lib.SIGNATURES[name][1]) == n, name
+    loaded = _lib.load()
+    assert loaded.ctu_arch() == b"gfx950"
+    assert loaded.ctu_abi_version() >= 1
+    # pure geometry helpers may be called without a GPU
+    assert loaded.ctu_conv3d_packed_floats(3, 8, 8) == 27 * 128
+    assert loaded.ctu_conv3d_packed_floats(7, 8, 8) == 0
+    assert loaded.ctu_conv3d_num_blocks(1, 128, 128, 128, 8) == 32 * 32 * 8
+
+
+def test_no_gpu_no_fallback():
+    """The product path refuses CPU tensors instead of silently computing elsewhere."""
+    import ctunet_amd
+    from ctunet_amd import losses, ops
+    net = ctunet_amd.UNet(n_blocks=2, i_size=2)
+    with pytest.raises(RuntimeError, match="MI355X"):
+        net(torch.zeros(1, 1, 8, 8, 8))
+    with pytest.raises(RuntimeError):
+        losses.dice_loss()(torch.zeros(1, 2, 4, 4, 4), torch.zeros(1, 2, 4, 4, 4))
+    with pytest.raises(RuntimeError):
+        ops.ncdhw_to_cl(torch.zeros(1, 1, 4, 4, 4))
+
+
+def test_product_code_never_imports_oracle():
+    pkg = os.path.join(ROOT, "ct-unet_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "oracle" not in txt.replace("the oracle", "").lower() or f == "__none__", (dp, f)
+
+
+@pytest.mark.parametrize("name", ["UNet", "UNet4b2i3o", "UNet5b2i3o", "UNet4b1i3o", "UNetSP", "UNetSPSmall", "UNetDO",
+                                  "recAE_v2_fixed", "UNet4_2IC"])
+def test_state_dict_and_seeded_init_match_reference(name):
+    import ctunet_amd
+    exp = load_json("class_checksums.json")[name]
+    torch.manual_seed(0)
+    net = getattr(ctunet_amd, name)()
+    sd = net.state_dict()
+    assert {k: list(v.shape) for k, v in sd.items()} == exp["keys_shapes"]
+    assert len(sd) == exp["n_keys"]
+    for n_, p in net.named_parameters():
+        assert abs(p.double().sum().item() - exp["param_sums"][n_]) < 1e-9, n_
+    # round trip incl. the DataParallel "module." prefix the reference's checkpoints may carry (Model.py:282,486)
+    from ctunet_amd.checkpoint import load_state
+    net2 = getattr(ctunet_amd, name)()
+    load_state(net2, {"module." + k: v for k, v in sd.items()})
+    for k, v in net2.state_dict().items():
+        assert torch.equal(v, sd[k])
+
+
+def test_unsupported_options_raise():
+    import ctunet_amd
+    for kw in (dict(residual=True), dict(fc_layer=[8, 4]), dict(cat=False), dict(use_skip_connections=False),
+               dict(dropout_p=0.5), dict(kern_sz_conv=7, padding=3), dict(out_channels=5)):
+        with pytest.raises(NotImplementedError):
+            ctunet_amd.UNet(**kw)
+
+
+def test_ini_parser_matches_reference():
+    from ctunet_amd.utilities import load_params, set_cfg_params
+    exp = load_json("ini_params.json")
+    ref_root = "/root/reference"
+    if not os.path.isdir(ref_root):
+        pytest.skip("reference tree not present (GPU box)")
+    for rel, params in exp.items():
+        got = set_cfg_params(os.path.join(ref_root, rel), {})
+        assert json.loads(json.dumps(got)) == params, rel
+        import ctunet_amd
+        from ctunet_amd import ProblemHandler
+        assert hasattr(ctunet_amd, got["model_class"])                 # s_model_class resolves to a drop-in
+        assert hasattr(ProblemHandler, got["problem_handler"])         # s_problem_handler resolves
+    with pytest.raises(FileNotFoundError):
+        set_cfg_params("/nonexistent.ini", {})
+    assert set_cfg_params(None) is None
+
+
+def test_ini_parser_type_prefixes(tmp_path):
+    from ctunet_amd.utilities import set_cfg_params
+    p = tmp_path / "x.ini"
+    p.write_text("[A]\ni_n = 3\nf_x = 0.5\nb_flag = True\ns_name = abc\nplain = 7\n[B]\ns_resume_model =\n")
+    got = set_cfg_params(str(p), {"keep": 1})
+    assert got == {"keep": 1, "n": 3, "x": 0.5, "flag": True, "name": "abc", "plain": "7", "resume_model": ""}
+
+
+def test_hard_segmentation_and_dice_metric():
+    from ctunet_amd.utilities import dice_coeff, hard_segm_from_tensor
+    p = torch.rand(2, 2, 4, 4, 4, generator=torch.Generator().manual_seed(0))
+    seg = hard_segm_from_tensor(p)
+    assert seg.shape == (2, 4, 4, 4) and seg.dtype == torch.float32
+    assert hard_segm_from_tensor(p, keep_dims=True).shape == (2, 1, 4, 4, 4)
+    t = torch.nn.functional.one_hot(p.argmax(1), 2).movedim(-1, 1).float()
+    assert abs(dice_coeff(p, t).item() - 1.0) < 1e-6

@@ -1,0 +1,74 @@
+"""N > 1 path on CPU: two gloo ranks, gradient bucketing/averaging of ctunet_amd.parallel.
+
+Checks the property the reference's DataParallel step defines: after the exchange every
+rank holds the mean over ranks of each live gradient, parameters the graph never touches (None)
+are skipped on every rank, and parameters/buffers start identical after ``distribute``."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _worker(rank, world, port, tmp):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "ct-unet_amd")]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ctunet_amd import parallel
+        import ctunet_amd
+        # 1. broadcast makes replicas identical
+        torch.manual_seed(100 + rank)
+        net = ctunet_amd.UNet(n_blocks=2, i_size=2)
+        parallel.distribute(net)
+        flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+        gathered = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        assert all(torch.equal(gathered[0], g) for g in gathered)
+        # 2. block-wise push in backward order with tiny buckets (forces several collectives) + unused params
+        names = [n for n, _ in net.named_parameters()]
+        g = torch.Generator().manual_seed(7 + rank)
+        grads = {n: (None if n.startswith("cblock.") else torch.randn(p.shape, generator=g))
+                 for n, p in net.named_parameters()}
+        sync = parallel.GradSync(None, bucket_bytes=256)
+        live = [(n, t.clone()) for n, t in grads.items() if t is not None]
+        for i in range(0, len(live), 3):
+            sync.push(live[i:i + 3])
+        red = sync.finish()
+        assert set(red) == {n for n, _ in live}
+        for n, t in live:
+            exp = torch.zeros_like(t)
+            for r in range(world):
+                gr = torch.Generator().manual_seed(7 + r)
+                for n2, p2 in net.named_parameters():
+                    v = None if n2.startswith("cblock.") else torch.randn(p2.shape, generator=gr)
+                    if n2 == n:
+                        exp += v
+            assert torch.allclose(red[n], exp / world, atol=1e-6), n
+        # 3. stand-alone in-place form
+        ts = [torch.full((5,), float(rank + 1)), None, torch.full((2, 3), float(10 * (rank + 1)))]
+        parallel.allreduce_mean_(ts)
+        assert torch.allclose(ts[0], torch.full((5,), (1 + world) / 2.0))
+        assert ts[1] is None and torch.allclose(ts[2], torch.full((2, 3), 10 * (1 + world) / 2.0))
+        open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gloo_world2_gradient_mean(tmp_path):
+    world = 2
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
+def test_single_process_is_noop():
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ct-unet_amd"))
+    from ctunet_amd import parallel
+    s = parallel.GradSync()
+    s.push([("a", torch.ones(3))])
+    assert s.finish() == {}
