@@ -216,6 +216,211 @@ __global__ __launch_bounds__(256) void conv3d_fwd_kernel(ConvP p) {
     }
 }
 
+
+// ------------------------------------------------------------------ persistent k=3 kernel
+// Same GEMM view and LDS images as conv3d_fwd_kernel, restructured for the large layers:
+//  * a block walks a CONTIGUOUS range of voxel boxes (neighbouring boxes share halos in L1/L2),
+//  * the next (box, chunk) stage's input and weights are prefetched into registers while the current
+//    stage's 27 taps run on the matrix cores; one LDS image, two barriers per stage,
+//  * layers with a single 8-channel chunk (C_in <= 8) stage their weights once per block.
+template <int NT>
+__global__ __launch_bounds__(256) void conv3d_fwd_k3_persist(ConvP p, int ntiles, int tiles_per_block) {
+    constexpr int PAD = 1, TD = 4, TH = 4, TW = 16;
+    constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2, HV = HD * HH * HW;
+    constexpr int MT = 4;
+    constexpr int WFL = 27 * NT * 128;
+    constexpr int AITEMS = HV * 2, AITER = (AITEMS + 255) / 256;
+    constexpr int WITER = (WFL / 4 + 255) / 256;
+
+    __shared__ __attribute__((aligned(16))) float sA[HV * VS];
+    __shared__ __attribute__((aligned(16))) float sW[WFL];
+    __shared__ float sRed[4 * NT * 16 * 2];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, kq = lane >> 4;
+    const int by = blockIdx.y;
+    const int n16 = p.n16;
+    const int nchunk = p.rin_p >> 3;
+    const bool hoist_w = nchunk == 1;
+    const int half = tid & 1;
+    const bool has_xf = p.in_scale != nullptr;
+
+    int abase[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) abase[mt] = ((wave * HH + mt) * HW + m) * VS + kq * 2;   // td = wave, th = mt, tw = m
+    const int bbase = kq * 32 + m * 2;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int tile = blockIdx.x * tiles_per_block;
+    const int tile_end = min(ntiles, tile + tiles_per_block);
+    if (tile >= tile_end) return;
+    int c = 0;
+
+    float4 va[AITER], vw[WITER];
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned vmask = 0;
+
+    auto tile_origin = [&](int t, int& n_img, int& d0, int& h0, int& w0) {
+        const int tx = t % p.tiles_w; t /= p.tiles_w;
+        const int ty = t % p.tiles_h; t /= p.tiles_h;
+        const int tz = t % p.tiles_d; t /= p.tiles_d;
+        n_img = t; d0 = tz * TD; h0 = ty * TH; w0 = tx * TW;
+    };
+    auto load_a = [&](int t, int cc) {
+        int n_img, d0, h0, w0;
+        tile_origin(t, n_img, d0, h0, w0);
+        if (has_xf) {
+            sc = *reinterpret_cast<const float4*>(p.in_scale + cc * 8 + half * 4);
+            sh = *reinterpret_cast<const float4*>(p.in_shift + cc * 8 + half * 4);
+        }
+        vmask = 0;
+#pragma unroll
+        for (int it = 0; it < AITER; ++it) {
+            const int i = tid + it * 256;
+            const int v = i >> 1;
+            const int pw = v % HW, t2 = v / HW, ph = t2 % HH, pd = t2 / HH;
+            const int gd = d0 + pd - PAD, gh = h0 + ph - PAD, gw = w0 + pw - PAD;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < AITEMS && (unsigned)gd < (unsigned)p.D && (unsigned)gh < (unsigned)p.H &&
+                (unsigned)gw < (unsigned)p.W) {
+                const size_t vox = (((size_t)n_img * p.D + gd) * p.H + gh) * p.W + gw;
+                val = *reinterpret_cast<const float4*>(p.in + vox * p.in_cs + cc * 8 + half * 4);
+                vmask |= 1u << it;
+            }
+            va[it] = val;
+        }
+    };
+    auto load_w = [&](int cc) {
+        const float* wsrc = p.wp + (size_t)cc * 27 * n16 * 128 + (size_t)by * NT * 128;
+#pragma unroll
+        for (int it = 0; it < WITER; ++it) {
+            const int i = (tid + it * 256) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < WFL) {
+                const int ts = i / (NT * 128), r = i % (NT * 128);
+                if (by * NT * 128 + r < n16 * 128) v = *reinterpret_cast<const float4*>(wsrc + (size_t)ts * n16 * 128 + r);
+            }
+            vw[it] = v;
+        }
+    };
+    auto store_w = [&]() {
+#pragma unroll
+        for (int it = 0; it < WITER; ++it) {
+            const int i = (tid + it * 256) * 4;
+            if (i < WFL) *reinterpret_cast<float4*>(&sW[i]) = vw[it];
+        }
+    };
+
+    load_a(tile, 0);
+    load_w(0);
+    if (hoist_w) store_w();
+
+    while (true) {
+        __syncthreads();                       // the previous stage's readers are done with sA / sW
+#pragma unroll
+        for (int it = 0; it < AITER; ++it) {
+            const int i = tid + it * 256;
+            float4 val = va[it];
+            if (has_xf && ((vmask >> it) & 1u)) val = xform4(val, sc, sh, p.in_relu);
+            if (i < AITEMS) *reinterpret_cast<float4*>(&sA[(i >> 1) * VS + half * 4]) = val;
+        }
+        if (!hoist_w) store_w();
+        __syncthreads();
+        // ---- prefetch the next stage while this one computes
+        int ntile = tile, nc = c + 1;
+        if (nc == nchunk) { nc = 0; ntile = tile + 1; }
+        const bool has_next = ntile < tile_end;
+        if (has_next) {
+            load_a(ntile, nc);
+            if (!hoist_w) load_w(nc);
+        }
+        // ---- 27 taps on the matrix cores
+#pragma unroll
+        for (int ts = 0; ts < 27; ++ts) {
+            const int kd = ts / 9, kh = (ts / 3) % 3, kw = ts % 3;
+            const int toff = ((kd * HH + kh) * HW + kw) * VS;
+            float2 b[NT], a[MT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const float2*>(&sW[(ts * NT + nt) * 128 + bbase]);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const float2*>(&sA[abase[mt] + toff]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].x, b[nt].x, acc[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].y, b[nt].y, acc[mt][nt], 0, 0, 0);
+        }
+        if (c == nchunk - 1) {
+            // ---- epilogue of this box: bias, store, BatchNorm partial statistics
+            int n_img, d0, h0, w0;
+            tile_origin(tile, n_img, d0, h0, w0);
+            float s1[NT], s2[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                s1[nt] = 0.f; s2[nt] = 0.f;
+                const int co = (by * NT + nt) * 16 + m;
+                const bool cok = co < p.nout_p;
+                const float bv = (p.bias && co < p.nbias) ? p.bias[co] : 0.f;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int gd = d0 + wave, gh = h0 + mt;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int gw = w0 + kq * 4 + r;
+                        if (cok && gd < p.D && gh < p.H && gw < p.W) {
+                            const float v = acc[mt][nt][r] + bv;
+                            const size_t vox = (((size_t)n_img * p.D + gd) * p.H + gh) * p.W + gw;
+                            p.out[vox * p.out_cs + co] = v;
+                            s1[nt] += v;
+                            s2[nt] += v * v;
+                        }
+                    }
+                    acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            if (p.stats) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    float a1 = s1[nt], a2 = s2[nt];
+                    a1 += __shfl_xor(a1, 16); a1 += __shfl_xor(a1, 32);
+                    a2 += __shfl_xor(a2, 16); a2 += __shfl_xor(a2, 32);
+                    if (kq == 0) {
+                        sRed[((wave * NT + nt) * 16 + m) * 2 + 0] = a1;
+                        sRed[((wave * NT + nt) * 16 + m) * 2 + 1] = a2;
+                    }
+                }
+                __syncthreads();
+                if (tid < NT * 16) {
+                    const int co = by * NT * 16 + tid;
+                    if (co < p.nout_p) {
+                        float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) {
+                            a1 += sRed[((w * NT) * 16 + tid) * 2 + 0];
+                            a2 += sRed[((w * NT) * 16 + tid) * 2 + 1];
+                        }
+                        float* row = p.stats + (size_t)tile * 2 * p.nout_p;
+                        row[co] = a1;
+                        row[p.nout_p + co] = a2;
+                    }
+                }
+            }
+        }
+        if (!has_next) break;
+        tile = ntile; c = nc;
+    }
+}
+
 // ------------------------------------------------------------------ packing
 // wp index for (chunk c, stage s, tap-in-stage ts, 16-wide output tile, kq, n, j)
 template <int KS>
@@ -423,6 +628,191 @@ inline int wgrad_gx(int ntiles, int pairs_z) {
     return gx;
 }
 
+
+// ------------------------------------------------------------------ weight gradient, narrow layers (k = 3)
+// When a side has only 8 (padded) channels, a plain 16x16 MFMA tile is half empty on that side.  Here a
+// tile axis carries (w-shift, channel) pairs instead:
+//   M index (s, ci):  A[(s,ci)][k = v] = a_in[v + (kd, kh, t0 + s) - pad][ci]
+//   N index (s', co): B[k = v][(s',co)] = gout[v - s' e_w][co]
+//   => entry [(s,ci),(s',co)] = dW[kd, kh, kw = t0 + s + s'][ci][co]
+// (re-indexing u = v - s' e_w; the u_w = W-1 plane that a box decomposition of v never reaches for s' = 1
+//  only multiplies a_in at w = W, i.e. zero padding, for the entries that are kept).
+//   SM = SN = 2 (8 -> 8):   1 MFMA per (kd,kh) gives kw 0,1,2           ->  9 MFMAs per K-step (27 before)
+//   SM = 1, SN = 2 (C -> 8): t0 = 0 keeps s'=0 (kw 0); t0 = 1 gives kw 1,2 -> 18
+//   SM = 2, SN = 1 (8 -> C): t0 = 0 gives kw 0,1; t0 = 1 keeps s=1 (kw 2)  -> 18
+// Persistent blocks walk contiguous voxel boxes with register prefetch of the next box.
+template <int SM, int SN>
+__global__ __launch_bounds__(256) void conv3d_wgrad_k3s_kernel(WgP p, int tiles_per_block) {
+    constexpr int TD = 4, TH = 4, TW = 16, HD = 6, HH = 6, HW = 18, HV = HD * HH * HW;
+    constexpr int CM = 16 / SM, CN = 16 / SN;        // channels per block on the input / output side
+    constexpr int GW = TW + (SN - 1), GV = TD * TH * GW;
+    constexpr int NMF = (SM == 2 && SN == 2) ? 9 : 18;
+    constexpr int AQ = CM / 4, GQ = CN / 4;
+    constexpr int AITEMS = HV * AQ, AITER = (AITEMS + 255) / 256;
+    constexpr int GITEMS = GV * GQ, GITER = (GITEMS + 255) / 256;
+
+    __shared__ __attribute__((aligned(16))) float sA[HV * CM];
+    __shared__ __attribute__((aligned(16))) float sG[GV * CN];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, kq = lane >> 4;
+    const int cig = blockIdx.y % p.n_ci_t, cog = blockIdx.y / p.n_ci_t;
+    const int ci0 = cig * CM, co0 = cog * CN;
+    const bool has_xf = p.in_scale != nullptr;
+
+    f32x4 acc[NMF];
+#pragma unroll
+    for (int t = 0; t < NMF; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int aq = tid % AQ, gq = tid % GQ;          // 256 % AQ == 0: a thread keeps its channel quad
+    const bool a_ok = (ci0 + aq * 4) < p.cin_p, g_ok = (co0 + gq * 4) < p.cout_p;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (has_xf && a_ok) {
+        sc = *reinterpret_cast<const float4*>(p.in_scale + ci0 + aq * 4);
+        sh = *reinterpret_cast<const float4*>(p.in_shift + ci0 + aq * 4);
+    }
+    const int boff = (SN == 2) ? ((i < 8) ? i : i - 16) : i;
+
+    int tile = blockIdx.x * tiles_per_block;
+    const int tile_end = min(p.ntiles, tile + tiles_per_block);
+    float4 va[AITER], vg[GITER];
+
+    auto load = [&](int t) {
+        const int tx = t % p.tiles_w; t /= p.tiles_w;
+        const int ty = t % p.tiles_h; t /= p.tiles_h;
+        const int tz = t % p.tiles_d; t /= p.tiles_d;
+        const int n_img = t, d0 = tz * TD, h0 = ty * TH, w0 = tx * TW;
+#pragma unroll
+        for (int it = 0; it < AITER; ++it) {
+            const int e = tid + it * 256, v = e / AQ;
+            const int pw = v % HW, t2 = v / HW, ph = t2 % HH, pd = t2 / HH;
+            const int gd = d0 + pd - 1, gh = h0 + ph - 1, gw = w0 + pw - 1;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < AITEMS && a_ok && (unsigned)gd < (unsigned)p.D && (unsigned)gh < (unsigned)p.H &&
+                (unsigned)gw < (unsigned)p.W) {
+                const size_t vox = (((size_t)n_img * p.D + gd) * p.H + gh) * p.W + gw;
+                val = *reinterpret_cast<const float4*>(p.in + vox * p.in_cs + ci0 + aq * 4);
+                if (has_xf) val = xform4(val, sc, sh, p.in_relu);
+            }
+            va[it] = val;
+        }
+#pragma unroll
+        for (int it = 0; it < GITER; ++it) {
+            const int e = tid + it * 256, v = e / GQ;
+            const int tw = v % GW, th = (v / GW) % TH, td = v / (GW * TH);
+            const int gd = d0 + td, gh = h0 + th, gw = w0 + tw - (SN - 1);
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < GITEMS && g_ok && gd < p.D && gh < p.H && (unsigned)gw < (unsigned)p.W) {
+                const size_t vox = (((size_t)n_img * p.D + gd) * p.H + gh) * p.W + gw;
+                val = *reinterpret_cast<const float4*>(p.g + vox * p.g_cs + co0 + gq * 4);
+            }
+            vg[it] = val;
+        }
+    };
+
+    if (tile < tile_end) load(tile);
+    while (tile < tile_end) {
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < AITER; ++it) {
+            const int e = tid + it * 256;
+            if (e < AITEMS) *reinterpret_cast<float4*>(&sA[e * 4]) = va[it];
+        }
+#pragma unroll
+        for (int it = 0; it < GITER; ++it) {
+            const int e = tid + it * 256;
+            if (e < GITEMS) *reinterpret_cast<float4*>(&sG[e * 4]) = vg[it];
+        }
+        __syncthreads();
+        if (tile + 1 < tile_end) load(tile + 1);
+#pragma unroll 2
+        for (int ks = 0; ks < 16; ++ks) {
+            const int th = ks >> 2, tw = (ks & 3) * 4 + kq;           // td = wave
+            const float b = sG[((wave * TH + th) * GW + tw + (SN - 1)) * CN + boff];
+            const int ab = ((wave * HH + th) * HW + tw) * CM + i;
+#pragma unroll
+            for (int t = 0; t < NMF; ++t) {
+                const int r = (NMF == 9) ? t : t / 2, q = (NMF == 9) ? 0 : t % 2;
+                const int kd = r / 3, kh = r % 3;
+                const float a = sA[ab + ((kd * HH + kh) * HW + q) * CM];
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
+            }
+        }
+        ++tile;
+    }
+    // 4 waves -> one slab [NMF][16][16] per block (through sA, 4 * NMF * 256 floats <= HV * CM for CM = 8 needs rounds)
+    constexpr int RT = (HV * CM / 1024) < NMF ? (HV * CM / 1024) : NMF;
+    static_assert(RT >= 1, "reduction scratch");
+    const size_t slab = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    float* dst = p.ws + slab * (NMF * 256);
+    for (int t0 = 0; t0 < NMF; t0 += RT) {
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < NMF; ++t)
+            if (t >= t0 && t < t0 + RT) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sA[(wave * RT + (t - t0)) * 256 + (kq * 4 + r) * 16 + i] = acc[t][r];
+            }
+        __syncthreads();
+        const int nt = (NMF - t0) < RT ? (NMF - t0) : RT;
+        for (int e = tid; e < nt * 256; e += 256)
+            dst[t0 * 256 + e] = (sA[e] + sA[RT * 256 + e]) + (sA[2 * RT * 256 + e] + sA[3 * RT * 256 + e]);
+    }
+}
+
+template <int SM, int SN>
+__global__ __launch_bounds__(256) void conv3d_wgrad_k3s_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
+                                                                      int Co, int Ci, const int32_t* __restrict__ cinv,
+                                                                      int cin_p, int n_ci_g, int gx) {
+    constexpr int NMF = (SM == 2 && SN == 2) ? 9 : 18;
+    constexpr int CM = 16 / SM, CN = 16 / SN;
+    __shared__ float red[4][64];
+    const int e = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int el = blockIdx.x * 64 + e;
+    const int pair = blockIdx.y;
+    float s = 0.f;
+    if (el < NMF * 256) {
+        const float* src = ws + (size_t)pair * gx * (NMF * 256) + el;
+        for (int k = part; k < gx; k += 4) s += src[(size_t)k * (NMF * 256)];
+    }
+    red[part][e] = s;
+    __syncthreads();
+    if (part != 0 || el >= NMF * 256) return;
+    const float tot = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    const int t = el >> 8, i = (el >> 4) & 15, j = el & 15;
+    const int r = (NMF == 9) ? t : t / 2, q = (NMF == 9) ? 0 : t % 2;
+    const int sm = (SM == 2) ? i / 8 : 0, cil = (SM == 2) ? i % 8 : i;
+    const int sn = (SN == 2) ? j / 8 : 0, col = (SN == 2) ? j % 8 : j;
+    int kw;
+    bool ok = true;
+    if (SM == 2 && SN == 2) { kw = sm + sn; ok = !(sm == 0 && sn == 1); }
+    else if (SN == 2) { if (q == 0) { kw = 0; ok = sn == 0; } else kw = 1 + sn; }
+    else { if (q == 0) kw = sm; else { kw = 2; ok = sm == 1; } }
+    const int cig = pair % n_ci_g, cog = pair / n_ci_g;
+    const int cip = cig * CM + cil, co = cog * CN + col;
+    const int ci = (cip < cin_p) ? (cinv ? cinv[cip] : (cip < Ci ? cip : -1)) : -1;
+    if (ok && ci >= 0 && co < Co) dw[((size_t)co * Ci + ci) * 27 + r * 3 + kw] = tot;
+}
+
+template <int SM, int SN>
+static int launch_wgrad_k3s(WgP p, float* dw, int Co, int Ci, const int32_t* cinv, hipStream_t st) {
+    constexpr int NMF = (SM == 2 && SN == 2) ? 9 : 18;
+    p.tiles_d = ceil_div(p.D, 4); p.tiles_h = ceil_div(p.H, 4); p.tiles_w = ceil_div(p.W, 16);
+    p.ntiles = p.N * p.tiles_d * p.tiles_h * p.tiles_w;
+    p.n_ci_t = ceil_div(p.cin_p, 16 / SM);
+    const int n_co_g = ceil_div(p.cout_p, 16 / SN);
+    const int pairs = p.n_ci_t * n_co_g;
+    int gx = wgrad_gx(p.ntiles, pairs);
+    const int tpb = ceil_div(p.ntiles, gx);
+    gx = ceil_div(p.ntiles, tpb);
+    conv3d_wgrad_k3s_kernel<SM, SN><<<dim3(gx, pairs), 256, 0, st>>>(p, tpb);
+    CTU_CHECK_LAUNCH("conv3d_wgrad_k3s");
+    conv3d_wgrad_k3s_reduce_kernel<SM, SN><<<dim3(ceil_div(NMF * 256, 64), pairs), 256, 0, st>>>(p.ws, dw, Co, Ci, cinv, p.cin_p,
+                                                                                              p.n_ci_t, gx);
+    CTU_CHECK_LAUNCH("conv3d_wgrad_k3s_reduce");
+    return CTU_OK;
+}
+
 }  // namespace
 
 // =================================================================== C ABI
@@ -484,6 +874,21 @@ extern "C" int ctu_conv3d_fwd(const float* in, int in_cs, int rin_p, const float
     hipStream_t st = (hipStream_t)stream;
     int NT, td, th, tw;
     pick_launch(N, D, H, W, nout_p, &NT, &td, &th, &tw);
+    if (k == 3 && tw == 16 && NT <= 2) {
+        // large layers: persistent, register-prefetching kernel; 3 resident blocks per CU
+        p.n16 = ceil_div(p.nout_p, 16);
+        p.tiles_d = ceil_div(D, 4); p.tiles_h = ceil_div(H, 4); p.tiles_w = ceil_div(W, 16);
+        const int ntiles = N * p.tiles_d * p.tiles_h * p.tiles_w;
+        const int ny = ceil_div(p.n16, NT);
+        int gx = ntiles < 768 / ny ? ntiles : 768 / ny;
+        if (gx < 1) gx = 1;
+        const int tpb = ceil_div(ntiles, gx);
+        gx = ceil_div(ntiles, tpb);
+        if (NT == 1) conv3d_fwd_k3_persist<1><<<dim3(gx, ny), 256, 0, st>>>(p, ntiles, tpb);
+        else conv3d_fwd_k3_persist<2><<<dim3(gx, ny), 256, 0, st>>>(p, ntiles, tpb);
+        CTU_CHECK_LAUNCH("conv3d_fwd_k3_persist");
+        return CTU_OK;
+    }
     if (k == 3) {
         if (NT == 1) return launch_fwd<3, 1>(p, td, th, tw, st);
         if (NT == 2) return launch_fwd<3, 2>(p, td, th, tw, st);
@@ -552,6 +957,16 @@ extern "C" int ctu_conv3d_wgrad(const float* in, int in_cs, int cin_p, const flo
     p.N = N; p.D = D; p.H = H; p.W = W;
     int gz, gx, bt;
     wgrad_geom(N, D, H, W, k, cin_p, cout_p, &p.ntiles, &p.n_ci_t, &p.n_co_t, &gz, &gx, &bt);
+    if (k == 3 && W >= 16 && (cin_p == 8 || cout_p == 8)) {
+        // narrow layers: (shift, channel) MFMA tiles; workspace need is below the generic bound
+        int rc2;
+        if (cin_p == 8 && cout_p == 8) rc2 = launch_wgrad_k3s<2, 2>(p, dw, Co, Ci, cinv, st);
+        else if (cout_p == 8) rc2 = launch_wgrad_k3s<1, 2>(p, dw, Co, Ci, cinv, st);
+        else rc2 = launch_wgrad_k3s<2, 1>(p, dw, Co, Ci, cinv, st);
+        if (rc2 != CTU_OK) return rc2;
+        if (dbias) return ctu_channel_sum(gout, g_cs, cout_p, (int64_t)N * D * H * W, ws, dbias, Co, stream);
+        return CTU_OK;
+    }
     int rc = (k == 3) ? launch_wgrad<3, 3>(p, dw, Co, Ci, cinv, gz, gx, st)
                       : launch_wgrad<5, 1>(p, dw, Co, Ci, cinv, gz, gx, st);
     if (rc != CTU_OK) return rc;
