@@ -421,6 +421,201 @@ __global__ __launch_bounds__(256) void conv3d_fwd_k3_persist(ConvP p, int ntiles
     }
 }
 
+// ------------------------------------------------------------------ persistent k=3 kernel, C_out = 8 ("pair" layout)
+// With 8 output channels a 16-wide MFMA N tile would be half padding.  Here N = (s, co), s in {0,1} a shift
+// along w, and M = 16 voxel PAIRS (w = 2m, 2m+1):
+//   out[(d,h,2m+s), co] = sum_{kd,kh,kw',ci} in[(d+kd, h+kh, 2m+kw') - pad][ci] * Wp[kd,kh,kw'][ci][(s,co)],
+//   Wp[.., kw'][ci][(s,co)] = W[.., kw'-s][ci][co] for 0 <= kw'-s <= 2, else 0        (kw' = 0..3)
+// 36 taps over half as many M-tiles: 1.5x fewer MFMAs than padding N.  Box = 4x4x32 voxels per block.
+__global__ __launch_bounds__(256) void conv3d_fwd_k3_pair8(ConvP p, int ntiles, int tiles_per_block) {
+    constexpr int PAD = 1, TD = 4, TH = 4, TW = 32;
+    constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2, HV = HD * HH * HW;
+    constexpr int MT = 4, NTAP = 36;
+    constexpr int WFL = NTAP * 128;
+    constexpr int AITEMS = HV * 2, AITER = (AITEMS + 255) / 256;
+    constexpr int WITER = (WFL / 4 + 255) / 256;
+
+    __shared__ __attribute__((aligned(16))) float sA[HV * VS];
+    __shared__ __attribute__((aligned(16))) float sW[WFL];
+    __shared__ float sRed[4 * 16 * 2];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, kq = lane >> 4;
+    const int nchunk = p.rin_p >> 3;
+    const bool hoist_w = nchunk == 1;
+    const int half = tid & 1;
+    const bool has_xf = p.in_scale != nullptr;
+
+    int abase[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) abase[mt] = ((wave * HH + mt) * HW + 2 * m) * VS + kq * 2;   // td = wave, th = mt
+    const int bbase = kq * 32 + m * 2;
+
+    f32x4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int tile = blockIdx.x * tiles_per_block;
+    const int tile_end = min(ntiles, tile + tiles_per_block);
+    if (tile >= tile_end) return;
+    int c = 0;
+
+    float4 va[AITER], vw[WITER];
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned vmask = 0;
+
+    auto tile_origin = [&](int t, int& n_img, int& d0, int& h0, int& w0) {
+        const int tx = t % p.tiles_w; t /= p.tiles_w;
+        const int ty = t % p.tiles_h; t /= p.tiles_h;
+        const int tz = t % p.tiles_d; t /= p.tiles_d;
+        n_img = t; d0 = tz * TD; h0 = ty * TH; w0 = tx * TW;
+    };
+    auto load_a = [&](int t, int cc) {
+        int n_img, d0, h0, w0;
+        tile_origin(t, n_img, d0, h0, w0);
+        if (has_xf) {
+            sc = *reinterpret_cast<const float4*>(p.in_scale + cc * 8 + half * 4);
+            sh = *reinterpret_cast<const float4*>(p.in_shift + cc * 8 + half * 4);
+        }
+        vmask = 0;
+#pragma unroll
+        for (int it = 0; it < AITER; ++it) {
+            const int i = tid + it * 256;
+            const int v = i >> 1;
+            const int pw = v % HW, t2 = v / HW, ph = t2 % HH, pd = t2 / HH;
+            const int gd = d0 + pd - PAD, gh = h0 + ph - PAD, gw = w0 + pw - PAD;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < AITEMS && (unsigned)gd < (unsigned)p.D && (unsigned)gh < (unsigned)p.H &&
+                (unsigned)gw < (unsigned)p.W) {
+                const size_t vox = (((size_t)n_img * p.D + gd) * p.H + gh) * p.W + gw;
+                val = *reinterpret_cast<const float4*>(p.in + vox * p.in_cs + cc * 8 + half * 4);
+                vmask |= 1u << it;
+            }
+            va[it] = val;
+        }
+    };
+    auto load_w = [&](int cc) {
+        const float* wsrc = p.wp + (size_t)cc * WFL;
+#pragma unroll
+        for (int it = 0; it < WITER; ++it) {
+            const int i = (tid + it * 256) * 4;
+            vw[it] = (i < WFL) ? *reinterpret_cast<const float4*>(wsrc + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_w = [&]() {
+#pragma unroll
+        for (int it = 0; it < WITER; ++it) {
+            const int i = (tid + it * 256) * 4;
+            if (i < WFL) *reinterpret_cast<float4*>(&sW[i]) = vw[it];
+        }
+    };
+
+    load_a(tile, 0);
+    load_w(0);
+    if (hoist_w) store_w();
+
+    while (true) {
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < AITER; ++it) {
+            const int i = tid + it * 256;
+            float4 val = va[it];
+            if (has_xf && ((vmask >> it) & 1u)) val = xform4(val, sc, sh, p.in_relu);
+            if (i < AITEMS) *reinterpret_cast<float4*>(&sA[(i >> 1) * VS + half * 4]) = val;
+        }
+        if (!hoist_w) store_w();
+        __syncthreads();
+        int ntile = tile, nc = c + 1;
+        if (nc == nchunk) { nc = 0; ntile = tile + 1; }
+        const bool has_next = ntile < tile_end;
+        if (has_next) {
+            load_a(ntile, nc);
+            if (!hoist_w) load_w(nc);
+        }
+#pragma unroll
+        for (int ts = 0; ts < NTAP; ++ts) {
+            const int kd = ts / 12, kh = (ts / 4) % 3, kw = ts % 4;
+            const int toff = ((kd * HH + kh) * HW + kw) * VS;
+            const float2 b = *reinterpret_cast<const float2*>(&sW[ts * 128 + bbase]);
+            float2 a[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const float2*>(&sA[abase[mt] + toff]);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].x, b.x, acc[mt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].y, b.y, acc[mt], 0, 0, 0);
+        }
+        if (c == nchunk - 1) {
+            int n_img, d0, h0, w0;
+            tile_origin(tile, n_img, d0, h0, w0);
+            const int co = m & 7, s = m >> 3;
+            const float bv = (p.bias && co < p.nbias) ? p.bias[co] : 0.f;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int gd = d0 + wave, gh = h0 + mt;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int gw = w0 + 2 * (kq * 4 + r) + s;
+                    if (gd < p.D && gh < p.H && gw < p.W) {
+                        const float v = acc[mt][r] + bv;
+                        const size_t vox = (((size_t)n_img * p.D + gd) * p.H + gh) * p.W + gw;
+                        p.out[vox * p.out_cs + co] = v;
+                        s1 += v;
+                        s2 += v * v;
+                    }
+                }
+                acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            if (p.stats) {
+                s1 += __shfl_xor(s1, 8); s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
+                s2 += __shfl_xor(s2, 8); s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
+                if (lane < 8) { sRed[(wave * 8 + lane) * 2] = s1; sRed[(wave * 8 + lane) * 2 + 1] = s2; }
+                __syncthreads();
+                if (tid < 8) {
+                    float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) { a1 += sRed[(w * 8 + tid) * 2]; a2 += sRed[(w * 8 + tid) * 2 + 1]; }
+                    float* row = p.stats + (size_t)tile * 2 * p.nout_p;
+                    row[tid] = a1;
+                    row[p.nout_p + tid] = a2;
+                }
+            }
+        }
+        if (!has_next) break;
+        tile = ntile; c = nc;
+    }
+}
+
+// pair layout packing: [chunk][kd][kh][kw' (4)][kq][n = s*8+o][j]; gather, every element written
+__global__ void pack_conv_w_pair8_kernel(const float* __restrict__ w, float* __restrict__ wp, int Co, int Ci,
+                                         const int32_t* __restrict__ cinv, int nchunk, int mode) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nchunk * 36 * 128) return;
+    int r = idx;
+    const int j = r & 1; r >>= 1;
+    const int n = r & 15; r >>= 4;
+    const int kq = r & 3; r >>= 2;
+    const int kwp = r & 3; r >>= 2;
+    const int kh = r % 3; r /= 3;
+    const int kd = r % 3; r /= 3;
+    const int c = r;
+    const int s = n >> 3, o = n & 7, kw = kwp - s;
+    const int rp = c * 8 + kq * 2 + j;
+    float v = 0.f;
+    if (kw >= 0 && kw <= 2) {
+        const int t = (kd * 3 + kh) * 3 + kw;
+        if (mode == 0) {
+            const int ci = cinv ? cinv[rp] : (rp < Ci ? rp : -1);
+            if (ci >= 0 && o < Co) v = w[((size_t)o * Ci + ci) * 27 + t];
+        } else {
+            const int ci = cinv ? cinv[o] : (o < Ci ? o : -1);
+            if (ci >= 0 && rp < Co) v = w[((size_t)rp * Ci + ci) * 27 + (26 - t)];
+        }
+    }
+    wp[idx] = v;
+}
+
 // ------------------------------------------------------------------ packing
 // wp index for (chunk c, stage s, tap-in-stage ts, 16-wide output tile, kq, n, j)
 template <int KS>
@@ -816,25 +1011,39 @@ static int launch_wgrad_k3s(WgP p, float* dw, int Co, int Ci, const int32_t* cin
 }  // namespace
 
 // =================================================================== C ABI
-extern "C" size_t ctu_conv3d_packed_floats(int k, int rin_p, int nout_p) {
+extern "C" int ctu_conv3d_layout(int k, int nout_p, int W) {
+    return (k == 3 && nout_p == 8 && W >= 32) ? 1 : 0;
+}
+
+extern "C" size_t ctu_conv3d_packed_floats(int k, int rin_p, int nout_p, int layout) {
     if ((k != 3 && k != 5) || rin_p <= 0 || nout_p <= 0) return 0;
+    if (layout == 1) return (k == 3 && nout_p == 8) ? (size_t)(rin_p / 8) * 36 * 128 : 0;
     return (size_t)(rin_p / 8) * k * k * k * ceil_div(nout_p, 16) * 128;
 }
 
-extern "C" int ctu_conv3d_num_blocks(int N, int D, int H, int W, int nout_p) {
+extern "C" int ctu_conv3d_num_blocks(int N, int D, int H, int W, int nout_p, int layout) {
+    if (layout == 1) return N * ceil_div(D, 4) * ceil_div(H, 4) * ceil_div(W, 32);
     int nt, td, th, tw;
     pick_launch(N, D, H, W, nout_p, &nt, &td, &th, &tw);
     return N * ceil_div(D, td) * ceil_div(H, th) * ceil_div(W, tw);
 }
 
 extern "C" int ctu_pack_conv3d_weight(const float* w, float* wp, int Co, int Ci, int k, const int32_t* cinv,
-                                      int rin_p, int nout_p, int mode, void* stream) {
+                                      int rin_p, int nout_p, int mode, int layout, void* stream) {
     CTU_REQUIRE(k == 3 || k == 5, "pack_conv3d_weight: k=%d unsupported (3 or 5)", k);
     CTU_REQUIRE(rin_p % 8 == 0 && nout_p % 8 == 0, "pack_conv3d_weight: padded channels must be multiples of 8");
     CTU_REQUIRE(w && wp && Co > 0 && Ci > 0, "pack_conv3d_weight: null/empty argument");
+    CTU_REQUIRE(layout == 0 || (layout == 1 && k == 3 && nout_p == 8), "pack_conv3d_weight: layout %d needs k=3, nout_p=8",
+                layout);
     hipStream_t st = (hipStream_t)stream;
+    if (layout == 1) {
+        const int tot = (rin_p / 8) * 36 * 128;
+        pack_conv_w_pair8_kernel<<<ceil_div(tot, 256), 256, 0, st>>>(w, wp, Co, Ci, cinv, rin_p / 8, mode);
+        CTU_CHECK_LAUNCH("pack_conv3d_weight(pair8)");
+        return CTU_OK;
+    }
     const int n16 = ceil_div(nout_p, 16);
-    const int total = (int)ctu_conv3d_packed_floats(k, rin_p, nout_p);
+    const int total = (int)ctu_conv3d_packed_floats(k, rin_p, nout_p, 0);
     const int nb = ceil_div(total, 256);
     if (k == 3) pack_conv_w_kernel<3><<<nb, 256, 0, st>>>(w, wp, Co, Ci, cinv, rin_p / 8, n16, mode);
     else pack_conv_w_kernel<5><<<nb, 256, 0, st>>>(w, wp, Co, Ci, cinv, rin_p / 8, n16, mode);
@@ -857,7 +1066,7 @@ static int launch_fwd(const ConvP& p0, int td, int th, int tw, hipStream_t st) {
 
 extern "C" int ctu_conv3d_fwd(const float* in, int in_cs, int rin_p, const float* in_scale, const float* in_shift,
                               int in_relu, const float* wp, const float* bias, int nbias, float* out, int out_cs,
-                              int nout_p, float* stats, int N, int D, int H, int W, int k, void* stream) {
+                              int nout_p, float* stats, int N, int D, int H, int W, int k, int layout, void* stream) {
     CTU_REQUIRE(k == 3 || k == 5, "conv3d_fwd: k=%d unsupported (3 or 5)", k);
     CTU_REQUIRE(in && wp && out, "conv3d_fwd: null pointer");
     CTU_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0, "conv3d_fwd: empty volume %dx%dx%dx%d", N, D, H, W);
@@ -872,6 +1081,19 @@ extern "C" int ctu_conv3d_fwd(const float* in, int in_cs, int rin_p, const float
     p.nbias = bias ? nbias : 0;
     p.N = N; p.D = D; p.H = H; p.W = W;
     hipStream_t st = (hipStream_t)stream;
+    if (layout == 1) {
+        CTU_REQUIRE(k == 3 && nout_p == 8, "conv3d_fwd: layout 1 needs k=3 and nout_p=8");
+        p.n16 = 1;
+        p.tiles_d = ceil_div(D, 4); p.tiles_h = ceil_div(H, 4); p.tiles_w = ceil_div(W, 32);
+        const int ntiles = N * p.tiles_d * p.tiles_h * p.tiles_w;
+        int gx = ntiles < 512 ? ntiles : 512;          // 2 resident blocks per CU (LDS)
+        const int tpb = ceil_div(ntiles, gx);
+        gx = ceil_div(ntiles, tpb);
+        conv3d_fwd_k3_pair8<<<gx, 256, 0, st>>>(p, ntiles, tpb);
+        CTU_CHECK_LAUNCH("conv3d_fwd_k3_pair8");
+        return CTU_OK;
+    }
+    CTU_REQUIRE(layout == 0, "conv3d_fwd: unknown layout %d", layout);
     int NT, td, th, tw;
     pick_launch(N, D, H, W, nout_p, &NT, &td, &th, &tw);
     if (k == 3 && tw == 16 && NT <= 2) {

@@ -26,10 +26,11 @@ SIGNATURES = {
     "ctu_arch": (C.c_char_p, []),
     "ctu_ncdhw_to_ndhwc": (I, [P, P, I, I, I, I, I, I, I, P]),
     "ctu_ndhwc_to_ncdhw": (I, [P, P, I, I, I, I, I, I, P]),
-    "ctu_conv3d_packed_floats": (Z, [I, I, I]),
-    "ctu_conv3d_num_blocks": (I, [I, I, I, I, I]),
-    "ctu_pack_conv3d_weight": (I, [P, P, I, I, I, P, I, I, I, P]),
-    "ctu_conv3d_fwd": (I, [P, I, I, P, P, I, P, P, I, P, I, I, P, I, I, I, I, I, P]),
+    "ctu_conv3d_layout": (I, [I, I, I]),
+    "ctu_conv3d_packed_floats": (Z, [I, I, I, I]),
+    "ctu_conv3d_num_blocks": (I, [I, I, I, I, I, I]),
+    "ctu_pack_conv3d_weight": (I, [P, P, I, I, I, P, I, I, I, I, P]),
+    "ctu_conv3d_fwd": (I, [P, I, I, P, P, I, P, P, I, P, I, I, P, I, I, I, I, I, I, P]),
     "ctu_conv3d_wgrad_ws_floats": (Z, [I, I, I, I, I, I, I]),
     "ctu_conv3d_wgrad": (I, [P, I, I, P, P, I, P, I, I, P, P, I, I, P, P, I, I, I, I, I, P]),
     "ctu_bn_finalize": (I, [P, I, I, I, D, P, P, P, P, F, F, I, P, P, P, P, P]),

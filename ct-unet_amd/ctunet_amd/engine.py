@@ -83,14 +83,15 @@ class UNetEngine:
             self._imaps[key] = t
         return t
 
-    def _packed(self, name: str, w: torch.Tensor, kind: str, imap, rin_p: int, nout_p: int, mode: int) -> torch.Tensor:
-        key = (name, kind, mode, rin_p, nout_p)
+    def _packed(self, name: str, w: torch.Tensor, kind: str, imap, rin_p: int, nout_p: int, mode: int,
+                layout: int = 0) -> torch.Tensor:
+        key = (name, kind, mode, rin_p, nout_p, layout)
         hit = self._pack_cache.get(key)
         ver = (w._version, w.data_ptr())
         if hit is not None and hit[0] == ver:
             return hit[1]
         wd = w.detach()
-        wp = ops.pack_conv_w(wd, imap, rin_p, nout_p, mode) if kind == "conv" else \
+        wp = ops.pack_conv_w(wd, imap, rin_p, nout_p, mode, layout) if kind == "conv" else \
             ops.pack_convt_w(wd, imap, rin_p, nout_p, mode)
         self._pack_cache[key] = (ver, wp)
         return wp
@@ -100,22 +101,23 @@ class UNetEngine:
                  training: bool, n_upd: int, save: bool) -> Tuple[CL, Optional[_ConvRec]]:
         k = self.plan.k
         w = P[conv + ".weight"]
-        wp = self._packed(conv, w, "conv", imap, x.cp, out.cp, 0)
+        lay = ops.conv_layout(k, out.cp, x.dims[3])
+        wp = self._packed(conv, w, "conv", imap, x.cp, out.cp, 0, lay)
         bias = P.get(conv + ".bias")
         bias_p = None if bias is None else bias.detach()
         dims = x.dims
         c = cout
         if training:
-            nblk = ops.conv_num_blocks(dims, out.cp)
+            nblk = ops.conv_num_blocks(dims, out.cp, lay)
             stats = torch.empty((nblk, 2, out.cp), dtype=torch.float32, device=x.buf.device)
-            ops.conv3d_fwd(x, wp, bias_p, out, k, stats, (cin, cout))
+            ops.conv3d_fwd(x, wp, bias_p, out, k, stats, (cin, cout), lay)
             ops.bn_finalize_into(stats, nblk, c, out.cp, x.nvox, P[bn + ".weight"], P[bn + ".bias"],
                                  P[bn + ".running_mean"], P[bn + ".running_var"], BN_MOMENTUM, BN_EPS, n_upd, vec4)
             if n_upd:
                 self._nbt.append(P[bn + ".num_batches_tracked"])
         else:
             stats, nblk = None, 0
-            ops.conv3d_fwd(x, wp, bias_p, out, k, None, (cin, cout))
+            ops.conv3d_fwd(x, wp, bias_p, out, k, None, (cin, cout), lay)
             ops.bn_eval_affine_into(P[bn + ".weight"], P[bn + ".bias"], P[bn + ".running_mean"],
                                     P[bn + ".running_var"], BN_EPS, c, out.cp, vec4)
         y = out.with_xf(vec4[0], vec4[1], True)
@@ -236,8 +238,9 @@ class UNetEngine:
         if rec.bias:
             grads[rec.conv + ".bias"] = dbias
         if gin is not None:
-            wpd = self._packed(rec.conv, P[rec.conv + ".weight"], "conv", rec.imap, ga.cp, gin.cp, 1)
-            ops.conv3d_fwd(ga, wpd, None, gin, k, None, (rec.cout, rec.cin))
+            lay = ops.conv_layout(k, gin.cp, ga.dims[3])
+            wpd = self._packed(rec.conv, P[rec.conv + ".weight"], "conv", rec.imap, ga.cp, gin.cp, 1, lay)
+            ops.conv3d_fwd(ga, wpd, None, gin, k, None, (rec.cout, rec.cin), lay)
 
     def backward(self, P: Dict[str, torch.Tensor], ctx, g0: torch.Tensor, g1: Optional[torch.Tensor],
                  need_dx: bool, sync=None):

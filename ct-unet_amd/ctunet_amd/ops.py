@@ -156,25 +156,31 @@ def cl_to_ncdhw(a: CL, c: int) -> torch.Tensor:
 
 
 # ---------------------------------------------------------------------------- conv3d
-def pack_conv_w(w: torch.Tensor, cinv: Optional[torch.Tensor], rin_p: int, nout_p: int, mode: int) -> torch.Tensor:
+def conv_layout(k: int, nout_p: int, w: int) -> int:
+    """Packed-weight layout the forward kernel wants for this output width / volume width."""
+    return _lib.load().ctu_conv3d_layout(k, nout_p, w)
+
+
+def pack_conv_w(w: torch.Tensor, cinv: Optional[torch.Tensor], rin_p: int, nout_p: int, mode: int,
+                layout: int = 0) -> torch.Tensor:
     """cinv: int32 map padded input-channel position -> logical channel (-1 = padding), None = identity."""
     _need_cuda(w, "conv weight")
     co, ci, k = w.shape[0], w.shape[1], w.shape[2]
     lib = _lib.load()
-    n = lib.ctu_conv3d_packed_floats(k, rin_p, nout_p)
+    n = lib.ctu_conv3d_packed_floats(k, rin_p, nout_p, layout)
     wp = torch.empty(n, dtype=torch.float32, device=w.device)
     _lib.check(lib.ctu_pack_conv3d_weight(w.contiguous().data_ptr(), wp.data_ptr(), co, ci, k, _ptr(cinv), rin_p,
-                                          nout_p, mode, _stream()), "pack_conv3d_weight")
+                                          nout_p, mode, layout, _stream()), "pack_conv3d_weight")
     return wp
 
 
-def conv_num_blocks(dims, nout_p: int) -> int:
+def conv_num_blocks(dims, nout_p: int, layout: int = 0) -> int:
     n, d, h, w = dims
-    return _lib.load().ctu_conv3d_num_blocks(n, d, h, w, nout_p)
+    return _lib.load().ctu_conv3d_num_blocks(n, d, h, w, nout_p, layout)
 
 
 def conv3d_fwd(x: CL, wp: torch.Tensor, bias: Optional[torch.Tensor], out: CL, k: int,
-               stats: Optional[torch.Tensor] = None, algo_ch: Optional[Tuple[int, int]] = None) -> None:
+               stats: Optional[torch.Tensor] = None, algo_ch: Optional[Tuple[int, int]] = None, layout: int = 0) -> None:
     """algo_ch = (logical Cin, logical Cout) -- only used to count algorithmic FLOPs when timing."""
     n, d, h, w = x.dims
     assert out.dims == x.dims
@@ -182,7 +188,7 @@ def conv3d_fwd(x: CL, wp: torch.Tensor, bias: Optional[torch.Tensor], out: CL, k
     t0 = TIMER.begin() if TIMER is not None else None
     _lib.check(lib.ctu_conv3d_fwd(x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), wp.data_ptr(),
                                   _ptr(bias), 0 if bias is None else bias.numel(), out.ptr, out.cs, out.cp, _ptr(stats),
-                                  n, d, h, w, k, _stream()), "conv3d_fwd")
+                                  n, d, h, w, k, layout, _stream()), "conv3d_fwd")
     if t0 is not None:
         ci, co = algo_ch if algo_ch is not None else (x.cp, out.cp)
         vox = n * d * h * w

@@ -56,10 +56,15 @@ int ctu_ndhwc_to_ncdhw(const float* src, float* dst, int N, int C, int D, int H,
                        int cs, void* stream);
 
 /* ------------------------------------------------------- conv3d (k=3 / k=5) ---- */
-/* Geometry helpers: packed-weight size (floats) and number of spatial blocks (= rows of
- * the stats-partials buffer) for a conv call. */
-size_t ctu_conv3d_packed_floats(int k, int rin_p, int nout_p);
-int ctu_conv3d_num_blocks(int N, int D, int H, int W, int nout_p);
+/* Packed-weight layouts.  0: [8-ch chunk][tap][16-wide out tile][kq][n][j].  1 ("pair", only k = 3 with
+ * nout_p = 8): the MFMA N axis carries (w-shift, out channel) and M carries voxel pairs, 36 taps with
+ * zero-filled entries -- 1.5x fewer MFMAs than padding 8 channels to 16.  ctu_conv3d_layout returns the
+ * layout the forward kernel is fastest with for a volume of width W; pack and forward must agree.
+ * Geometry helpers: packed-weight size (floats) and number of spatial blocks (= rows of the
+ * stats-partials buffer) of a conv call. */
+int ctu_conv3d_layout(int k, int nout_p, int W);
+size_t ctu_conv3d_packed_floats(int k, int rin_p, int nout_p, int layout);
+int ctu_conv3d_num_blocks(int N, int D, int H, int W, int nout_p, int layout);
 
 /* Re-layout a torch Conv3d weight [Co,Ci,k,k,k] for the implicit-GEMM kernels.
  *  mode 0 (forward): reduction side = padded input channels, output side = co.
@@ -72,7 +77,8 @@ int ctu_conv3d_num_blocks(int N, int D, int H, int W, int nout_p);
  * wp is written (padding slots get 0), no prior memset needed.
  * nn.Conv3d weights: ctunet/pytorch/models.py:26,29,38,41,71,76,403,407,430,434,482-488. */
 int ctu_pack_conv3d_weight(const float* w, float* wp, int Co, int Ci, int k,
-                           const int32_t* cinv, int rin_p, int nout_p, int mode, void* stream);
+                           const int32_t* cinv, int rin_p, int nout_p, int mode, int layout,
+                           void* stream);
 
 /* Implicit-GEMM 3D convolution on MFMA (v_mfma_f32_16x16x4_f32), stride 1, zero padding
  * (k-1)/2, NDHWC.  out[v, o] = bias[o] + sum_{tap,r} A(in[v+tap, r]) * wp[tap, r, o] with
@@ -89,7 +95,7 @@ int ctu_conv3d_fwd(const float* in, int in_cs, int rin_p,
                    const float* in_scale, const float* in_shift, int in_relu,
                    const float* wp, const float* bias, int nbias,
                    float* out, int out_cs, int nout_p, float* stats,
-                   int N, int D, int H, int W, int k, void* stream);
+                   int N, int D, int H, int W, int k, int layout, void* stream);
 
 /* Weight gradient of nn.Conv3d: dW[co,ci,tap] = sum_v A(in[v+tap, pos(ci)]) * gout[v, co],
  * pos = inverse of cinv.

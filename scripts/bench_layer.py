@@ -18,11 +18,12 @@ xx = x.with_xf(sc, sh, True)
 flops = 2.0 * ci * co * k ** 3 * s ** 3
 if op == "fwd":
     w = torch.randn(co, ci, k, k, k, device=dev) * 0.1
-    wp = ops.pack_conv_w(w, None, cip, cop, 0)
+    lay = ops.conv_layout(k, cop, s)
+    wp = ops.pack_conv_w(w, None, cip, cop, 0, lay)
     out = ops.CL(torch.empty(1, s, s, s, cop, device=dev), 0, cop)
-    nb = ops.conv_num_blocks((1, s, s, s), cop)
+    nb = ops.conv_num_blocks((1, s, s, s), cop, lay)
     stats = torch.empty(nb, 2, cop, device=dev)
-    fn = lambda: ops.conv3d_fwd(xx, wp, None, out, k, stats)
+    fn = lambda: ops.conv3d_fwd(xx, wp, None, out, k, stats, None, lay)
 elif op == "wgrad":
     g = ops.CL(torch.randn(1, s, s, s, cop, device=dev), 0, cop)
     ws = torch.empty(ops.conv3d_wgrad_ws((1, s, s, s), k, cip, cop), device=dev)

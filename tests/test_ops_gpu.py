@@ -47,6 +47,9 @@ def xf_vectors(c, cp, seed):
 CONV_CASES = [
     # N, Ci, Co, D, H, W, k, xf, bias
     (1, 8, 8, 8, 8, 16, 3, False, False),
+    (1, 8, 8, 4, 8, 32, 3, True, False),       # W >= 32, C_out 8: "pair" layout kernel
+    (2, 32, 7, 6, 5, 40, 3, True, True),       # pair layout, ragged box, 4 chunks, bias, 7 real channels
+    (1, 1, 8, 8, 4, 70, 3, False, False),
     (1, 1, 8, 16, 16, 16, 3, False, False),
     (2, 8, 16, 8, 12, 20, 3, True, False),     # ragged: H, W not multiples of the tile
     (1, 32, 8, 8, 8, 16, 3, True, False),      # the dominant decoder shape
@@ -76,14 +79,15 @@ def test_conv3d_fwd_and_stats(case):
         xa = F.relu(x * sc[:ci].view(1, -1, 1, 1, 1) + sh[:ci].view(1, -1, 1, 1, 1))
         xc = xc.with_xf(sc.cuda(), sh.cuda(), True)
     ref = F.conv3d(xa, wt, b, 1, (k - 1) // 2)
-    wp = ops.pack_conv_w(wt.cuda(), None, cip, cop, 0)
+    lay = ops.conv_layout(k, cop, w)
+    wp = ops.pack_conv_w(wt.cuda(), None, cip, cop, 0, lay)
     bp = b.cuda() if bias else None          # logical, unpadded bias
     # write into a channel slice of a wider buffer to exercise strides
     obuf = torch.full((n, d, h, w, cop + 8), 7.0, device="cuda")
     out = ops.CL(obuf, 8, cop)
-    nb = ops.conv_num_blocks((n, d, h, w), cop)
+    nb = ops.conv_num_blocks((n, d, h, w), cop, lay)
     stats = torch.full((nb, 2, cop), float("nan"), device="cuda")      # every row must be written
-    ops.conv3d_fwd(xc, wp, bp, out, k, stats)
+    ops.conv3d_fwd(xc, wp, bp, out, k, stats, None, lay)
     torch.cuda.synchronize()
     got = from_cl(out, co)
     assert rel_err(got, ref) < 1e-4
@@ -117,9 +121,10 @@ def test_conv3d_backward(case):
     y.backward(gy)
     gc = to_cl(gy)
     # data gradient
-    wpd = ops.pack_conv_w(wt.detach().cuda(), None, cop, cip, 1)
+    lay = ops.conv_layout(k, cip, w)
+    wpd = ops.pack_conv_w(wt.detach().cuda(), None, cop, cip, 1, lay)
     gin = ops.CL(torch.empty(n, d, h, w, cip, device="cuda"), 0, cip)
-    ops.conv3d_fwd(gc, wpd, None, gin, k, None)
+    ops.conv3d_fwd(gc, wpd, None, gin, k, None, None, lay)
     # weight gradient
     ws = torch.empty(ops.conv3d_wgrad_ws((n, d, h, w), k, cip, cop), device="cuda")
     dw, db = ops.conv3d_wgrad(xc, gc, co, ci, k, None, ws, True)
