@@ -34,12 +34,15 @@ __device__ __forceinline__ size_t fine_vox(int64_t v, int D, int H, int W, int t
 
 // MODE 0: forward (A staged once, one store per tap).  MODE 1: data gradient (A gathered per tap
 // from the fine grid, accumulated over the 8 taps, one store).
+// The MFMA operands are swapped (weights as the row operand, voxels as the column operand) so that a
+// lane ends up with 4 CONSECUTIVE output channels of one voxel: the epilogue is one 16-byte store per
+// lane instead of four scattered dword stores.  `tps` taps' weights are staged per barrier pair.
 template <int NTT, int MODE>
-__global__ __launch_bounds__(256) void convt2_kernel(CtP p) {
+__global__ __launch_bounds__(256) void convt2_kernel(CtP p, int tps) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int AS = p.rin_p + 4;                       // LDS row stride (floats)
     float* sA = smem;                                 // [64][AS]
-    float* sW = smem + 64 * AS;                       // [rin_p/8][NTT][128]
+    float* sW = smem + 64 * AS;                       // [tps][rin_p/8][NTT][128]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = lane & 15, kq = lane >> 4;
     const int64_t v0 = (int64_t)blockIdx.x * 64;
@@ -47,21 +50,21 @@ __global__ __launch_bounds__(256) void convt2_kernel(CtP p) {
     const int nq = p.rin_p >> 2;                      // float4 per voxel
     const bool has_xf = p.in_scale != nullptr;
     const int wfl = ng * NTT * 128;
+    const int64_t vme = v0 + wave * 16 + m;           // this lane's voxel (column of the MFMA tile)
 
     f32x4 acc[NTT];
 #pragma unroll
     for (int nt = 0; nt < NTT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int tap = 0; tap < 8; ++tap) {
+    for (int tap0 = 0; tap0 < 8; tap0 += tps) {
         __syncthreads();
-        if (MODE == 1 || tap == 0) {
+        if (MODE == 0 && tap0 == 0) {
             for (int it = tid; it < 64 * nq; it += 256) {
                 const int vl = it / nq, qd = it % nq;
                 const int64_t v = v0 + vl;
                 float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (v < p.nvox) {
-                    const size_t src = (MODE == 0) ? (size_t)v : fine_vox(v, p.D, p.H, p.W, tap);
-                    val = *reinterpret_cast<const float4*>(p.in + src * p.in_cs + qd * 4);
+                    val = *reinterpret_cast<const float4*>(p.in + (size_t)v * p.in_cs + qd * 4);
                     if (has_xf) {
                         const float4 sc = *reinterpret_cast<const float4*>(p.in_scale + qd * 4);
                         const float4 sh = *reinterpret_cast<const float4*>(p.in_shift + qd * 4);
@@ -71,51 +74,67 @@ __global__ __launch_bounds__(256) void convt2_kernel(CtP p) {
                 *reinterpret_cast<float4*>(&sA[vl * AS + qd * 4]) = val;
             }
         }
-        const float* wsrc = p.wp + (size_t)tap * wfl;
-        for (int i = tid * 4; i < wfl; i += 1024)
-            *reinterpret_cast<float4*>(&sW[i]) = *reinterpret_cast<const float4*>(wsrc + i);
-        __syncthreads();
-        if (MODE == 0) {
-#pragma unroll
-            for (int nt = 0; nt < NTT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        {
+            const float* wsrc = p.wp + (size_t)tap0 * wfl;
+            const int tot = tps * wfl;
+            for (int i = tid * 4; i < tot; i += 1024)
+                *reinterpret_cast<float4*>(&sW[i]) = *reinterpret_cast<const float4*>(wsrc + i);
         }
-        const float* arow = &sA[(wave * 16 + m) * AS + kq * 2];
-        const float* brow = &sW[kq * 32 + m * 2];
-        for (int g = 0; g < ng; ++g) {
-            const float2 a = *reinterpret_cast<const float2*>(arow + g * 8);
+        if (MODE == 0) __syncthreads();
+        for (int tl = 0; tl < tps; ++tl) {
+            const int tap = tap0 + tl;
+            if (MODE == 1) {
+                // gather this tap's fine-grid voxels (the block's 64 coarse voxels) into sA
+                __syncthreads();
+                for (int it = tid; it < 64 * nq; it += 256) {
+                    const int vl = it / nq, qd = it % nq;
+                    const int64_t v = v0 + vl;
+                    float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (v < p.nvox)
+                        val = *reinterpret_cast<const float4*>(p.in + fine_vox(v, p.D, p.H, p.W, tap) * p.in_cs + qd * 4);
+                    *reinterpret_cast<float4*>(&sA[vl * AS + qd * 4]) = val;
+                }
+                __syncthreads();
+            } else {
 #pragma unroll
-            for (int nt = 0; nt < NTT; ++nt) {
-                const float2 b = *reinterpret_cast<const float2*>(brow + (g * NTT + nt) * 128);
-                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[nt], 0, 0, 0);
-                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[nt], 0, 0, 0);
+                for (int nt = 0; nt < NTT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-        }
-        if (MODE == 0) {
+            const float* arow = &sA[(wave * 16 + m) * AS + kq * 2];
+            const float* brow = &sW[tl * wfl + kq * 32 + m * 2];
+            for (int g = 0; g < ng; ++g) {
+                const float2 a = *reinterpret_cast<const float2*>(arow + g * 8);
 #pragma unroll
-            for (int nt = 0; nt < NTT; ++nt) {
-                const int co = nt * 16 + m;
-                if (co < p.nout_p) {
-                    const float bv = (p.bias && co < p.nbias) ? p.bias[co] : 0.f;
+                for (int nt = 0; nt < NTT; ++nt) {
+                    const float2 b = *reinterpret_cast<const float2*>(brow + (g * NTT + nt) * 128);
+                    // rows = output channels (weights), columns = voxels
+                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.x, a.x, acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.y, a.y, acc[nt], 0, 0, 0);
+                }
+            }
+            if (MODE == 0 && vme < p.nvox) {
+                float* orow = p.out + fine_vox(vme, p.D, p.H, p.W, tap) * p.out_cs;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int64_t v = v0 + wave * 16 + kq * 4 + r;
-                        if (v < p.nvox) p.out[fine_vox(v, p.D, p.H, p.W, tap) * p.out_cs + co] = acc[nt][r] + bv;
+                for (int nt = 0; nt < NTT; ++nt) {
+                    const int co = nt * 16 + kq * 4;            // this lane: channels co .. co+3 of voxel vme
+                    if (co < p.nout_p) {
+                        float4 o;
+                        o.x = acc[nt][0] + ((p.bias && co + 0 < p.nbias) ? p.bias[co + 0] : 0.f);
+                        o.y = acc[nt][1] + ((p.bias && co + 1 < p.nbias) ? p.bias[co + 1] : 0.f);
+                        o.z = acc[nt][2] + ((p.bias && co + 2 < p.nbias) ? p.bias[co + 2] : 0.f);
+                        o.w = acc[nt][3] + ((p.bias && co + 3 < p.nbias) ? p.bias[co + 3] : 0.f);
+                        *reinterpret_cast<float4*>(orow + co) = o;
                     }
                 }
             }
         }
     }
-    if (MODE == 1) {
+    if (MODE == 1 && vme < p.nvox) {
+        float* orow = p.out + (size_t)vme * p.out_cs;
 #pragma unroll
         for (int nt = 0; nt < NTT; ++nt) {
-            const int co = nt * 16 + m;
-            if (co < p.nout_p) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int64_t v = v0 + wave * 16 + kq * 4 + r;
-                    if (v < p.nvox) p.out[(size_t)v * p.out_cs + co] = acc[nt][r];
-                }
-            }
+            const int co = nt * 16 + kq * 4;
+            if (co < p.nout_p)
+                *reinterpret_cast<float4*>(orow + co) = make_float4(acc[nt][0], acc[nt][1], acc[nt][2], acc[nt][3]);
         }
     }
 }
@@ -217,26 +236,39 @@ __global__ __launch_bounds__(256) void convt2_wgrad_kernel(CtWgP p) {
             }
         }
     }
-    const size_t slab = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave;
-    float* dst = p.ws + slab * (8 * 256);
+    // 4 waves -> one slab [8][16 ci][16 co] per block, summed through sG (8192 floats = 4 waves x 8 x 256)
+    __syncthreads();
 #pragma unroll
     for (int t = 0; t < 8; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dst[t * 256 + (kq * 4 + r) * 16 + i] = acc[t][r];
+        for (int r = 0; r < 4; ++r) sG[(wave * 8 + t) * 256 + (kq * 4 + r) * 16 + i] = acc[t][r];
+    __syncthreads();
+    float* dst = p.ws + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (8 * 256);
+    for (int e = tid; e < 8 * 256; e += 256)
+        dst[e] = (sG[e] + sG[2048 + e]) + (sG[4096 + e] + sG[6144 + e]);
 }
 
-// dw[ci][co][tap]; one thread per (tap, ci, co) with co fastest
-__global__ void convt2_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Ci, int Co,
-                                           const int32_t* __restrict__ imap, int n_ci_t, int gx) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= Ci * Co * 8) return;
-    const int co = idx % Co, ci = (idx / Co) % Ci, tap = idx / (Co * Ci);
-    const int cip = imap ? imap[ci] : ci;      // logical -> padded position
-    const int pair = (co >> 4) * n_ci_t + (cip >> 4);
-    const float* src = ws + ((size_t)pair * gx * 4) * (8 * 256) + tap * 256 + (cip & 15) * 16 + (co & 15);
+// dw[ci][co][tap]: a block owns 64 consecutive outputs (co fastest) and sums the gx slabs of their
+// (ci-tile, co-tile) with 4 thread groups in a fixed order.
+__global__ __launch_bounds__(256) void convt2_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
+                                                                  int Ci, int Co, const int32_t* __restrict__ imap,
+                                                                  int n_ci_t, int gx) {
+    __shared__ float red[4][64];
+    const int e = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + e;
     float s = 0.f;
-    for (int k = 0; k < gx * 4; ++k) s += src[(size_t)k * (8 * 256)];
-    dw[((size_t)ci * Co + co) * 8 + tap] = s;
+    const bool ok = idx < Ci * Co * 8;
+    int co = 0, ci = 0, tap = 0;
+    if (ok) {
+        co = idx % Co; ci = (idx / Co) % Ci; tap = idx / (Co * Ci);
+        const int cip = imap ? imap[ci] : ci;      // logical -> padded position
+        const int pair = (co >> 4) * n_ci_t + (cip >> 4);
+        const float* src = ws + ((size_t)pair * gx) * (8 * 256) + tap * 256 + (cip & 15) * 16 + (co & 15);
+        for (int k = part; k < gx; k += 4) s += src[(size_t)k * (8 * 256)];
+    }
+    red[part][e] = s;
+    __syncthreads();
+    if (part == 0 && ok) dw[((size_t)ci * Co + co) * 8 + tap] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
 }
 
 inline int ct_wgrad_gx(int ntiles, int pairs) {
@@ -249,15 +281,20 @@ inline int ct_wgrad_gx(int ntiles, int pairs) {
 template <int MODE>
 int launch_convt(const CtP& p, hipStream_t st, const char* name) {
     const int ntt = pick_ntt(p.nout_p);
-    const size_t lds = ((size_t)64 * (p.rin_p + 4) + (size_t)(p.rin_p / 8) * ntt * 128) * sizeof(float);
+    const size_t a_b = (size_t)64 * (p.rin_p + 4) * sizeof(float);
+    const size_t w_b = (size_t)(p.rin_p / 8) * ntt * 128 * sizeof(float);      // one tap's packed weights
+    int tps = 8;                                                                // taps staged per barrier pair
+    while (tps > 1 && a_b + tps * w_b > 72 * 1024) tps >>= 1;
+    const size_t lds = a_b + tps * w_b;
     CTU_REQUIRE(lds <= 160 * 1024, "%s: rin_p=%d nout_p=%d needs %zu B of LDS", name, p.rin_p, p.nout_p, lds);
+    CTU_REQUIRE(p.out_cs % 4 == 0 && ((uintptr_t)p.out & 15) == 0, "%s: output must be 16-byte aligned", name);
     const unsigned grid = (unsigned)ceil_div64(p.nvox, 64);
 #define CT_LAUNCH(N_)                                                                                             \
     do {                                                                                                          \
         if (lds > 64 * 1024)                                                                                      \
             (void)hipFuncSetAttribute((const void*)convt2_kernel<N_, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                       (int)lds);                                                                  \
-        convt2_kernel<N_, MODE><<<grid, 256, lds, st>>>(p);                                                       \
+        convt2_kernel<N_, MODE><<<grid, 256, lds, st>>>(p, tps);                                                  \
     } while (0)
     switch (ntt) {
         case 1: CT_LAUNCH(1); break;
@@ -323,7 +360,7 @@ extern "C" size_t ctu_convt2_wgrad_ws_floats(int N, int D, int H, int W, int cin
     const int64_t nvox = (int64_t)N * D * H * W;
     const int ntiles = (int)ceil_div64(nvox, 64);
     const int pairs = ceil_div(cin_p, 16) * ceil_div(cout_p, 16);
-    const size_t slabs = (size_t)pairs * ct_wgrad_gx(ntiles, pairs) * 4 * 8 * 256;
+    const size_t slabs = (size_t)pairs * ct_wgrad_gx(ntiles, pairs) * 8 * 256;
     const size_t bsum = (size_t)ctu_channel_sum_num_blocks(nvox * 8) * cout_p;
     return slabs > bsum ? slabs : bsum;
 }
@@ -345,7 +382,7 @@ extern "C" int ctu_convt2_wgrad(const float* in, int in_cs, int cin_p, const flo
     const int gx = ct_wgrad_gx(p.ntiles, pairs);
     convt2_wgrad_kernel<<<dim3(gx, pairs), 256, 0, st>>>(p);
     CTU_CHECK_LAUNCH("convt2_wgrad");
-    convt2_wgrad_reduce_kernel<<<ceil_div(Ci * Co * 8, 256), 256, 0, st>>>(ws, dw, Ci, Co, imap, p.n_ci_t, gx);
+    convt2_wgrad_reduce_kernel<<<ceil_div(Ci * Co * 8, 64), 256, 0, st>>>(ws, dw, Ci, Co, imap, p.n_ci_t, gx);
     CTU_CHECK_LAUNCH("convt2_wgrad_reduce");
     if (dbias) return ctu_channel_sum(gout, g_cs, cout_p, p.nvox * 8, ws, dbias, Co, stream);
     return CTU_OK;
