@@ -212,6 +212,40 @@ def test_gradients_against_fp64_oracle(name):
         assert err(got, r64) <= max(5 * err(c32, r64), 2e-3 * scale) + 1e-7, (n_, err(got, r64), err(c32, r64), scale)
 
 
+def test_graphed_step_equals_eager_step():
+    """The HIP-graph replay of a train step (graph.GraphedTrainStep) updates parameters, BN buffers and
+    reports losses exactly like the eagerly launched step."""
+    A, M, L, PH = _mods()
+    from ctunet_amd.graph import GraphedTrainStep
+    x = torch.randn(1, 2, 32, 32, 32, generator=gen(3)).cuda()
+    tg = [onehot_target((1, 2, 32, 32, 32), 11 + i, 0.2).cuda() for i in range(2)]
+
+    def make():
+        torch.manual_seed(0)
+        net = A.UNetSP().cuda().train()
+        opt = torch.optim.Adam(net.parameters(), lr=1e-3, amsgrad=True, capturable=True)
+        return net, opt
+    net_e, opt_e = make()
+    losses_e = []
+    for _ in range(3 + 2):                      # GraphedTrainStep runs 3 warm-up + 1 capture... replay twice below
+        h = Holder(1.0, 1.0)
+        out = net_e(x.clone().requires_grad_(True))
+        PH.FlapRecWithShapePriorDoubleOut.comp_losses_metrics(h, out, tg, 0, 1)
+        h.pt_loss.backward()
+        opt_e.step()
+        for p in net_e.parameters():
+            p.grad = None
+        losses_e.append(h.pt_loss.item())
+    net_g, opt_g = make()
+    gs = GraphedTrainStep(net_g, opt_g, x, tg, 1.0, 1.0, warmup=3)      # 3 eager warm-up steps; capture itself does not execute
+    assert gs.keys == ["ce_sk", "ce_fl", "dice_loss_sk", "dice_loss_fl", "epoch_loss"]
+    l3 = gs(x, tg).tolist()[-1]
+    l4 = gs(x, tg).tolist()[-1]
+    assert abs(l3 - losses_e[3]) < 1e-5 and abs(l4 - losses_e[4]) < 1e-5
+    for (n_, a), (_, b) in zip(net_e.state_dict().items(), net_g.state_dict().items()):
+        assert torch.allclose(a.float(), b.float(), rtol=1e-4, atol=1e-6), n_
+
+
 def test_full_size_properties_128():
     """BASELINE size (128^3, UNet default): size-independent properties instead of a CPU re-run --
     determinism (bitwise), batch independence in eval mode, zero grads for the dead centre block."""
