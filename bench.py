@@ -70,6 +70,18 @@ def host_cores():
     return n
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+    (profiles/r01_hbm_traffic.json, produced by scripts/collect_traffic.py with the guide's gfx950 corrections);
+    None when no PMC run covers this kernel."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:
+            k = json.load(f)["kernels"].get(kernel.split(" (")[0])
+        return None if k is None else round(k["hbm_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def cpu_baseline(size, steps=2):
     """The oracle (same ATen-CPU graph as the reference, no checkpoint recompute) timed on the host
     cores: 1 warm-up + best of `steps` forward+backward steps of the same 128^3 workload."""
@@ -209,7 +221,9 @@ def main():
             dom = max(summ.items(), key=lambda kv: kv[1]["total_ms"])
             ach = dom[1]["flops"] / (dom[1]["total_ms"] * 1e-3) / 1e12
             roofline = {"kernel": dom[0], "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                        "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+                        "traffic": pmc_traffic(dom[0]),
+                        "algorithmic_mb_per_launch": round(dom[1]["bytes"] / dom[1]["launches"] / 1e6, 1),
                         "avg_launch_ms": round(dom[1]["avg_ms"], 4),
                         "measured": ("HIP events around each launch, " +
                                      ("inside the timed region" if mode == "eager" else

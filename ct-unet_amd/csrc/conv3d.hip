@@ -1015,6 +1015,28 @@ extern "C" int ctu_conv3d_layout(int k, int nout_p, int W) {
     return (k == 3 && nout_p == 8 && W >= 32) ? 1 : 0;
 }
 
+extern "C" const char* ctu_conv3d_fwd_kernel_name(int N, int D, int H, int W, int k, int nout_p, int layout) {
+    static thread_local char buf[64];
+    if (layout == 1) return "conv3d_fwd_k3_pair8";
+    int nt, td, th, tw;
+    pick_launch(N, D, H, W, nout_p, &nt, &td, &th, &tw);
+    if (k == 3 && tw == 16 && nt <= 2) snprintf(buf, sizeof(buf), "conv3d_fwd_k3_persist<%d>", nt);
+    else snprintf(buf, sizeof(buf), "conv3d_fwd_kernel<%d, %d, %d, %d, %d>", k, nt, td, th, tw);
+    return buf;
+}
+
+extern "C" const char* ctu_conv3d_wgrad_kernel_name(int W, int k, int cin_p, int cout_p) {
+    static thread_local char buf[64];
+    if (k == 3 && W >= 16 && (cin_p == 8 || cout_p == 8))
+        snprintf(buf, sizeof(buf), "conv3d_wgrad_k3s_kernel<%d, %d>", cin_p == 8 ? 2 : 1, cout_p == 8 ? 2 : 1);
+    else {
+        int td, th, tw;
+        pick_tile(W, &td, &th, &tw);
+        snprintf(buf, sizeof(buf), "conv3d_wgrad_kernel<%d, %d, %d, %d, %d>", k, k == 3 ? 3 : 1, td, th, tw);
+    }
+    return buf;
+}
+
 extern "C" size_t ctu_conv3d_packed_floats(int k, int rin_p, int nout_p, int layout) {
     if ((k != 3 && k != 5) || rin_p <= 0 || nout_p <= 0) return 0;
     if (layout == 1) return (k == 3 && nout_p == 8) ? (size_t)(rin_p / 8) * 36 * 128 : 0;

@@ -27,6 +27,8 @@ SIGNATURES = {
     "ctu_ncdhw_to_ndhwc": (I, [P, P, I, I, I, I, I, I, I, P]),
     "ctu_ndhwc_to_ncdhw": (I, [P, P, I, I, I, I, I, I, P]),
     "ctu_conv3d_layout": (I, [I, I, I]),
+    "ctu_conv3d_fwd_kernel_name": (C.c_char_p, [I, I, I, I, I, I, I]),
+    "ctu_conv3d_wgrad_kernel_name": (C.c_char_p, [I, I, I, I]),
     "ctu_conv3d_packed_floats": (Z, [I, I, I, I]),
     "ctu_conv3d_num_blocks": (I, [I, I, I, I, I, I]),
     "ctu_pack_conv3d_weight": (I, [P, P, I, I, I, P, I, I, I, I, P]),

@@ -192,7 +192,7 @@ def conv3d_fwd(x: CL, wp: torch.Tensor, bias: Optional[torch.Tensor], out: CL, k
     if t0 is not None:
         ci, co = algo_ch if algo_ch is not None else (x.cp, out.cp)
         vox = n * d * h * w
-        TIMER.end(f"conv3d_fwd_kernel<k{k}>", 2.0 * ci * co * k ** 3 * vox,
+        TIMER.end(lib.ctu_conv3d_fwd_kernel_name(n, d, h, w, k, out.cp, layout).decode(), 2.0 * ci * co * k ** 3 * vox,
                   4.0 * vox * (ci + co), t0)
 
 
@@ -210,7 +210,8 @@ def conv3d_wgrad(x: CL, g: CL, co: int, ci: int, k: int, cinv: Optional[torch.Te
                                     _stream()), "conv3d_wgrad")
     if t0 is not None:
         vox = n * d * h * w
-        TIMER.end(f"conv3d_wgrad<k{k}>(+reduce)", 2.0 * ci * co * k ** 3 * vox, 4.0 * vox * (ci + co), t0)
+        TIMER.end(lib.ctu_conv3d_wgrad_kernel_name(w, k, x.cp, g.cp).decode() + " (+slab reduce)",
+                  2.0 * ci * co * k ** 3 * vox, 4.0 * vox * (ci + co), t0)
     return dw, db
 
 

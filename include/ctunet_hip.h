@@ -63,6 +63,10 @@ int ctu_ndhwc_to_ncdhw(const float* src, float* dst, int N, int C, int D, int H,
  * Geometry helpers: packed-weight size (floats) and number of spatial blocks (= rows of the
  * stats-partials buffer) of a conv call. */
 int ctu_conv3d_layout(int k, int nout_p, int W);
+/* Name of the device kernel a ctu_conv3d_fwd / ctu_conv3d_wgrad call with this geometry launches (as it
+ * appears in a rocprofv3 kernel trace; thread-local string) -- used to match timings with profiles. */
+const char* ctu_conv3d_fwd_kernel_name(int N, int D, int H, int W, int k, int nout_p, int layout);
+const char* ctu_conv3d_wgrad_kernel_name(int W, int k, int cin_p, int cout_p);
 size_t ctu_conv3d_packed_floats(int k, int rin_p, int nout_p, int layout);
 int ctu_conv3d_num_blocks(int N, int D, int H, int W, int nout_p, int layout);
 
