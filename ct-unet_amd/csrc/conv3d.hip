@@ -217,20 +217,28 @@ __global__ __launch_bounds__(256) void conv3d_fwd_kernel(ConvP p) {
 }
 
 
-// ------------------------------------------------------------------ persistent k=3 kernel
+// ------------------------------------------------------------------ persistent k=3 kernels (large layers)
 // Same GEMM view and LDS images as conv3d_fwd_kernel, restructured for the large layers:
-//  * a block walks a CONTIGUOUS range of voxel boxes (neighbouring boxes share halos in L1/L2),
+//  * a block walks a CONTIGUOUS range of voxel boxes; per-thread halo offsets are computed once per block,
 //  * the next (box, chunk) stage's input and weights are prefetched into registers while the current
-//    stage's 27 taps run on the matrix cores; one LDS image, two barriers per stage,
-//  * layers with a single 8-channel chunk (C_in <= 8) stage their weights once per block.
-template <int NT>
+//    stage's taps run on the matrix cores; one LDS image, two barriers per stage,
+//  * layers with a single 8-channel chunk (C_in <= 8) stage their weights once per block,
+//  * MFMA operands are swapped (weights = row operand): a lane ends with 4 consecutive output channels of
+//    one voxel -> one 16-byte store per lane per tile,
+//  * BatchNorm partial sums live in registers across all boxes of the block: ONE stats row per block.
+// PAIR = false: N = 16*NT output channels, box 4x4x16.
+// PAIR = true : C_out = 8, N = (w-shift s, co), M = voxel pairs, 36 taps, box 4x4x32 (NT must be 1):
+//   out[(d,h,2m+s), co] = sum in[(d+kd, h+kh, 2m+kw') - pad][ci] * Wp[kd,kh,kw'][ci][(s,co)],
+//   Wp[..kw'][ci][(s,co)] = W[..kw'-s][ci][co] for 0 <= kw'-s <= 2, else 0  -> 1.5x fewer MFMAs than padding N.
+template <int NT, bool PAIR>
 __global__ __launch_bounds__(256) void conv3d_fwd_k3_persist(ConvP p, int ntiles, int tiles_per_block) {
-    constexpr int PAD = 1, TD = 4, TH = 4, TW = 16;
+    constexpr int TD = 4, TH = 4, TW = PAIR ? 32 : 16;
     constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2, HV = HD * HH * HW;
-    constexpr int MT = 4;
-    constexpr int WFL = 27 * NT * 128;
+    constexpr int MT = 4, NTAP = PAIR ? 36 : 27, KWN = PAIR ? 4 : 3;
+    constexpr int WFL = NTAP * NT * 128;
     constexpr int AITEMS = HV * 2, AITER = (AITEMS + 255) / 256;
     constexpr int WITER = (WFL / 4 + 255) / 256;
+    static_assert(!PAIR || NT == 1, "pair layout has a single N tile");
 
     __shared__ __attribute__((aligned(16))) float sA[HV * VS];
     __shared__ __attribute__((aligned(16))) float sW[WFL];
@@ -247,14 +255,30 @@ __global__ __launch_bounds__(256) void conv3d_fwd_k3_persist(ConvP p, int ntiles
 
     int abase[MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) abase[mt] = ((wave * HH + mt) * HW + m) * VS + kq * 2;   // td = wave, th = mt, tw = m
+    for (int mt = 0; mt < MT; ++mt) abase[mt] = ((wave * HH + mt) * HW + (PAIR ? 2 * m : m)) * VS + kq * 2;   // td = wave, th = mt
     const int bbase = kq * 32 + m * 2;
 
+    // per-thread staging items: halo coordinates (packed) and the offset relative to the box origin
+    int hoff[AITER];
+    unsigned hpos[AITER];
+#pragma unroll
+    for (int it = 0; it < AITER; ++it) {
+        const int i = tid + it * 256;
+        const int v = (i < AITEMS) ? (i >> 1) : 0;
+        const int pw = v % HW, t2 = v / HW, ph = t2 % HH, pd = t2 / HH;
+        hpos[it] = (unsigned)pd | ((unsigned)ph << 8) | ((unsigned)pw << 16);
+        hoff[it] = (((pd - 1) * p.H + (ph - 1)) * p.W + (pw - 1)) * p.in_cs + half * 4;
+    }
+
     f32x4 acc[MT][NT];
+    float s1[NT][4], s2[NT][4];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s1[nt][r] = 0.f; s2[nt][r] = 0.f; }
+    }
 
     int tile = blockIdx.x * tiles_per_block;
     const int tile_end = min(ntiles, tile + tiles_per_block);
@@ -278,25 +302,28 @@ __global__ __launch_bounds__(256) void conv3d_fwd_k3_persist(ConvP p, int ntiles
             sc = *reinterpret_cast<const float4*>(p.in_scale + cc * 8 + half * 4);
             sh = *reinterpret_cast<const float4*>(p.in_shift + cc * 8 + half * 4);
         }
+        const float* base = p.in + ((((size_t)n_img * p.D + d0) * p.H + h0) * p.W + w0) * p.in_cs + cc * 8;
+        const bool interior = d0 >= 1 && h0 >= 1 && w0 >= 1 && d0 + TD < p.D && h0 + TH < p.H && w0 + TW < p.W;
         vmask = 0;
 #pragma unroll
         for (int it = 0; it < AITER; ++it) {
             const int i = tid + it * 256;
-            const int v = i >> 1;
-            const int pw = v % HW, t2 = v / HW, ph = t2 % HH, pd = t2 / HH;
-            const int gd = d0 + pd - PAD, gh = h0 + ph - PAD, gw = w0 + pw - PAD;
+            bool ok = i < AITEMS;
+            if (!interior) {
+                const int gd = d0 + (int)(hpos[it] & 255u) - 1, gh = h0 + (int)((hpos[it] >> 8) & 255u) - 1,
+                          gw = w0 + (int)(hpos[it] >> 16) - 1;
+                ok = ok && (unsigned)gd < (unsigned)p.D && (unsigned)gh < (unsigned)p.H && (unsigned)gw < (unsigned)p.W;
+            }
             float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < AITEMS && (unsigned)gd < (unsigned)p.D && (unsigned)gh < (unsigned)p.H &&
-                (unsigned)gw < (unsigned)p.W) {
-                const size_t vox = (((size_t)n_img * p.D + gd) * p.H + gh) * p.W + gw;
-                val = *reinterpret_cast<const float4*>(p.in + vox * p.in_cs + cc * 8 + half * 4);
+            if (ok) {
+                val = *reinterpret_cast<const float4*>(base + hoff[it]);
                 vmask |= 1u << it;
             }
             va[it] = val;
         }
     };
     auto load_w = [&](int cc) {
-        const float* wsrc = p.wp + (size_t)cc * 27 * n16 * 128 + (size_t)by * NT * 128;
+        const float* wsrc = p.wp + (size_t)cc * NTAP * n16 * 128 + (size_t)by * NT * 128;
 #pragma unroll
         for (int it = 0; it < WITER; ++it) {
             const int i = (tid + it * 256) * 4;
@@ -339,10 +366,10 @@ __global__ __launch_bounds__(256) void conv3d_fwd_k3_persist(ConvP p, int ntiles
             load_a(ntile, nc);
             if (!hoist_w) load_w(nc);
         }
-        // ---- 27 taps on the matrix cores
+        // ---- taps on the matrix cores: rows = output channels, columns = voxels (or voxel pairs)
 #pragma unroll
-        for (int ts = 0; ts < 27; ++ts) {
-            const int kd = ts / 9, kh = (ts / 3) % 3, kw = ts % 3;
+        for (int ts = 0; ts < NTAP; ++ts) {
+            const int kd = ts / (3 * KWN), kh = (ts / KWN) % 3, kw = ts % KWN;
             const int toff = ((kd * HH + kh) * HW + kw) * VS;
             float2 b[NT], a[MT];
 #pragma unroll
@@ -353,237 +380,80 @@ __global__ __launch_bounds__(256) void conv3d_fwd_k3_persist(ConvP p, int ntiles
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].x, b[nt].x, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[nt].x, a[mt].x, acc[mt][nt], 0, 0, 0);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].y, b[nt].y, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[nt].y, a[mt].y, acc[mt][nt], 0, 0, 0);
         }
         if (c == nchunk - 1) {
-            // ---- epilogue of this box: bias, store, BatchNorm partial statistics
+            // ---- epilogue of this box: bias, one float4 store per lane and (mt, nt), BN partial sums
             int n_img, d0, h0, w0;
             tile_origin(tile, n_img, d0, h0, w0);
-            float s1[NT], s2[NT];
+            const int gd = d0 + wave;
+            const int gw = PAIR ? (w0 + 2 * m + (kq >> 1)) : (w0 + m);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                s1[nt] = 0.f; s2[nt] = 0.f;
-                const int co = (by * NT + nt) * 16 + m;
+                const int co = PAIR ? (kq & 1) * 4 : (by * NT + nt) * 16 + kq * 4;
                 const bool cok = co < p.nout_p;
-                const float bv = (p.bias && co < p.nbias) ? p.bias[co] : 0.f;
+                float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.bias) {
+                    bv.x = co + 0 < p.nbias ? p.bias[co + 0] : 0.f; bv.y = co + 1 < p.nbias ? p.bias[co + 1] : 0.f;
+                    bv.z = co + 2 < p.nbias ? p.bias[co + 2] : 0.f; bv.w = co + 3 < p.nbias ? p.bias[co + 3] : 0.f;
+                }
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
-                    const int gd = d0 + wave, gh = h0 + mt;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int gw = w0 + kq * 4 + r;
-                        if (cok && gd < p.D && gh < p.H && gw < p.W) {
-                            const float v = acc[mt][nt][r] + bv;
-                            const size_t vox = (((size_t)n_img * p.D + gd) * p.H + gh) * p.W + gw;
-                            p.out[vox * p.out_cs + co] = v;
-                            s1[nt] += v;
-                            s2[nt] += v * v;
-                        }
+                    const int gh = h0 + mt;
+                    if (cok && gd < p.D && gh < p.H && gw < p.W) {
+                        float4 o;
+                        o.x = acc[mt][nt][0] + bv.x; o.y = acc[mt][nt][1] + bv.y;
+                        o.z = acc[mt][nt][2] + bv.z; o.w = acc[mt][nt][3] + bv.w;
+                        const size_t vox = (((size_t)n_img * p.D + gd) * p.H + gh) * p.W + gw;
+                        *reinterpret_cast<float4*>(p.out + vox * p.out_cs + co) = o;
+                        s1[nt][0] += o.x; s1[nt][1] += o.y; s1[nt][2] += o.z; s1[nt][3] += o.w;
+                        s2[nt][0] += o.x * o.x; s2[nt][1] += o.y * o.y; s2[nt][2] += o.z * o.z; s2[nt][3] += o.w * o.w;
                     }
                     acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-            }
-            if (p.stats) {
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    float a1 = s1[nt], a2 = s2[nt];
-                    a1 += __shfl_xor(a1, 16); a1 += __shfl_xor(a1, 32);
-                    a2 += __shfl_xor(a2, 16); a2 += __shfl_xor(a2, 32);
-                    if (kq == 0) {
-                        sRed[((wave * NT + nt) * 16 + m) * 2 + 0] = a1;
-                        sRed[((wave * NT + nt) * 16 + m) * 2 + 1] = a2;
-                    }
-                }
-                __syncthreads();
-                if (tid < NT * 16) {
-                    const int co = by * NT * 16 + tid;
-                    if (co < p.nout_p) {
-                        float a1 = 0.f, a2 = 0.f;
-#pragma unroll
-                        for (int w = 0; w < 4; ++w) {
-                            a1 += sRed[((w * NT) * 16 + tid) * 2 + 0];
-                            a2 += sRed[((w * NT) * 16 + tid) * 2 + 1];
-                        }
-                        float* row = p.stats + (size_t)tile * 2 * p.nout_p;
-                        row[co] = a1;
-                        row[p.nout_p + co] = a2;
-                    }
                 }
             }
         }
         if (!has_next) break;
         tile = ntile; c = nc;
     }
-}
-
-// ------------------------------------------------------------------ persistent k=3 kernel, C_out = 8 ("pair" layout)
-// With 8 output channels a 16-wide MFMA N tile would be half padding.  Here N = (s, co), s in {0,1} a shift
-// along w, and M = 16 voxel PAIRS (w = 2m, 2m+1):
-//   out[(d,h,2m+s), co] = sum_{kd,kh,kw',ci} in[(d+kd, h+kh, 2m+kw') - pad][ci] * Wp[kd,kh,kw'][ci][(s,co)],
-//   Wp[.., kw'][ci][(s,co)] = W[.., kw'-s][ci][co] for 0 <= kw'-s <= 2, else 0        (kw' = 0..3)
-// 36 taps over half as many M-tiles: 1.5x fewer MFMAs than padding N.  Box = 4x4x32 voxels per block.
-__global__ __launch_bounds__(256) void conv3d_fwd_k3_pair8(ConvP p, int ntiles, int tiles_per_block) {
-    constexpr int PAD = 1, TD = 4, TH = 4, TW = 32;
-    constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2, HV = HD * HH * HW;
-    constexpr int MT = 4, NTAP = 36;
-    constexpr int WFL = NTAP * 128;
-    constexpr int AITEMS = HV * 2, AITER = (AITEMS + 255) / 256;
-    constexpr int WITER = (WFL / 4 + 255) / 256;
-
-    __shared__ __attribute__((aligned(16))) float sA[HV * VS];
-    __shared__ __attribute__((aligned(16))) float sW[WFL];
-    __shared__ float sRed[4 * 16 * 2];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m = lane & 15, kq = lane >> 4;
-    const int nchunk = p.rin_p >> 3;
-    const bool hoist_w = nchunk == 1;
-    const int half = tid & 1;
-    const bool has_xf = p.in_scale != nullptr;
-
-    int abase[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) abase[mt] = ((wave * HH + mt) * HW + 2 * m) * VS + kq * 2;   // td = wave, th = mt
-    const int bbase = kq * 32 + m * 2;
-
-    f32x4 acc[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    int tile = blockIdx.x * tiles_per_block;
-    const int tile_end = min(ntiles, tile + tiles_per_block);
-    if (tile >= tile_end) return;
-    int c = 0;
-
-    float4 va[AITER], vw[WITER];
-    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-    unsigned vmask = 0;
-
-    auto tile_origin = [&](int t, int& n_img, int& d0, int& h0, int& w0) {
-        const int tx = t % p.tiles_w; t /= p.tiles_w;
-        const int ty = t % p.tiles_h; t /= p.tiles_h;
-        const int tz = t % p.tiles_d; t /= p.tiles_d;
-        n_img = t; d0 = tz * TD; h0 = ty * TH; w0 = tx * TW;
-    };
-    auto load_a = [&](int t, int cc) {
-        int n_img, d0, h0, w0;
-        tile_origin(t, n_img, d0, h0, w0);
-        if (has_xf) {
-            sc = *reinterpret_cast<const float4*>(p.in_scale + cc * 8 + half * 4);
-            sh = *reinterpret_cast<const float4*>(p.in_shift + cc * 8 + half * 4);
-        }
-        vmask = 0;
-#pragma unroll
-        for (int it = 0; it < AITER; ++it) {
-            const int i = tid + it * 256;
-            const int v = i >> 1;
-            const int pw = v % HW, t2 = v / HW, ph = t2 % HH, pd = t2 / HH;
-            const int gd = d0 + pd - PAD, gh = h0 + ph - PAD, gw = w0 + pw - PAD;
-            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < AITEMS && (unsigned)gd < (unsigned)p.D && (unsigned)gh < (unsigned)p.H &&
-                (unsigned)gw < (unsigned)p.W) {
-                const size_t vox = (((size_t)n_img * p.D + gd) * p.H + gh) * p.W + gw;
-                val = *reinterpret_cast<const float4*>(p.in + vox * p.in_cs + cc * 8 + half * 4);
-                vmask |= 1u << it;
-            }
-            va[it] = val;
-        }
-    };
-    auto load_w = [&](int cc) {
-        const float* wsrc = p.wp + (size_t)cc * WFL;
-#pragma unroll
-        for (int it = 0; it < WITER; ++it) {
-            const int i = (tid + it * 256) * 4;
-            vw[it] = (i < WFL) ? *reinterpret_cast<const float4*>(wsrc + i) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    auto store_w = [&]() {
-#pragma unroll
-        for (int it = 0; it < WITER; ++it) {
-            const int i = (tid + it * 256) * 4;
-            if (i < WFL) *reinterpret_cast<float4*>(&sW[i]) = vw[it];
-        }
-    };
-
-    load_a(tile, 0);
-    load_w(0);
-    if (hoist_w) store_w();
-
-    while (true) {
+    // ---- one BatchNorm partial row per block: reduce over the 16 voxel lanes, (pair: the two shifts,) the 4 waves
+    if (p.stats) {
         __syncthreads();
 #pragma unroll
-        for (int it = 0; it < AITER; ++it) {
-            const int i = tid + it * 256;
-            float4 val = va[it];
-            if (has_xf && ((vmask >> it) & 1u)) val = xform4(val, sc, sh, p.in_relu);
-            if (i < AITEMS) *reinterpret_cast<float4*>(&sA[(i >> 1) * VS + half * 4]) = val;
-        }
-        if (!hoist_w) store_w();
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float a1 = s1[nt][r], a2 = s2[nt][r];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { a1 += __shfl_xor(a1, o); a2 += __shfl_xor(a2, o); }
+                if (PAIR) { a1 += __shfl_xor(a1, 32); a2 += __shfl_xor(a2, 32); }
+                const int ch = PAIR ? (kq & 1) * 4 + r : nt * 16 + kq * 4 + r;      // channel inside this block's N range
+                if (m == 0 && (!PAIR || kq < 2)) {
+                    sRed[(wave * NT * 16 + ch) * 2 + 0] = a1;
+                    sRed[(wave * NT * 16 + ch) * 2 + 1] = a2;
+                }
+            }
         __syncthreads();
-        int ntile = tile, nc = c + 1;
-        if (nc == nchunk) { nc = 0; ntile = tile + 1; }
-        const bool has_next = ntile < tile_end;
-        if (has_next) {
-            load_a(ntile, nc);
-            if (!hoist_w) load_w(nc);
-        }
+        const int nch = PAIR ? 8 : NT * 16;
+        if (tid < nch) {
+            const int co = (PAIR ? 0 : by * NT * 16) + tid;
+            if (co < p.nout_p) {
+                float a1 = 0.f, a2 = 0.f;
 #pragma unroll
-        for (int ts = 0; ts < NTAP; ++ts) {
-            const int kd = ts / 12, kh = (ts / 4) % 3, kw = ts % 4;
-            const int toff = ((kd * HH + kh) * HW + kw) * VS;
-            const float2 b = *reinterpret_cast<const float2*>(&sW[ts * 128 + bbase]);
-            float2 a[MT];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const float2*>(&sA[abase[mt] + toff]);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].x, b.x, acc[mt], 0, 0, 0);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].y, b.y, acc[mt], 0, 0, 0);
-        }
-        if (c == nchunk - 1) {
-            int n_img, d0, h0, w0;
-            tile_origin(tile, n_img, d0, h0, w0);
-            const int co = m & 7, s = m >> 3;
-            const float bv = (p.bias && co < p.nbias) ? p.bias[co] : 0.f;
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int gd = d0 + wave, gh = h0 + mt;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int gw = w0 + 2 * (kq * 4 + r) + s;
-                    if (gd < p.D && gh < p.H && gw < p.W) {
-                        const float v = acc[mt][r] + bv;
-                        const size_t vox = (((size_t)n_img * p.D + gd) * p.H + gh) * p.W + gw;
-                        p.out[vox * p.out_cs + co] = v;
-                        s1 += v;
-                        s2 += v * v;
-                    }
+                for (int w = 0; w < 4; ++w) {
+                    a1 += sRed[(w * NT * 16 + tid) * 2 + 0];
+                    a2 += sRed[(w * NT * 16 + tid) * 2 + 1];
                 }
-                acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-            if (p.stats) {
-                s1 += __shfl_xor(s1, 8); s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
-                s2 += __shfl_xor(s2, 8); s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
-                if (lane < 8) { sRed[(wave * 8 + lane) * 2] = s1; sRed[(wave * 8 + lane) * 2 + 1] = s2; }
-                __syncthreads();
-                if (tid < 8) {
-                    float a1 = 0.f, a2 = 0.f;
-#pragma unroll
-                    for (int w = 0; w < 4; ++w) { a1 += sRed[(w * 8 + tid) * 2]; a2 += sRed[(w * 8 + tid) * 2 + 1]; }
-                    float* row = p.stats + (size_t)tile * 2 * p.nout_p;
-                    row[tid] = a1;
-                    row[p.nout_p + tid] = a2;
-                }
+                float* row = p.stats + (size_t)blockIdx.x * 2 * p.nout_p;
+                row[co] = a1;
+                row[p.nout_p + co] = a2;
             }
         }
-        if (!has_next) break;
-        tile = ntile; c = nc;
     }
 }
 
@@ -1017,10 +887,10 @@ extern "C" int ctu_conv3d_layout(int k, int nout_p, int W) {
 
 extern "C" const char* ctu_conv3d_fwd_kernel_name(int N, int D, int H, int W, int k, int nout_p, int layout) {
     static thread_local char buf[64];
-    if (layout == 1) return "conv3d_fwd_k3_pair8";
+    if (layout == 1) return "conv3d_fwd_k3_persist<1, true>";
     int nt, td, th, tw;
     pick_launch(N, D, H, W, nout_p, &nt, &td, &th, &tw);
-    if (k == 3 && tw == 16 && nt <= 2) snprintf(buf, sizeof(buf), "conv3d_fwd_k3_persist<%d>", nt);
+    if (k == 3 && tw == 16 && nt <= 2) snprintf(buf, sizeof(buf), "conv3d_fwd_k3_persist<%d, false>", nt);
     else snprintf(buf, sizeof(buf), "conv3d_fwd_kernel<%d, %d, %d, %d, %d>", k, nt, td, th, tw);
     return buf;
 }
@@ -1043,11 +913,32 @@ extern "C" size_t ctu_conv3d_packed_floats(int k, int rin_p, int nout_p, int lay
     return (size_t)(rin_p / 8) * k * k * k * ceil_div(nout_p, 16) * 128;
 }
 
-extern "C" int ctu_conv3d_num_blocks(int N, int D, int H, int W, int nout_p, int layout) {
-    if (layout == 1) return N * ceil_div(D, 4) * ceil_div(H, 4) * ceil_div(W, 32);
+// grid of the persistent kernels: boxes per block and blocks in x
+static void persist_grid(int ntiles, int ny, int blocks_per_cu, int* gx, int* tpb) {
+    int g = (256 * blocks_per_cu) / ny;
+    if (g < 1) g = 1;
+    if (g > ntiles) g = ntiles;
+    *tpb = ceil_div(ntiles, g);
+    *gx = ceil_div(ntiles, *tpb);
+}
+
+// k == 3 volumes wide enough for the 4x4x16 box with at most 2 N-tiles per block use the persistent kernel
+static bool use_persist(int k, int nt, int tw) { return k == 3 && tw == 16 && nt <= 2; }
+
+extern "C" int ctu_conv3d_num_blocks(int N, int D, int H, int W, int k, int nout_p, int layout) {
+    int gx, tpb;
+    if (layout == 1) {
+        persist_grid(N * ceil_div(D, 4) * ceil_div(H, 4) * ceil_div(W, 32), 1, 2, &gx, &tpb);
+        return gx;                                   // the persistent kernels write ONE stats row per block
+    }
     int nt, td, th, tw;
     pick_launch(N, D, H, W, nout_p, &nt, &td, &th, &tw);
-    return N * ceil_div(D, td) * ceil_div(H, th) * ceil_div(W, tw);
+    const int ntiles = N * ceil_div(D, td) * ceil_div(H, th) * ceil_div(W, tw);
+    if (use_persist(k, nt, tw)) {
+        persist_grid(ntiles, ceil_div(ceil_div(nout_p, 16), nt), nt == 1 ? 3 : 2, &gx, &tpb);
+        return gx;
+    }
+    return ntiles;
 }
 
 extern "C" int ctu_pack_conv3d_weight(const float* w, float* wp, int Co, int Ci, int k, const int32_t* cinv,
@@ -1094,8 +985,10 @@ extern "C" int ctu_conv3d_fwd(const float* in, int in_cs, int rin_p, const float
     CTU_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0, "conv3d_fwd: empty volume %dx%dx%dx%d", N, D, H, W);
     CTU_REQUIRE(rin_p > 0 && rin_p % 8 == 0 && nout_p > 0 && nout_p % 8 == 0,
                 "conv3d_fwd: channel counts must be positive multiples of 8 (rin_p=%d nout_p=%d)", rin_p, nout_p);
-    CTU_REQUIRE(in_cs >= rin_p && in_cs % 4 == 0 && out_cs >= nout_p, "conv3d_fwd: bad channel stride");
-    CTU_REQUIRE(((uintptr_t)in & 15) == 0 && ((uintptr_t)wp & 15) == 0, "conv3d_fwd: in/wp must be 16-byte aligned");
+    CTU_REQUIRE(in_cs >= rin_p && in_cs % 4 == 0 && out_cs >= nout_p && out_cs % 4 == 0, "conv3d_fwd: bad channel stride");
+    CTU_REQUIRE(((uintptr_t)in & 15) == 0 && ((uintptr_t)wp & 15) == 0 && ((uintptr_t)out & 15) == 0,
+                "conv3d_fwd: in/wp/out must be 16-byte aligned");
+    CTU_REQUIRE((int64_t)D * H * W * in_cs < (1LL << 31), "conv3d_fwd: one batch item must stay below 2^31 elements");
     CTU_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv3d_fwd: scale/shift must come together");
     ConvP p;
     p.in = in; p.in_scale = in_scale; p.in_shift = in_shift; p.wp = wp; p.bias = bias; p.out = out; p.stats = stats;
@@ -1108,28 +1001,25 @@ extern "C" int ctu_conv3d_fwd(const float* in, int in_cs, int rin_p, const float
         p.n16 = 1;
         p.tiles_d = ceil_div(D, 4); p.tiles_h = ceil_div(H, 4); p.tiles_w = ceil_div(W, 32);
         const int ntiles = N * p.tiles_d * p.tiles_h * p.tiles_w;
-        int gx = ntiles < 512 ? ntiles : 512;          // 2 resident blocks per CU (LDS)
-        const int tpb = ceil_div(ntiles, gx);
-        gx = ceil_div(ntiles, tpb);
-        conv3d_fwd_k3_pair8<<<gx, 256, 0, st>>>(p, ntiles, tpb);
-        CTU_CHECK_LAUNCH("conv3d_fwd_k3_pair8");
+        int gx, tpb;
+        persist_grid(ntiles, 1, 2, &gx, &tpb);         // 2 resident blocks per CU (LDS)
+        conv3d_fwd_k3_persist<1, true><<<gx, 256, 0, st>>>(p, ntiles, tpb);
+        CTU_CHECK_LAUNCH("conv3d_fwd_k3_persist<1, pair>");
         return CTU_OK;
     }
     CTU_REQUIRE(layout == 0, "conv3d_fwd: unknown layout %d", layout);
     int NT, td, th, tw;
     pick_launch(N, D, H, W, nout_p, &NT, &td, &th, &tw);
-    if (k == 3 && tw == 16 && NT <= 2) {
-        // large layers: persistent, register-prefetching kernel; 3 resident blocks per CU
+    if (use_persist(k, NT, tw)) {
+        // large layers: persistent, register-prefetching kernel
         p.n16 = ceil_div(p.nout_p, 16);
         p.tiles_d = ceil_div(D, 4); p.tiles_h = ceil_div(H, 4); p.tiles_w = ceil_div(W, 16);
         const int ntiles = N * p.tiles_d * p.tiles_h * p.tiles_w;
         const int ny = ceil_div(p.n16, NT);
-        int gx = ntiles < 768 / ny ? ntiles : 768 / ny;
-        if (gx < 1) gx = 1;
-        const int tpb = ceil_div(ntiles, gx);
-        gx = ceil_div(ntiles, tpb);
-        if (NT == 1) conv3d_fwd_k3_persist<1><<<dim3(gx, ny), 256, 0, st>>>(p, ntiles, tpb);
-        else conv3d_fwd_k3_persist<2><<<dim3(gx, ny), 256, 0, st>>>(p, ntiles, tpb);
+        int gx, tpb;
+        persist_grid(ntiles, ny, NT == 1 ? 3 : 2, &gx, &tpb);
+        if (NT == 1) conv3d_fwd_k3_persist<1, false><<<dim3(gx, ny), 256, 0, st>>>(p, ntiles, tpb);
+        else conv3d_fwd_k3_persist<2, false><<<dim3(gx, ny), 256, 0, st>>>(p, ntiles, tpb);
         CTU_CHECK_LAUNCH("conv3d_fwd_k3_persist");
         return CTU_OK;
     }

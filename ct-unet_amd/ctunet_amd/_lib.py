@@ -30,7 +30,7 @@ SIGNATURES = {
     "ctu_conv3d_fwd_kernel_name": (C.c_char_p, [I, I, I, I, I, I, I]),
     "ctu_conv3d_wgrad_kernel_name": (C.c_char_p, [I, I, I, I]),
     "ctu_conv3d_packed_floats": (Z, [I, I, I, I]),
-    "ctu_conv3d_num_blocks": (I, [I, I, I, I, I, I]),
+    "ctu_conv3d_num_blocks": (I, [I, I, I, I, I, I, I]),
     "ctu_pack_conv3d_weight": (I, [P, P, I, I, I, P, I, I, I, I, P]),
     "ctu_conv3d_fwd": (I, [P, I, I, P, P, I, P, P, I, P, I, I, P, I, I, I, I, I, I, P]),
     "ctu_conv3d_wgrad_ws_floats": (Z, [I, I, I, I, I, I, I]),

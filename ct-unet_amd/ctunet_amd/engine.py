@@ -108,7 +108,7 @@ class UNetEngine:
         dims = x.dims
         c = cout
         if training:
-            nblk = ops.conv_num_blocks(dims, out.cp, lay)
+            nblk = ops.conv_num_blocks(dims, out.cp, lay, k)
             stats = torch.empty((nblk, 2, out.cp), dtype=torch.float32, device=x.buf.device)
             ops.conv3d_fwd(x, wp, bias_p, out, k, stats, (cin, cout), lay)
             ops.bn_finalize_into(stats, nblk, c, out.cp, x.nvox, P[bn + ".weight"], P[bn + ".bias"],

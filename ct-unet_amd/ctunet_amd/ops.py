@@ -174,9 +174,10 @@ def pack_conv_w(w: torch.Tensor, cinv: Optional[torch.Tensor], rin_p: int, nout_
     return wp
 
 
-def conv_num_blocks(dims, nout_p: int, layout: int = 0) -> int:
+def conv_num_blocks(dims, nout_p: int, layout: int = 0, k: int = 3) -> int:
+    """Rows of the BN partial-sum buffer a conv3d_fwd call with this geometry writes."""
     n, d, h, w = dims
-    return _lib.load().ctu_conv3d_num_blocks(n, d, h, w, nout_p, layout)
+    return _lib.load().ctu_conv3d_num_blocks(n, d, h, w, k, nout_p, layout)
 
 
 def conv3d_fwd(x: CL, wp: torch.Tensor, bias: Optional[torch.Tensor], out: CL, k: int,

@@ -68,7 +68,7 @@ int ctu_conv3d_layout(int k, int nout_p, int W);
 const char* ctu_conv3d_fwd_kernel_name(int N, int D, int H, int W, int k, int nout_p, int layout);
 const char* ctu_conv3d_wgrad_kernel_name(int W, int k, int cin_p, int cout_p);
 size_t ctu_conv3d_packed_floats(int k, int rin_p, int nout_p, int layout);
-int ctu_conv3d_num_blocks(int N, int D, int H, int W, int nout_p, int layout);
+int ctu_conv3d_num_blocks(int N, int D, int H, int W, int k, int nout_p, int layout);
 
 /* Re-layout a torch Conv3d weight [Co,Ci,k,k,k] for the implicit-GEMM kernels.
  *  mode 0 (forward): reduction side = padded input channels, output side = co.

@@ -21,7 +21,7 @@ if op == "fwd":
     lay = ops.conv_layout(k, cop, s)
     wp = ops.pack_conv_w(w, None, cip, cop, 0, lay)
     out = ops.CL(torch.empty(1, s, s, s, cop, device=dev), 0, cop)
-    nb = ops.conv_num_blocks((1, s, s, s), cop, lay)
+    nb = ops.conv_num_blocks((1, s, s, s), cop, lay, k)
     stats = torch.empty(nb, 2, cop, device=dev)
     fn = lambda: ops.conv3d_fwd(xx, wp, None, out, k, stats, None, lay)
 elif op == "wgrad":

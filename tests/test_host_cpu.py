@@ -45,8 +45,9 @@ def test_library_exports_every_declared_symbol():
     assert loaded.ctu_conv3d_packed_floats(3, 8, 8, 1) == 36 * 128
     assert loaded.ctu_conv3d_packed_floats(7, 8, 8, 0) == 0
     assert loaded.ctu_conv3d_layout(3, 8, 128) == 1 and loaded.ctu_conv3d_layout(3, 16, 128) == 0
-    assert loaded.ctu_conv3d_num_blocks(1, 128, 128, 128, 16, 0) == 32 * 32 * 8
-    assert loaded.ctu_conv3d_num_blocks(1, 128, 128, 128, 8, 1) == 32 * 32 * 4
+    assert loaded.ctu_conv3d_num_blocks(1, 128, 128, 128, 3, 16, 0) == 745     # persistent kernel: one row per block
+    assert loaded.ctu_conv3d_num_blocks(1, 128, 128, 128, 3, 8, 1) == 512
+    assert loaded.ctu_conv3d_num_blocks(1, 8, 8, 8, 5, 16, 0) == 8              # generic kernel: one row per box
 
 
 def test_no_gpu_no_fallback():

@@ -85,7 +85,7 @@ def test_conv3d_fwd_and_stats(case):
     # write into a channel slice of a wider buffer to exercise strides
     obuf = torch.full((n, d, h, w, cop + 8), 7.0, device="cuda")
     out = ops.CL(obuf, 8, cop)
-    nb = ops.conv_num_blocks((n, d, h, w), cop, lay)
+    nb = ops.conv_num_blocks((n, d, h, w), cop, lay, k)
     stats = torch.full((nb, 2, cop), float("nan"), device="cuda")      # every row must be written
     ops.conv3d_fwd(xc, wp, bp, out, k, stats, None, lay)
     torch.cuda.synchronize()
@@ -190,7 +190,7 @@ def test_batchnorm_train_fwd_bwd(shape):
     wt = torch.zeros(c, c, 3, 3, 3); wt[range(c), range(c), 1, 1, 1] = 1.0
     wp = ops.pack_conv_w(wt.cuda(), None, cp, cp, 0)
     out = ops.CL(torch.empty(n, d, h, w, cp, device="cuda"), 0, cp)
-    nb = ops.conv_num_blocks((n, d, h, w), cp)
+    nb = ops.conv_num_blocks((n, d, h, w), cp, 0, 3)
     stats = torch.zeros(nb, 2, cp, device="cuda")
     ops.conv3d_fwd(yc, wp, None, out, 3, stats)
     rm_g, rv_g = rm.cuda(), rv.cuda()
