@@ -742,35 +742,60 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_k3s_kernel(WgP p, int tiles_
     const int tile_end = min(p.ntiles, tile + tiles_per_block);
     float4 va[AITER], vg[GITER];
 
+    // staging items: position inside the (haloed) box, packed, and the offset relative to the box origin
+    int aoff[AITER], goff[GITER];
+    unsigned apos[AITER], gpos[GITER];
+#pragma unroll
+    for (int it = 0; it < AITER; ++it) {
+        const int e = tid + it * 256, v = (e < AITEMS) ? e / AQ : 0;
+        const int pw = v % HW, t2 = v / HW, ph = t2 % HH, pd = t2 / HH;
+        apos[it] = (unsigned)pd | ((unsigned)ph << 8) | ((unsigned)pw << 16);
+        aoff[it] = (((pd - 1) * p.H + (ph - 1)) * p.W + (pw - 1)) * p.in_cs + ci0 + aq * 4;
+    }
+#pragma unroll
+    for (int it = 0; it < GITER; ++it) {
+        const int e = tid + it * 256, v = (e < GITEMS) ? e / GQ : 0;
+        const int tw = v % GW, th = (v / GW) % TH, td = v / (GW * TH);
+        gpos[it] = (unsigned)td | ((unsigned)th << 8) | ((unsigned)tw << 16);
+        goff[it] = ((td * p.H + th) * p.W + tw - (SN - 1)) * p.g_cs + co0 + gq * 4;
+    }
+
     auto load = [&](int t) {
         const int tx = t % p.tiles_w; t /= p.tiles_w;
         const int ty = t % p.tiles_h; t /= p.tiles_h;
         const int tz = t % p.tiles_d; t /= p.tiles_d;
         const int n_img = t, d0 = tz * TD, h0 = ty * TH, w0 = tx * TW;
+        const size_t org = (((size_t)n_img * p.D + d0) * p.H + h0) * p.W + w0;
+        const float* abase = p.in + org * p.in_cs;
+        const float* gbase = p.g + org * p.g_cs;
+        const bool interior = d0 >= 1 && h0 >= 1 && w0 >= 1 && d0 + TD < p.D && h0 + TH < p.H && w0 + TW < p.W;
 #pragma unroll
         for (int it = 0; it < AITER; ++it) {
-            const int e = tid + it * 256, v = e / AQ;
-            const int pw = v % HW, t2 = v / HW, ph = t2 % HH, pd = t2 / HH;
-            const int gd = d0 + pd - 1, gh = h0 + ph - 1, gw = w0 + pw - 1;
+            const int e = tid + it * 256;
+            bool ok = e < AITEMS && a_ok;
+            if (!interior) {
+                const int gd = d0 + (int)(apos[it] & 255u) - 1, gh = h0 + (int)((apos[it] >> 8) & 255u) - 1,
+                          gw = w0 + (int)(apos[it] >> 16) - 1;
+                ok = ok && (unsigned)gd < (unsigned)p.D && (unsigned)gh < (unsigned)p.H && (unsigned)gw < (unsigned)p.W;
+            }
             float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e < AITEMS && a_ok && (unsigned)gd < (unsigned)p.D && (unsigned)gh < (unsigned)p.H &&
-                (unsigned)gw < (unsigned)p.W) {
-                const size_t vox = (((size_t)n_img * p.D + gd) * p.H + gh) * p.W + gw;
-                val = *reinterpret_cast<const float4*>(p.in + vox * p.in_cs + ci0 + aq * 4);
+            if (ok) {
+                val = *reinterpret_cast<const float4*>(abase + aoff[it]);
                 if (has_xf) val = xform4(val, sc, sh, p.in_relu);
             }
             va[it] = val;
         }
 #pragma unroll
         for (int it = 0; it < GITER; ++it) {
-            const int e = tid + it * 256, v = e / GQ;
-            const int tw = v % GW, th = (v / GW) % TH, td = v / (GW * TH);
-            const int gd = d0 + td, gh = h0 + th, gw = w0 + tw - (SN - 1);
-            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e < GITEMS && g_ok && gd < p.D && gh < p.H && (unsigned)gw < (unsigned)p.W) {
-                const size_t vox = (((size_t)n_img * p.D + gd) * p.H + gh) * p.W + gw;
-                val = *reinterpret_cast<const float4*>(p.g + vox * p.g_cs + co0 + gq * 4);
+            const int e = tid + it * 256;
+            bool ok = e < GITEMS && g_ok;
+            if (!interior) {
+                const int gd = d0 + (int)(gpos[it] & 255u), gh = h0 + (int)((gpos[it] >> 8) & 255u),
+                          gw = w0 + (int)(gpos[it] >> 16) - (SN - 1);
+                ok = ok && gd < p.D && gh < p.H && (unsigned)gw < (unsigned)p.W;
             }
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) val = *reinterpret_cast<const float4*>(gbase + goff[it]);
             vg[it] = val;
         }
     };
