@@ -82,7 +82,7 @@ def pmc_traffic(kernel):
         return None
 
 
-def cpu_baseline(size, steps=2):
+def cpu_baseline(size, steps=5):
     """The oracle (same ATen-CPU graph as the reference, no checkpoint recompute) timed on the host
     cores: 1 warm-up + best of `steps` forward+backward steps of the same 128^3 workload."""
     from oracle import unet_oracle as O
@@ -108,6 +108,11 @@ def cpu_baseline(size, steps=2):
 
 
 def main():
+    # Libraries (RCCL's version banner, ...) write to fd 1; the contract is ONE JSON line on stdout.  Route fd 1 to
+    # stderr for the whole run and keep the real stdout for the final line.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -125,8 +130,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    distributed = world > 1 or "RANK" in os.environ           # torchrun with 1 process also takes the N>1 code path
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
@@ -136,11 +143,14 @@ def main():
 
     torch.manual_seed(0)
     net = ctunet_amd.UNet().to(dev).train()
-    if world > 1:
-        parallel.distribute(net)
-    use_graph = world == 1 and not args.eager
+    use_graph = not args.eager
+    if distributed:
+        if use_graph:
+            parallel.broadcast_parameters(net)              # graph(fwd+bwd) -> flat RCCL all-reduce -> optimizer
+        else:
+            parallel.distribute(net)                        # eager: bucketed all-reduce overlapped with backward
     opt = torch.optim.Adam(net.parameters(), lr=1e-4, weight_decay=0, amsgrad=True,      # Model.py:514-520
-                           capturable=use_graph)
+                           capturable=use_graph and not distributed)
     x, target = synth_batch(args.size, rank, dev)
     holder = Holder()
 
@@ -158,7 +168,8 @@ def main():
     if use_graph:
         try:
             from ctunet_amd.graph import GraphedTrainStep
-            gstep = GraphedTrainStep(net, opt, x, [target], 1.0, 1.0, input_requires_grad=True)
+            gstep = GraphedTrainStep(net, opt, x, [target], 1.0, 1.0, input_requires_grad=True,
+                                     distributed=distributed)
 
             def step():
                 vals = gstep(x, [target])                   # same batch each step (synthetic), copied in like a loader would
@@ -167,9 +178,11 @@ def main():
         except Exception as e:                              # capture unsupported -> measured eagerly, and said so
             log(f"graph capture failed ({type(e).__name__}: {e}); falling back to eager launches")
             step = eager_step
+            if distributed:
+                parallel.distribute(net, broadcast=False)
 
     def barrier():
-        if world > 1:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -200,7 +213,7 @@ def main():
             eager_step()
         torch.cuda.synchronize()
         ops.TIMER = None
-    if world > 1:
+    if distributed:
         tt = torch.tensor([dt], device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
@@ -243,8 +256,9 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.size)
-        print(json.dumps(line), flush=True)
-    if world > 1:
+        real_stdout.write(json.dumps(line) + "\n")
+        real_stdout.flush()
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -4,7 +4,10 @@ launch-bound inner loops in hipGraphs").
 
 The step is the reference's ``Model.forward_pass`` train branch (ctunet/pytorch/Model.py:343-374) minus its
 host round trips: the per-term ``float(loss)`` syncs become ONE device->host copy after the replay.
-Single-process only; with ``parallel.distribute`` (RCCL collectives inside backward) use the eager path.
+With ``process_group`` set (one process per GPU) the captured graph holds forward + loss + backward only;
+the gradient mean over ranks (one flat RCCL all-reduce, 3.3 MB for UNet()) and the optimizer step are
+launched eagerly after each replay -- no collective is ever captured.  The bucketed, backward-overlapped
+``parallel.GradSync`` path remains the eager alternative.
 """
 from __future__ import annotations
 
@@ -20,8 +23,12 @@ class GraphedTrainStep:
 
     def __init__(self, model: torch.nn.Module, optimizer: torch.optim.Optimizer, example_input: torch.Tensor,
                  example_targets: Sequence[torch.Tensor], ce_lambda: float, dice_lambda: float,
-                 input_requires_grad: bool = True, warmup: int = 3):
+                 input_requires_grad: bool = True, warmup: int = 3, distributed: bool = False, process_group=None):
         self.model, self.opt = model, optimizer
+        self.distributed, self.group = distributed, process_group
+        if distributed and model.__dict__.get("_grad_sync_cfg") is not None:
+            raise RuntimeError("GraphedTrainStep(distributed=True) does its own all-reduce: do not also call "
+                               "parallel.distribute() on the model (use parallel.broadcast_parameters)")
         self.ce, self.dice = float(ce_lambda), float(dice_lambda)
         self.x = example_input.detach().clone()
         self.targets = [t.detach().clone() for t in example_targets]
@@ -39,6 +46,11 @@ class GraphedTrainStep:
         with torch.cuda.graph(self.graph):
             self.values = self._step()
         self.keys = self._keys()
+        if distributed:
+            import torch.distributed as dist
+            self.world = dist.get_world_size(process_group)
+            self.live = [p for p in model.parameters() if p.grad is not None]     # static .grad tensors of the graph
+            self.sizes = [p.grad.numel() for p in self.live]
 
     def _keys(self) -> List[str]:
         k: List[str] = []
@@ -74,10 +86,20 @@ class GraphedTrainStep:
                 terms.append(dc)
         loss = sum(terms)
         loss.backward()
-        self.opt.step()
-        for p in self.model.parameters():
-            p.grad = None
+        if not self.distributed:
+            self.opt.step()
+            for p in self.model.parameters():
+                p.grad = None
         return torch.stack([t.detach() for t in terms] + [loss.detach()])
+
+    def _reduce_and_step(self) -> None:
+        import torch.distributed as dist
+        grads = [p.grad for p in self.live]
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        flat.mul_(1.0 / self.world)
+        torch._foreach_copy_(grads, [c.view_as(g) for c, g in zip(flat.split(self.sizes), grads)])
+        self.opt.step()
 
     def __call__(self, x: Optional[torch.Tensor] = None, targets: Optional[Sequence[torch.Tensor]] = None) -> torch.Tensor:
         """Copies the batch into the captured buffers, replays the step, returns the loss terms (device tensor,
@@ -88,4 +110,6 @@ class GraphedTrainStep:
             for dst, src in zip(self.targets, targets):
                 dst.copy_(src)
         self.graph.replay()
+        if self.distributed:
+            self._reduce_and_step()
         return self.values

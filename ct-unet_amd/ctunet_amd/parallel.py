@@ -106,6 +106,13 @@ def distribute(module: torch.nn.Module, process_group=None, bucket_bytes: int = 
     return module
 
 
+def broadcast_parameters(module: torch.nn.Module, process_group=None) -> torch.nn.Module:
+    """Make every rank start from rank 0's parameters and buffers (no gradient hook is installed)."""
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src=0, group=process_group)
+    return module
+
+
 def make_sync(module) -> Optional[GradSync]:
     cfg = module.__dict__.get("_grad_sync_cfg")
     if cfg is None:
