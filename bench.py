@@ -149,8 +149,8 @@ def main():
             parallel.broadcast_parameters(net)              # graph(fwd+bwd) -> flat RCCL all-reduce -> optimizer
         else:
             parallel.distribute(net)                        # eager: bucketed all-reduce overlapped with backward
-    opt = torch.optim.Adam(net.parameters(), lr=1e-4, weight_decay=0, amsgrad=True,      # Model.py:514-520
-                           capturable=use_graph and not distributed)
+    from ctunet_amd import optim as ctu_optim
+    opt = ctu_optim.Adam(net.parameters(), lr=1e-4, weight_decay=0, amsgrad=True)         # Model.py:514-520, fused kernel
     x, target = synth_batch(args.size, rank, dev)
     holder = Holder()
 

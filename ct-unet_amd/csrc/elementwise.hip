@@ -346,26 +346,49 @@ __global__ void channel_sum_final_kernel(const float* __restrict__ partials, int
 }
 
 // ------------------------------------------------------------------ Adam(amsgrad)
-__global__ void adam_amsgrad_kernel(void* const* __restrict__ ptrs, const int64_t* __restrict__ sizes, float lr,
-                                    float beta1, float beta2, float eps, float wd, float bc1, float bc2_sqrt) {
+// Pointer table passed BY VALUE in the kernel arguments (<= 64 tensors, 3 KB): no device-side table to keep
+// in sync, and the launch is graph-capturable.  The step counter lives on the device so a replayed graph
+// still advances the bias corrections.
+constexpr int ADAM_MAXT = 64;
+struct AdamTable {
+    float* p[ADAM_MAXT];
+    const float* g[ADAM_MAXT];
+    float* m[ADAM_MAXT];
+    float* v[ADAM_MAXT];
+    float* vm[ADAM_MAXT];
+    int64_t n[ADAM_MAXT];
+};
+
+__global__ void adam_step_inc_kernel(float* step) { step[0] += 1.f; }
+
+__global__ void adam_amsgrad_kernel(AdamTable tb, const float* __restrict__ step, float lr, float beta1, float beta2,
+                                    float omb1, float omb2, float eps, float wd, int decoupled) {
     const int t = blockIdx.y;
-    const int64_t n = sizes[t];
-    float* p = (float*)ptrs[t * 5 + 0];
-    const float* g = (const float*)ptrs[t * 5 + 1];
-    float* m = (float*)ptrs[t * 5 + 2];
-    float* v = (float*)ptrs[t * 5 + 3];
-    float* vm = (float*)ptrs[t * 5 + 4];
+    const int64_t n = tb.n[t];
+    float* __restrict__ p = tb.p[t];
+    const float* __restrict__ g = tb.g[t];
+    float* __restrict__ m = tb.m[t];
+    float* __restrict__ v = tb.v[t];
+    float* __restrict__ vm = tb.vm[t];
+    // bias corrections in double, like the Python scalars of torch.optim.Adam
+    const double st = (double)step[0];
+    const float bc1 = (float)(1.0 - pow((double)beta1, st));
+    const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, st));
+    const float step_size = lr / bc1;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         float gr = g[i];
-        const float pv = p[i];
-        if (wd != 0.f) gr = fmaf(wd, pv, gr);
-        // torch.optim.Adam single-tensor form: lerp for exp_avg, addcmul for exp_avg_sq
-        const float mi = m[i] + (gr - m[i]) * (1.f - beta1);
-        const float vi = v[i] * beta2 + (1.f - beta2) * gr * gr;
+        float pv = p[i];
+        if (wd != 0.f) {
+            if (decoupled) pv *= 1.f - lr * wd;     // AdamW
+            else gr = fmaf(wd, pv, gr);            // Adam (L2)
+        }
+        // torch.optim.Adam single-tensor form: lerp for exp_avg, mul/addcmul for exp_avg_sq
+        const float mi = m[i] + (gr - m[i]) * omb1;          // omb = 1 - beta formed in double on the host, as torch does
+        const float vi = v[i] * beta2 + omb2 * gr * gr;
         const float vmx = fmaxf(vm[i], vi);
         m[i] = mi; v[i] = vi; vm[i] = vmx;
         const float denom = sqrtf(vmx) / bc2_sqrt + eps;
-        p[i] = pv - (lr / bc1) * (mi / denom);
+        p[i] = pv - step_size * (mi / denom);
     }
 }
 
@@ -499,18 +522,30 @@ extern "C" int ctu_channel_sum(const float* x, int cs, int cp, int64_t nvox, flo
     return CTU_OK;
 }
 
-extern "C" int ctu_adam_amsgrad(void* const* ptrs, const int64_t* sizes, int n, int64_t max_size, double lr,
-                                double beta1, double beta2, double eps, double weight_decay, int64_t step,
-                                void* stream) {
-    CTU_REQUIRE(ptrs && sizes && n > 0 && step > 0, "adam_amsgrad: bad argument");
-    const double bc1 = 1.0 - pow(beta1, (double)step);
-    const double bc2 = 1.0 - pow(beta2, (double)step);
-    int gx = (int)ceil_div64(max_size, EW_BLOCK);
-    if (gx > 64) gx = 64;
-    if (gx < 1) gx = 1;
-    adam_amsgrad_kernel<<<dim3(gx, n), EW_BLOCK, 0, (hipStream_t)stream>>>(ptrs, sizes, (float)lr, (float)beta1,
-                                                                          (float)beta2, (float)eps, (float)weight_decay,
-                                                                          (float)bc1, (float)sqrt(bc2));
-    CTU_CHECK_LAUNCH("adam_amsgrad");
+extern "C" int ctu_adam_amsgrad(void* const* ptrs, const int64_t* sizes, int n, float* step, double lr, double beta1,
+                                double beta2, double eps, double weight_decay, int decoupled, void* stream) {
+    CTU_REQUIRE(ptrs && sizes && n > 0 && step, "adam_amsgrad: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    adam_step_inc_kernel<<<1, 1, 0, st>>>(step);
+    CTU_CHECK_LAUNCH("adam_step_inc");
+    for (int t0 = 0; t0 < n; t0 += ADAM_MAXT) {
+        const int nt = (n - t0) < ADAM_MAXT ? (n - t0) : ADAM_MAXT;
+        AdamTable tb;
+        int64_t mx = 1;
+        for (int t = 0; t < nt; ++t) {
+            void* const* q = ptrs + (size_t)(t0 + t) * 5;
+            CTU_REQUIRE(q[0] && q[1] && q[2] && q[3] && q[4], "adam_amsgrad: null tensor pointer at %d", t0 + t);
+            tb.p[t] = (float*)q[0]; tb.g[t] = (const float*)q[1]; tb.m[t] = (float*)q[2]; tb.v[t] = (float*)q[3];
+            tb.vm[t] = (float*)q[4]; tb.n[t] = sizes[t0 + t];
+            if (tb.n[t] > mx) mx = tb.n[t];
+        }
+        int gx = (int)ceil_div64(mx, EW_BLOCK * 4);
+        if (gx > 128) gx = 128;
+        if (gx < 1) gx = 1;
+        adam_amsgrad_kernel<<<dim3(gx, nt), EW_BLOCK, 0, st>>>(tb, step, (float)lr, (float)beta1, (float)beta2,
+                                                              (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps,
+                                                              (float)weight_decay, decoupled);
+        CTU_CHECK_LAUNCH("adam_amsgrad");
+    }
     return CTU_OK;
 }

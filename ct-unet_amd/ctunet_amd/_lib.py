@@ -57,7 +57,7 @@ SIGNATURES = {
     "ctu_loss_bwd": (I, [P, P, I, L, F, F, I, P, P, P, I, P]),
     "ctu_channel_sum_num_blocks": (I, [L]),
     "ctu_channel_sum": (I, [P, I, I, L, P, P, I, P]),
-    "ctu_adam_amsgrad": (I, [P, P, I, L, D, D, D, D, D, L, P]),
+    "ctu_adam_amsgrad": (I, [P, P, I, P, D, D, D, D, D, I, P]),
 }
 
 _lib = None

@@ -225,12 +225,14 @@ int ctu_loss_bwd(const float* pred, const float* target, int N, int64_t V, float
 int ctu_channel_sum_num_blocks(int64_t nvox);
 int ctu_channel_sum(const float* x, int cs, int cp, int64_t nvox, float* partials,
                     float* out, int C, void* stream);
-/* Fused multi-tensor Adam with amsgrad (torch.optim.Adam(amsgrad=True), Model.py:514-520).
- * ptrs: device array of 5*n pointers {param, grad, exp_avg, exp_avg_sq, max_exp_avg_sq};
- * sizes: device int64[n].  step is the 1-based step count. */
-int ctu_adam_amsgrad(void* const* ptrs, const int64_t* sizes, int n, int64_t max_size,
+/* Fused multi-tensor Adam / AdamW with amsgrad (torch.optim.Adam(amsgrad=True) and optim.AdamW,
+ * Model.py:514-527).  ptrs: HOST array of 5*n DEVICE pointers {param, grad, exp_avg, exp_avg_sq,
+ * max_exp_avg_sq} (copied into the kernel arguments, 64 tensors per launch); sizes: HOST int64[n].
+ * step: DEVICE float[1] step counter, incremented by this call before it is used (so a captured graph
+ * keeps advancing the bias corrections).  decoupled != 0: AdamW weight decay. */
+int ctu_adam_amsgrad(void* const* ptrs, const int64_t* sizes, int n, float* step,
                      double lr, double beta1, double beta2, double eps, double weight_decay,
-                     int64_t step, void* stream);
+                     int decoupled, void* stream);
 
 #ifdef __cplusplus
 }

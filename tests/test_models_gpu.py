@@ -212,6 +212,31 @@ def test_gradients_against_fp64_oracle(name):
         assert err(got, r64) <= max(5 * err(c32, r64), 2e-3 * scale) + 1e-7, (n_, err(got, r64), err(c32, r64), scale)
 
 
+@pytest.mark.parametrize("cls,wd", [("Adam", 0.0), ("Adam", 0.01), ("AdamW", 0.01)])
+def test_fused_adam_matches_torch(cls, wd):
+    """ctunet_amd.optim.Adam/AdamW (one fused launch) vs torch.optim.Adam/AdamW(amsgrad=True) over 5 steps, incl. a
+    parameter without gradient (skipped like torch does)."""
+    from ctunet_amd import optim as O2
+    g = gen(5)
+    shapes = [(8, 1, 3, 3, 3), (8,), (16, 8, 3, 3, 3), (2, 16, 1, 1, 1), (1000003,)]
+    ps_a = [torch.randn(s, generator=g).cuda().requires_grad_(True) for s in shapes] + [torch.zeros(3).cuda().requires_grad_(True)]
+    ps_b = [p.detach().clone().requires_grad_(True) for p in ps_a]
+    ref = getattr(torch.optim, cls)(ps_a, lr=1e-2, weight_decay=wd, amsgrad=True)
+    mine = getattr(O2, cls)(ps_b, lr=1e-2, weight_decay=wd, amsgrad=True)
+    for it in range(5):
+        for pa, pb in zip(ps_a[:-1], ps_b[:-1]):
+            gr = torch.randn(pa.shape, generator=g).cuda() * (1.0 + it)
+            pa.grad, pb.grad = gr.clone(), gr.clone()
+        ref.step(); mine.step()
+    for pa, pb in zip(ps_a, ps_b):
+        assert torch.allclose(pa, pb, rtol=1e-5, atol=1e-6)
+    assert len(mine.state[ps_b[-1]]) == 0                       # no grad -> no state, parameter untouched
+    assert abs(mine.param_groups[0]["step_t"].item() - 5.0) < 1e-6
+    st = mine.state[ps_b[0]]
+    for k_ in ("exp_avg", "exp_avg_sq", "max_exp_avg_sq"):
+        assert torch.allclose(st[k_], ref.state[ps_a[0]][k_], rtol=1e-5, atol=1e-7), k_
+
+
 def test_graphed_step_equals_eager_step():
     """The HIP-graph replay of a train step (graph.GraphedTrainStep) updates parameters, BN buffers and
     reports losses exactly like the eagerly launched step."""
@@ -223,7 +248,8 @@ def test_graphed_step_equals_eager_step():
     def make():
         torch.manual_seed(0)
         net = A.UNetSP().cuda().train()
-        opt = torch.optim.Adam(net.parameters(), lr=1e-3, amsgrad=True, capturable=True)
+        from ctunet_amd import optim as O2
+        opt = O2.Adam(net.parameters(), lr=1e-3, amsgrad=True)
         return net, opt
     net_e, opt_e = make()
     losses_e = []

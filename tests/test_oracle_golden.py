@@ -53,30 +53,25 @@ def test_tiny_net_eval_train_grads_buffers(name):
 
 
 def test_checkpoint_double_bn_update():
-    """use_checkpoint=True (shipped default): BN buffers move twice per step, dead centre block once."""
+    """use_checkpoint=True (the shipped default): every BN of a re-computed block applies its momentum update
+    twice per step with the same batch statistics; the dead centre block (never re-computed) only once."""
     rec, spec = load_npz("tiny_unet.npz"), TINY["tiny_unet.npz"]
     sd = sd_from(rec)
-    x = torch.from_numpy(rec["x"])
     before = {k: v.clone() for k, v in sd.items()}
-    O.forward(spec, sd, x, training=True)
+    O.forward(spec, sd, torch.from_numpy(rec["x"]), training=True)          # first update, from the forward
+    n_per_level = {}                                                         # prefix -> (mean, biased var, n)
     stats = {}
-    for k in sd:
-        if k.endswith(".running_mean"):
-            p = k[:-len(".running_mean")]
-            # recover the batch statistics from the first momentum update
-            mean = (sd[k] - 0.9 * before[k]) / 0.1
-            n = x.shape[0] * np.prod(x.shape[2:]) / (8 ** int(p.split(".")[1]) if p.startswith(("d_blocks", "u_blocks")) else 1)
-            stats[p] = (mean, None, None)
-    # direct restatement: apply the same update again for every non-dead BN
-    for p in list(stats):
-        if p.startswith("cblock."):
+    x = torch.from_numpy(rec["x"])
+    for k in list(sd):
+        if not k.endswith(".running_mean"):
             continue
-        rm, rv = p + ".running_mean", p + ".running_var"
-        mean = (sd[rm] - 0.9 * before[rm]) / 0.1
-        unb = (sd[rv] - 0.9 * before[rv]) / 0.1
-        sd[rm] = 0.9 * sd[rm] + 0.1 * mean
-        sd[rv] = 0.9 * sd[rv] + 0.1 * unb
-        sd[p + ".num_batches_tracked"] += 1
+        p = k[:-len(".running_mean")]
+        mean = (sd[k] - (1 - O.BN_MOMENTUM) * before[k]) / O.BN_MOMENTUM            # batch mean, from the update
+        unb = (sd[p + ".running_var"] - (1 - O.BN_MOMENTUM) * before[p + ".running_var"]) / O.BN_MOMENTUM
+        level = int(p.split(".")[1]) if p.startswith("d_blocks") else (1 - int(p.split(".")[1]) if p.startswith("u_blocks") else 2)
+        n = x.shape[0] * x[0, 0].numel() // (8 ** level)
+        stats[p] = (mean, unb * (n - 1) / n, n)
+    O.bn_checkpoint_replay(spec, sd, stats)                                  # second update, from the recompute
     for k, v in rec.items():
         if k.startswith("chk_post."):
             assert np.allclose(sd[k[9:]].numpy(), v, rtol=1e-4, atol=1e-5), k
