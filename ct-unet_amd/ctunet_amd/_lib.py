@@ -35,6 +35,12 @@ SIGNATURES = {
     "ctu_conv3d_fwd": (I, [P, I, I, P, P, I, P, P, I, P, I, I, P, I, I, I, I, I, I, P]),
     "ctu_conv3d_wgrad_ws_floats": (Z, [I, I, I, I, I, I, I]),
     "ctu_conv3d_wgrad": (I, [P, I, I, P, P, I, P, I, I, P, P, I, I, P, P, I, I, I, I, I, P]),
+    "ctu_conv3d_first_supported": (I, [I, I, I, I]),
+    "ctu_conv3d_first_num_blocks": (I, [I, I, I, I]),
+    "ctu_conv3d_first_fwd": (I, [P, I, P, P, I, P, I, I, P, I, I, I, I, P]),
+    "ctu_conv3d_first_bwd_data": (I, [P, I, P, I, I, P, I, I, I, I, P]),
+    "ctu_conv3d_first_wgrad_ws_floats": (Z, [I, I, I, I, I]),
+    "ctu_conv3d_first_wgrad": (I, [P, I, P, I, P, I, P, I, I, I, I, P]),
     "ctu_bn_finalize": (I, [P, I, I, I, D, P, P, P, P, F, F, I, P, P, P, P, P]),
     "ctu_bn_eval_affine": (I, [P, P, P, P, F, I, I, P, P, P]),
     "ctu_bn_bwd_num_blocks": (I, [L]),

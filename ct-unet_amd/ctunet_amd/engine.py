@@ -55,7 +55,7 @@ class NetPlan:
 
 class _ConvRec:
     """What one conv+BN stage leaves behind for backward."""
-    __slots__ = ("x", "y", "vec", "stats", "nblk", "conv", "bn", "cin", "cout", "imap", "bias")
+    __slots__ = ("x", "y", "vec", "stats", "nblk", "conv", "bn", "cin", "cout", "imap", "bias", "first")
 
 
 class UNetEngine:
@@ -124,8 +124,39 @@ class UNetEngine:
         rec = None
         if save:
             rec = _ConvRec()
+            rec.first = None
             rec.x, rec.y, rec.vec, rec.stats, rec.nblk = x, out.raw(), vec4, stats, nblk
             rec.conv, rec.bn, rec.cin, rec.cout, rec.imap, rec.bias = conv, bn, cin, cout, imap, bias is not None
+        return y, rec
+
+    def _first_conv_bn(self, P, x: torch.Tensor, conv: str, bn: str, cin: int, cout: int, out: CL, vec4: torch.Tensor,
+                       training: bool, n_upd: int, save: bool):
+        """First encoder conv through the direct C_in <= 2 kernels (reads the NCDHW input in place)."""
+        w = P[conv + ".weight"].detach()
+        bias = P.get(conv + ".bias")
+        bias_p = None if bias is None else bias.detach()
+        dims = out.dims
+        nvox = dims[0] * dims[1] * dims[2] * dims[3]
+        if training:
+            nblk = ops.conv_first_num_blocks(dims)
+            stats = torch.empty((nblk, 2, out.cp), dtype=torch.float32, device=x.device)
+            ops.conv_first_fwd(x, w, bias_p, out, stats)
+            ops.bn_finalize_into(stats, nblk, cout, out.cp, nvox, P[bn + ".weight"], P[bn + ".bias"],
+                                 P[bn + ".running_mean"], P[bn + ".running_var"], BN_MOMENTUM, BN_EPS, n_upd, vec4)
+            if n_upd:
+                self._nbt.append(P[bn + ".num_batches_tracked"])
+        else:
+            stats, nblk = None, 0
+            ops.conv_first_fwd(x, w, bias_p, out, None)
+            ops.bn_eval_affine_into(P[bn + ".weight"], P[bn + ".bias"], P[bn + ".running_mean"],
+                                    P[bn + ".running_var"], BN_EPS, cout, out.cp, vec4)
+        y = out.with_xf(vec4[0], vec4[1], True)
+        rec = None
+        if save:
+            rec = _ConvRec()
+            rec.first = x
+            rec.x, rec.y, rec.vec, rec.stats, rec.nblk = None, out.raw(), vec4, stats, nblk
+            rec.conv, rec.bn, rec.cin, rec.cout, rec.imap, rec.bias = conv, bn, cin, cout, None, bias is not None
         return y, rec
 
     def forward(self, P: Dict[str, torch.Tensor], x: torch.Tensor, training: bool, save: bool, chk: bool):
@@ -145,7 +176,10 @@ class UNetEngine:
         n_upd = 1 if training else 0
         self._nbt: List[torch.Tensor] = []
 
-        cur = ops.ncdhw_to_cl(x)
+        x = x.contiguous()
+        e0 = plan.enc[0]
+        first_direct = plan.conv_bias is False and ops.conv_first_supported(plan.k, cin, pad8(e0.cout), w)
+        cur = None if first_direct else ops.ncdhw_to_cl(x)
         x_cl = cur
         cat: List[torch.Tensor] = []     # concat buffer per level
         xf: List[torch.Tensor] = []      # [4, 2Cp] scale/shift/mean/invstd of the concat buffer
@@ -160,8 +194,14 @@ class UNetEngine:
             t1 = CL(torch.empty((n, dd, hh, ww, cp), dtype=torch.float32, device=dev), 0, cp)
             v1 = torch.empty((4, cp), dtype=torch.float32, device=dev)
             imap = None
-            a1, recs[(blk.prefix, 1)] = self._conv_bn(P, cur, f"{blk.prefix}.{blk.first}", f"{blk.prefix}.{blk.first + 1}",
-                                                      blk.cin, blk.cout, imap, t1, v1, training, n_upd, save)
+            if i == 0 and first_direct:
+                a1, recs[(blk.prefix, 1)] = self._first_conv_bn(P, x, f"{blk.prefix}.{blk.first}",
+                                                                f"{blk.prefix}.{blk.first + 1}", blk.cin, blk.cout, t1,
+                                                                v1, training, n_upd, save)
+            else:
+                a1, recs[(blk.prefix, 1)] = self._conv_bn(P, cur, f"{blk.prefix}.{blk.first}",
+                                                          f"{blk.prefix}.{blk.first + 1}", blk.cin, blk.cout, imap, t1,
+                                                          v1, training, n_upd, save)
             a2, recs[(blk.prefix, 2)] = self._conv_bn(P, a1, f"{blk.prefix}.{blk.first + 3}", f"{blk.prefix}.{blk.first + 4}",
                                                       blk.cout, blk.cout, None, CL(cat[i], cp, cp), xf[i][:, cp:],
                                                       training, n_upd, save)
@@ -233,6 +273,9 @@ class UNetEngine:
         k = self.plan.k
         dg, db = ops.bn_relu_bwd(rec.y, ga, rec.vec, P[rec.bn + ".weight"].detach(), rec.cout, part)
         grads[rec.bn + ".weight"], grads[rec.bn + ".bias"] = dg, db
+        if rec.first is not None:                  # direct C_in <= 2 kernels; gin is a request flag here
+            grads[rec.conv + ".weight"] = ops.conv_first_wgrad(rec.first, ga, rec.cout, ws)
+            return ops.conv_first_bwd_data(ga, P[rec.conv + ".weight"].detach(), rec.cin) if gin is not None else None
         dw, dbias = ops.conv3d_wgrad(rec.x, ga, rec.cout, rec.cin, k, rec.imap, ws, rec.bias)
         grads[rec.conv + ".weight"] = dw
         if rec.bias:
@@ -264,6 +307,10 @@ class UNetEngine:
         ws_n, part_n = 1, 1
         for r in recs.values():
             if r is None:
+                continue
+            if r.first is not None:
+                ws_n = max(ws_n, ops.conv_first_wgrad_ws(r.y.dims, r.cin))
+                part_n = max(part_n, ops.bn_bwd_partials_floats(r.y.nvox, r.y.cp))
                 continue
             ws_n = max(ws_n, ops.conv3d_wgrad_ws(r.x.dims, k, r.x.cp, r.y.cp))
             part_n = max(part_n, ops.bn_bwd_partials_floats(r.y.nvox, r.y.cp))
@@ -348,6 +395,8 @@ class UNetEngine:
             if i > 0:
                 g_pool = CL(torch.empty_like(ctx["pooled"][i - 1].buf), 0, ctx["pooled"][i - 1].cp)
                 self._conv_bn_bwd(P, r1, g_d1, g_pool, grads, ws, part)
+            elif need_dx and r1.first is not None:
+                dx = self._conv_bn_bwd(P, r1, g_d1, True, grads, ws, part)
             elif need_dx:
                 g_x = CL(torch.empty_like(ctx["x_cl"].buf), 0, ctx["x_cl"].cp)
                 self._conv_bn_bwd(P, r1, g_d1, g_x, grads, ws, part)
@@ -381,7 +430,7 @@ class _UNetFn(torch.autograd.Function):
         g1 = gouts[1] if fctx.two else None
         ctx = fctx.ctx
         if g0 is None:
-            g0 = torch.zeros(_out_shape(ctx, fctx, 0), device=ctx["x_cl"].buf.device)
+            g0 = torch.zeros(_out_shape(ctx, fctx, 0), device=ctx["cat"][0].device)
         if fctx.two and g1 is None:
             g1 = torch.zeros_like(g0)
         P = _tensor_dict(fctx.module)

@@ -221,6 +221,63 @@ def conv3d_wgrad_ws(dims, k, cin_p, cout_p) -> int:
     return _lib.load().ctu_conv3d_wgrad_ws_floats(n, d, h, w, k, cin_p, cout_p)
 
 
+# ---------------------------------------------------------------------------- first layer (C_in <= 2)
+def conv_first_supported(k: int, cin: int, nout_p: int, w: int) -> bool:
+    return bool(_lib.load().ctu_conv3d_first_supported(k, cin, nout_p, w))
+
+
+def conv_first_num_blocks(dims) -> int:
+    n, d, h, w = dims
+    return _lib.load().ctu_conv3d_first_num_blocks(n, d, h, w)
+
+
+def conv_first_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: CL,
+                   stats: Optional[torch.Tensor]) -> None:
+    """x: NCDHW float32 on the GPU (read in place); w: torch Conv3d weight [Co, cin, 3, 3, 3]."""
+    _need_cuda(x, "input")
+    n, cin, d, h, w_ = x.shape
+    lib = _lib.load()
+    t0 = TIMER.begin() if TIMER is not None else None
+    _lib.check(lib.ctu_conv3d_first_fwd(x.data_ptr(), cin, w.data_ptr(), _ptr(bias), 0 if bias is None else bias.numel(),
+                                        out.ptr, out.cs, w.shape[0], _ptr(stats), n, d, h, w_, _stream()),
+               "conv3d_first_fwd")
+    if t0 is not None:
+        vox = n * d * h * w_
+        TIMER.end(f"first_fwd_kernel<{cin}>", 2.0 * cin * w.shape[0] * 27 * vox, 4.0 * vox * (cin + w.shape[0]), t0)
+
+
+def conv_first_bwd_data(g: CL, w: torch.Tensor, cin: int) -> torch.Tensor:
+    n, d, h, w_ = g.dims
+    dx = torch.empty((n, cin, d, h, w_), dtype=torch.float32, device=g.buf.device)
+    lib = _lib.load()
+    t0 = TIMER.begin() if TIMER is not None else None
+    _lib.check(lib.ctu_conv3d_first_bwd_data(g.ptr, g.cs, w.data_ptr(), cin, w.shape[0], dx.data_ptr(), n, d, h, w_,
+                                             _stream()), "conv3d_first_bwd_data")
+    if t0 is not None:
+        vox = n * d * h * w_
+        TIMER.end(f"first_bwd_data_kernel<{cin}>", 2.0 * cin * w.shape[0] * 27 * vox, 4.0 * vox * (cin + w.shape[0]), t0)
+    return dx
+
+
+def conv_first_wgrad(x: torch.Tensor, g: CL, co: int, ws: torch.Tensor) -> torch.Tensor:
+    n, cin, d, h, w_ = x.shape
+    lib = _lib.load()
+    assert ws.numel() >= lib.ctu_conv3d_first_wgrad_ws_floats(n, d, h, w_, cin)
+    dw = torch.empty((co, cin, 3, 3, 3), dtype=torch.float32, device=x.device)
+    t0 = TIMER.begin() if TIMER is not None else None
+    _lib.check(lib.ctu_conv3d_first_wgrad(x.data_ptr(), cin, g.ptr, g.cs, dw.data_ptr(), co, ws.data_ptr(), n, d, h, w_,
+                                          _stream()), "conv3d_first_wgrad")
+    if t0 is not None:
+        vox = n * d * h * w_
+        TIMER.end(f"first_wgrad_kernel<{cin}> (+slab reduce)", 2.0 * cin * co * 27 * vox, 4.0 * vox * (cin + co), t0)
+    return dw
+
+
+def conv_first_wgrad_ws(dims, cin: int) -> int:
+    n, d, h, w = dims
+    return _lib.load().ctu_conv3d_first_wgrad_ws_floats(n, d, h, w, cin)
+
+
 # ---------------------------------------------------------------------------- batch norm
 def bn_finalize_into(stats, nblocks, c, cp, count, gamma, beta, rmean, rvar, momentum, eps, n_updates, vec4):
     """vec4: [4, cp] view (rows may be strided) receiving scale, shift, mean, invstd."""

@@ -113,6 +113,26 @@ int ctu_conv3d_wgrad(const float* in, int in_cs, int cin_p,
                      float* dw, float* dbias, int Co, int Ci, const int32_t* cinv,
                      float* ws, int N, int D, int H, int W, int k, void* stream);
 
+/* First encoder convolution: C_in = 1 or 2, k = 3, at most 8 output channels (nn.Conv3d(input_channels, i_size, 3),
+ * models.py:26 with the channel plan of :175,272-296).  K = 27*C_in is too short for the implicit-GEMM tile and the
+ * layer is HBM-bound, so it gets direct kernels that read / write the caller's NCDHW planes in place (no padded
+ * channels-last copy of the input):
+ *   fwd ....... x [N,cin,D,H,W] (NCDHW) * w [Co,cin,3,3,3] (torch layout, unpacked) -> out channels-last (8 padded
+ *               channels, stride out_cs) + one BN partial row [2][8] per block (ctu_conv3d_first_num_blocks rows)
+ *   bwd_data .. g channels-last (8 padded channels) -> dx [N,cin,D,H,W] (NCDHW)
+ *   wgrad ..... dw [Co,cin,3,3,3]; ws: ctu_conv3d_first_wgrad_ws_floats() floats
+ * ctu_conv3d_first_supported tells whether a layer qualifies (k = 3, cin <= 2, nout_p = 8, W >= 16). */
+int ctu_conv3d_first_supported(int k, int cin, int nout_p, int W);
+int ctu_conv3d_first_num_blocks(int N, int D, int H, int W);
+int ctu_conv3d_first_fwd(const float* x, int cin, const float* w, const float* bias, int nbias,
+                         float* out, int out_cs, int Co, float* stats,
+                         int N, int D, int H, int W, void* stream);
+int ctu_conv3d_first_bwd_data(const float* g, int g_cs, const float* w, int cin, int Co, float* dx,
+                              int N, int D, int H, int W, void* stream);
+size_t ctu_conv3d_first_wgrad_ws_floats(int N, int D, int H, int W, int cin);
+int ctu_conv3d_first_wgrad(const float* x, int cin, const float* g, int g_cs, float* dw, int Co,
+                           float* ws, int N, int D, int H, int W, void* stream);
+
 /* ------------------------------------------------------------ BatchNorm3d ---- */
 /* Train mode: reduce the per-block partials written by ctu_conv3d_fwd into batch
  * statistics and the lazy transform.  count = N*D*H*W.  C logical channels, cp padded.

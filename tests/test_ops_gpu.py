@@ -134,6 +134,35 @@ def test_conv3d_backward(case):
     assert rel_err(db.cpu(), b.grad) < 1e-4
 
 
+@pytest.mark.parametrize("case", [(1, 1, 8, 8, 8, 32), (2, 2, 7, 6, 5, 40), (1, 1, 3, 4, 4, 16), (1, 2, 4, 9, 7, 70)])
+def test_first_layer_direct_kernels(case):
+    """C_in <= 2 first conv: direct forward (+BN partials), input gradient and weight gradient, NCDHW in place."""
+    ops = _ops()
+    n, ci, co, d, h, w = case
+    assert ops.conv_first_supported(3, ci, 8, w)
+    x = torch.randn(n, ci, d, h, w, generator=g(1)).requires_grad_(True)
+    wt = (torch.randn(co, ci, 3, 3, 3, generator=g(2)) * 0.3).requires_grad_(True)
+    ref = F.conv3d(x, wt, None, 1, 1)
+    gy = torch.randn(ref.shape, generator=g(3))
+    ref.backward(gy)
+    obuf = torch.full((n, d, h, w, 16), 7.0, device="cuda")
+    out = ops.CL(obuf, 8, 8)
+    nb = ops.conv_first_num_blocks((n, d, h, w))
+    stats = torch.full((nb, 2, 8), float("nan"), device="cuda")
+    ops.conv_first_fwd(x.detach().cuda(), wt.detach().cuda(), None, out, stats)
+    assert rel_err(from_cl(out, co), ref.detach()) < 1e-5
+    assert torch.all(obuf[..., :8] == 7.0) and torch.all(obuf[..., 8 + co:] == 0)
+    s = stats.sum(0).cpu().double()
+    assert torch.allclose(s[0, :co], ref.detach().double().sum((0, 2, 3, 4)), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(s[1, :co], (ref.detach().double() ** 2).sum((0, 2, 3, 4)), rtol=1e-4)
+    gc = to_cl(gy)
+    dx = ops.conv_first_bwd_data(gc, wt.detach().cuda(), ci)
+    assert rel_err(dx.cpu(), x.grad) < 1e-5
+    ws = torch.empty(ops.conv_first_wgrad_ws((n, d, h, w), ci), device="cuda")
+    dw = ops.conv_first_wgrad(x.detach().cuda(), gc, co, ws)
+    assert rel_err(dw.cpu(), wt.grad) < 1e-4
+
+
 def test_conv3d_imap_concat():
     """Input channels scattered in a padded concat buffer (UNetSP: 7+pad | 7+pad)."""
     ops = _ops()
