@@ -328,20 +328,23 @@ __global__ __launch_bounds__(256) void first_wgrad_kernel(FirstP p, int tiles_pe
 }
 
 template <int CIN>
-__global__ __launch_bounds__(256) void first_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Co,
+__global__ __launch_bounds__(1024) void first_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Co,
                                                                  int gx) {
     constexpr int MTN = (27 * CIN + 15) / 16;
-    __shared__ float red[4][64];
-    const int e = threadIdx.x & 63, part = threadIdx.x >> 6;
+    __shared__ float red[16][64];
+    const int e = threadIdx.x & 63, part = threadIdx.x >> 6;          // 1024 threads: 16 slab groups x 64 elements
     const int el = blockIdx.x * 64 + e;
     float s = 0.f;
     if (el < MTN * 256)
-        for (int k = part; k < gx; k += 4) s += ws[(size_t)k * (MTN * 256) + el];
+        for (int k = part; k < gx; k += 16) s += ws[(size_t)k * (MTN * 256) + el];
     red[part][e] = s;
     __syncthreads();
     if (part != 0 || el >= MTN * 256) return;
+    float tot = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) tot += red[q][e];
     const int r = el >> 4, co = el & 15, tap = r / CIN, ci = r % CIN;
-    if (r < 27 * CIN && co < Co) dw[((size_t)co * CIN + ci) * 27 + tap] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    if (r < 27 * CIN && co < Co) dw[((size_t)co * CIN + ci) * 27 + tap] = tot;
 }
 
 void grid_for(int ntiles, int per_cu, int* gx, int* tpb) {
@@ -405,7 +408,7 @@ extern "C" int ctu_conv3d_first_bwd_data(const float* g, int g_cs, const float* 
 extern "C" size_t ctu_conv3d_first_wgrad_ws_floats(int N, int D, int H, int W, int cin) {
     FirstP p;
     int gx, tpb;
-    grid_for(fill(p, N, D, H, W, 32), 2, &gx, &tpb);
+    grid_for(fill(p, N, D, H, W, 32), 5, &gx, &tpb);
     return (size_t)gx * ((27 * cin + 15) / 16) * 256;
 }
 
@@ -417,14 +420,14 @@ extern "C" int ctu_conv3d_first_wgrad(const float* x, int cin, const float* g, i
     FirstP p{};
     p.x = x; p.g = g; p.g_cs = g_cs; p.ws = ws; p.Co = Co;
     int gx, tpb;
-    grid_for(fill(p, N, D, H, W, 32), 2, &gx, &tpb);
+    grid_for(fill(p, N, D, H, W, 32), 5, &gx, &tpb);
     hipStream_t st = (hipStream_t)stream;
     if (cin == 1) {
         first_wgrad_kernel<1><<<gx, 256, 0, st>>>(p, tpb);
-        first_wgrad_reduce_kernel<1><<<ceil_div(2 * 256, 64), 256, 0, st>>>(ws, dw, Co, gx);
+        first_wgrad_reduce_kernel<1><<<ceil_div(2 * 256, 64), 1024, 0, st>>>(ws, dw, Co, gx);
     } else {
         first_wgrad_kernel<2><<<gx, 256, 0, st>>>(p, tpb);
-        first_wgrad_reduce_kernel<2><<<ceil_div(4 * 256, 64), 256, 0, st>>>(ws, dw, Co, gx);
+        first_wgrad_reduce_kernel<2><<<ceil_div(4 * 256, 64), 1024, 0, st>>>(ws, dw, Co, gx);
     }
     CTU_CHECK_LAUNCH("conv3d_first_wgrad");
     return CTU_OK;
