@@ -48,6 +48,15 @@ __device__ __forceinline__ float4 xform4(float4 v, float4 sc, float4 sh, int rel
     return v;
 }
 
+// slab reductions: RPARTS thread groups of 64 stride over the partial slabs, then a fixed-order sum
+constexpr int RPARTS = 16;
+__device__ __forceinline__ float red_total(const float (*red)[64], int e) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < RPARTS; ++q) t += red[q][e];
+    return t;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

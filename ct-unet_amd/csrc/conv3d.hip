@@ -13,6 +13,7 @@
 // the taps with compile-time LDS offsets.  One ds_read_b64 per lane feeds two MFMAs: lane
 // (m, kq) holds channels {2kq, 2kq+1}; MFMA #0 contracts channels {0,2,4,6}, #1 {1,3,5,7}.
 #include "common.h"
+#include "pack.h"
 
 namespace {
 
@@ -30,12 +31,6 @@ struct ConvP {
     int n16;                 // number of 16-wide output-channel tiles in the packed weights
 };
 
-template <int KS>
-struct Taps {
-    static constexpr int TAPS = KS * KS * KS;
-    static constexpr int STAPS = (KS == 3) ? 27 : KS * KS;   // taps whose weights sit in LDS at once
-    static constexpr int NSTAGE = TAPS / STAPS;
-};
 
 __host__ __device__ inline void pick_tile(int W, int* td, int* th, int* tw) {
     if (W >= 16) { *td = 4; *th = 4; *tw = 16; }
@@ -457,72 +452,38 @@ __global__ __launch_bounds__(256) void conv3d_fwd_k3_persist(ConvP p, int ntiles
     }
 }
 
-// pair layout packing: [chunk][kd][kh][kw' (4)][kq][n = s*8+o][j]; gather, every element written
+
 __global__ void pack_conv_w_pair8_kernel(const float* __restrict__ w, float* __restrict__ wp, int Co, int Ci,
                                          const int32_t* __restrict__ cinv, int nchunk, int mode) {
+    pack_conv_w_pair8_elem(blockIdx.x * blockDim.x + threadIdx.x, w, wp, Co, Ci, cinv, nchunk, mode);
+}
+
+// ---- every weight tensor of the network in ONE launch: job table by value in the kernel arguments
+constexpr int PACK_MAXJ = 48;
+struct PackTable { ctu_pack_job j[PACK_MAXJ]; };
+
+__global__ void pack_batch_kernel(PackTable tb) {
+    const ctu_pack_job& q = tb.j[blockIdx.y];
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= nchunk * 36 * 128) return;
-    int r = idx;
-    const int j = r & 1; r >>= 1;
-    const int n = r & 15; r >>= 4;
-    const int kq = r & 3; r >>= 2;
-    const int kwp = r & 3; r >>= 2;
-    const int kh = r % 3; r /= 3;
-    const int kd = r % 3; r /= 3;
-    const int c = r;
-    const int s = n >> 3, o = n & 7, kw = kwp - s;
-    const int rp = c * 8 + kq * 2 + j;
-    float v = 0.f;
-    if (kw >= 0 && kw <= 2) {
-        const int t = (kd * 3 + kh) * 3 + kw;
-        if (mode == 0) {
-            const int ci = cinv ? cinv[rp] : (rp < Ci ? rp : -1);
-            if (ci >= 0 && o < Co) v = w[((size_t)o * Ci + ci) * 27 + t];
-        } else {
-            const int ci = cinv ? cinv[o] : (o < Ci ? o : -1);
-            if (ci >= 0 && rp < Co) v = w[((size_t)rp * Ci + ci) * 27 + (26 - t)];
-        }
+    if (q.kind == 1) {
+        const int n16 = (q.nout_p + 15) / 16;
+        pack_convt_w_elem(idx, q.w, q.wp, q.Ci, q.Co, q.cinv, q.rin_p, n16 <= 1 ? 1 : (n16 <= 2 ? 2 : (n16 <= 4 ? 4 : 8)), q.mode);
+    } else if (q.layout == 1) {
+        pack_conv_w_pair8_elem(idx, q.w, q.wp, q.Co, q.Ci, q.cinv, q.rin_p / 8, q.mode);
+    } else if (q.k == 3) {
+        pack_conv_w_elem<3>(idx, q.w, q.wp, q.Co, q.Ci, q.cinv, q.rin_p / 8, (q.nout_p + 15) / 16, q.mode);
+    } else {
+        pack_conv_w_elem<5>(idx, q.w, q.wp, q.Co, q.Ci, q.cinv, q.rin_p / 8, (q.nout_p + 15) / 16, q.mode);
     }
-    wp[idx] = v;
 }
 
 // ------------------------------------------------------------------ packing
-// wp index for (chunk c, stage s, tap-in-stage ts, 16-wide output tile, kq, n, j)
-template <int KS>
-__device__ __forceinline__ size_t wp_index(int rp, int np, int t, int n16) {
-    constexpr int STAPS = Taps<KS>::STAPS, NSTAGE = Taps<KS>::NSTAGE;
-    const int c = rp >> 3, kq = (rp & 7) >> 1, j = rp & 1;
-    const int nt = np >> 4, n = np & 15;
-    const int s = t / STAPS, ts = t % STAPS;
-    return ((((size_t)c * NSTAGE + s) * STAPS + ts) * n16 + nt) * 128 + kq * 32 + n * 2 + j;
-}
 
-// One thread per PACKED element (gather): layout [chunk][stage][tap][n16 tile][kq][n][j].
-// cinv maps a padded input-channel position to its logical channel (-1 = padding, NULL = identity).
+
 template <int KS>
 __global__ void pack_conv_w_kernel(const float* __restrict__ w, float* __restrict__ wp, int Co, int Ci,
                                    const int32_t* __restrict__ cinv, int nchunk, int n16, int mode) {
-    constexpr int TAPS = Taps<KS>::TAPS, STAPS = Taps<KS>::STAPS, NSTAGE = Taps<KS>::NSTAGE;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= nchunk * TAPS * n16 * 128) return;
-    int r = idx;
-    const int j = r & 1; r >>= 1;
-    const int n = r & 15; r >>= 4;
-    const int kq = r & 3; r >>= 2;
-    const int nt = r % n16; r /= n16;
-    const int ts = r % STAPS; r /= STAPS;
-    const int s = r % NSTAGE; r /= NSTAGE;
-    const int c = r;
-    const int rp = c * 8 + kq * 2 + j, np = nt * 16 + n, t = s * STAPS + ts;
-    float v = 0.f;
-    if (mode == 0) {
-        const int ci = cinv ? cinv[rp] : (rp < Ci ? rp : -1);
-        if (ci >= 0 && np < Co) v = w[((size_t)np * Ci + ci) * TAPS + t];
-    } else {
-        const int ci = cinv ? cinv[np] : (np < Ci ? np : -1);
-        if (ci >= 0 && rp < Co) v = w[((size_t)rp * Ci + ci) * TAPS + (TAPS - 1 - t)];
-    }
-    wp[idx] = v;
+    pack_conv_w_elem<KS>(blockIdx.x * blockDim.x + threadIdx.x, w, wp, Co, Ci, cinv, nchunk, n16, mode);
 }
 
 // Launch shape: output-channel tiles per block (NT) and spatial tile.  Big volumes take the widest tile
@@ -658,23 +619,23 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(WgP p) {
 // dW[co][ci][t] = sum over the gx slabs of its (kd-group, ci-tile, co-tile).  A block owns 64 consecutive
 // slab elements (coalesced 256-B reads); 4 thread groups stride over the slabs, combined in a fixed order.
 template <int KS, int KDS>
-__global__ __launch_bounds__(256) void conv3d_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
+__global__ __launch_bounds__(1024) void conv3d_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
                                                                   int Co, int Ci, const int32_t* __restrict__ pmap,
                                                                   int cin_p, int n_ci_t, int gx) {
     constexpr int TAPS = KS * KS * KS, BT = KDS * KS * KS;
-    __shared__ float red[4][64];
+    __shared__ float red[RPARTS][64];
     const int e = threadIdx.x & 63, part = threadIdx.x >> 6;
     const int el = blockIdx.x * 64 + e;                 // element inside the [BT][16][16] slab
     const int pz = blockIdx.y;                          // (z * n_pairs + pair)
     float s = 0.f;
     if (el < BT * 256) {
         const float* src = ws + (size_t)pz * gx * (BT * 256) + el;
-        for (int k = part; k < gx; k += 4) s += src[(size_t)k * (BT * 256)];
+        for (int k = part; k < gx; k += RPARTS) s += src[(size_t)k * (BT * 256)];
     }
     red[part][e] = s;
     __syncthreads();
     if (part == 0 && el < BT * 256) {
-        const float tot = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+        const float tot = red_total(red, e);
         const int n_pairs = gridDim.y / (TAPS / BT);
         const int z = pz / n_pairs, pair = pz % n_pairs;
         const int cit = pair % n_ci_t, cot = pair / n_ci_t;
@@ -851,24 +812,24 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_k3s_kernel(WgP p, int tiles_
 }
 
 template <int SM, int SN>
-__global__ __launch_bounds__(256) void conv3d_wgrad_k3s_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
+__global__ __launch_bounds__(1024) void conv3d_wgrad_k3s_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
                                                                       int Co, int Ci, const int32_t* __restrict__ cinv,
                                                                       int cin_p, int n_ci_g, int gx) {
     constexpr int NMF = (SM == 2 && SN == 2) ? 9 : 18;
     constexpr int CM = 16 / SM, CN = 16 / SN;
-    __shared__ float red[4][64];
+    __shared__ float red[RPARTS][64];
     const int e = threadIdx.x & 63, part = threadIdx.x >> 6;
     const int el = blockIdx.x * 64 + e;
     const int pair = blockIdx.y;
     float s = 0.f;
     if (el < NMF * 256) {
         const float* src = ws + (size_t)pair * gx * (NMF * 256) + el;
-        for (int k = part; k < gx; k += 4) s += src[(size_t)k * (NMF * 256)];
+        for (int k = part; k < gx; k += RPARTS) s += src[(size_t)k * (NMF * 256)];
     }
     red[part][e] = s;
     __syncthreads();
     if (part != 0 || el >= NMF * 256) return;
-    const float tot = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    const float tot = red_total(red, e);
     const int t = el >> 8, i = (el >> 4) & 15, j = el & 15;
     const int r = (NMF == 9) ? t : t / 2, q = (NMF == 9) ? 0 : t % 2;
     const int sm = (SM == 2) ? i / 8 : 0, cil = (SM == 2) ? i % 8 : i;
@@ -897,7 +858,7 @@ static int launch_wgrad_k3s(WgP p, float* dw, int Co, int Ci, const int32_t* cin
     gx = ceil_div(p.ntiles, tpb);
     conv3d_wgrad_k3s_kernel<SM, SN><<<dim3(gx, pairs), 256, 0, st>>>(p, tpb);
     CTU_CHECK_LAUNCH("conv3d_wgrad_k3s");
-    conv3d_wgrad_k3s_reduce_kernel<SM, SN><<<dim3(ceil_div(NMF * 256, 64), pairs), 256, 0, st>>>(p.ws, dw, Co, Ci, cinv, p.cin_p,
+    conv3d_wgrad_k3s_reduce_kernel<SM, SN><<<dim3(ceil_div(NMF * 256, 64), pairs), 64 * RPARTS, 0, st>>>(p.ws, dw, Co, Ci, cinv, p.cin_p,
                                                                                               p.n_ci_t, gx);
     CTU_CHECK_LAUNCH("conv3d_wgrad_k3s_reduce");
     return CTU_OK;
@@ -986,6 +947,36 @@ extern "C" int ctu_pack_conv3d_weight(const float* w, float* wp, int Co, int Ci,
     if (k == 3) pack_conv_w_kernel<3><<<nb, 256, 0, st>>>(w, wp, Co, Ci, cinv, rin_p / 8, n16, mode);
     else pack_conv_w_kernel<5><<<nb, 256, 0, st>>>(w, wp, Co, Ci, cinv, rin_p / 8, n16, mode);
     CTU_CHECK_LAUNCH("pack_conv3d_weight");
+    return CTU_OK;
+}
+
+extern "C" size_t ctu_convt_packed_floats(int rin_p, int nout_p);
+
+extern "C" int ctu_pack_batch(const ctu_pack_job* jobs, int n, void* stream) {
+    CTU_REQUIRE(jobs && n > 0, "pack_batch: no jobs");
+    hipStream_t st = (hipStream_t)stream;
+    for (int j0 = 0; j0 < n; j0 += PACK_MAXJ) {
+        const int nj = (n - j0) < PACK_MAXJ ? (n - j0) : PACK_MAXJ;
+        PackTable tb;
+        size_t mx = 1;
+        for (int j = 0; j < nj; ++j) {
+            const ctu_pack_job& q = jobs[j0 + j];
+            CTU_REQUIRE(q.w && q.wp && q.Co > 0 && q.Ci > 0 && q.rin_p % 8 == 0 && q.nout_p % 8 == 0, "pack_batch: bad job %d", j0 + j);
+            size_t tot;
+            if (q.kind == 1) {
+                CTU_REQUIRE(q.nout_p <= 128, "pack_batch: convT nout_p=%d", q.nout_p);
+                tot = ctu_convt_packed_floats(q.rin_p, q.nout_p);
+            } else {
+                CTU_REQUIRE(q.kind == 0 && (q.k == 3 || q.k == 5) && (q.layout == 0 || (q.layout == 1 && q.k == 3 && q.nout_p == 8)),
+                            "pack_batch: bad conv job %d", j0 + j);
+                tot = ctu_conv3d_packed_floats(q.k, q.rin_p, q.nout_p, q.layout);
+            }
+            if (tot > mx) mx = tot;
+            tb.j[j] = q;
+        }
+        pack_batch_kernel<<<dim3((unsigned)((mx + 255) / 256), nj), 256, 0, st>>>(tb);
+        CTU_CHECK_LAUNCH("pack_batch");
+    }
     return CTU_OK;
 }
 
@@ -1093,7 +1084,7 @@ static int launch_wgrad(WgP p, float* dw, int Co, int Ci, const int32_t* cinv, i
     CTU_CHECK_LAUNCH("conv3d_wgrad");
     constexpr int BT = KDS * KS * KS;
     const int n_pairs = p.n_ci_t * p.n_co_t;
-    conv3d_wgrad_reduce_kernel<KS, KDS><<<dim3(ceil_div(BT * 256, 64), gz * n_pairs), 256, 0, st>>>(
+    conv3d_wgrad_reduce_kernel<KS, KDS><<<dim3(ceil_div(BT * 256, 64), gz * n_pairs), 64 * RPARTS, 0, st>>>(
         p.ws, dw, Co, Ci, cinv, p.cin_p, p.n_ci_t, gx);
     CTU_CHECK_LAUNCH("conv3d_wgrad_reduce");
     return CTU_OK;

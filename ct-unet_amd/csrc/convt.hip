@@ -8,6 +8,7 @@
 // 8 taps, staging one tap's packed weights at a time.  v_mfma_f32_16x16x4_f32, exact fp32.
 // The op is HBM-bound (the 8x larger output stream), see DESIGN.md.
 #include "common.h"
+#include "pack.h"
 
 namespace {
 
@@ -148,26 +149,7 @@ inline int pick_ntt(int nout_p) {
 // cinv: padded input-channel position -> logical channel (-1 = padding, NULL = identity).
 __global__ void pack_convt_w_kernel(const float* __restrict__ w, float* __restrict__ wp, int Ci, int Co,
                                     const int32_t* __restrict__ cinv, int rin_p, int NTT, int mode) {
-    const int ng = rin_p >> 3;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= 8 * ng * NTT * 128) return;
-    int r = idx;
-    const int j = r & 1; r >>= 1;
-    const int n = r & 15; r >>= 4;
-    const int kq = r & 3; r >>= 2;
-    const int nt = r % NTT; r /= NTT;
-    const int g = r % ng; r /= ng;
-    const int tap = r;
-    const int rp = g * 8 + kq * 2 + j, np = nt * 16 + n;
-    float v = 0.f;
-    if (mode == 0) {
-        const int ci = cinv ? cinv[rp] : (rp < Ci ? rp : -1);
-        if (ci >= 0 && np < Co) v = w[((size_t)ci * Co + np) * 8 + tap];
-    } else {
-        const int ci = cinv ? cinv[np] : (np < Ci ? np : -1);
-        if (ci >= 0 && rp < Co) v = w[((size_t)ci * Co + rp) * 8 + tap];
-    }
-    wp[idx] = v;
+    pack_convt_w_elem(blockIdx.x * blockDim.x + threadIdx.x, w, wp, Ci, Co, cinv, rin_p, NTT, mode);
 }
 
 // ------------------------------------------------------------------ weight gradient
@@ -250,10 +232,10 @@ __global__ __launch_bounds__(256) void convt2_wgrad_kernel(CtWgP p) {
 
 // dw[ci][co][tap]: a block owns 64 consecutive outputs (co fastest) and sums the gx slabs of their
 // (ci-tile, co-tile) with 4 thread groups in a fixed order.
-__global__ __launch_bounds__(256) void convt2_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
+__global__ __launch_bounds__(1024) void convt2_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
                                                                   int Ci, int Co, const int32_t* __restrict__ imap,
                                                                   int n_ci_t, int gx) {
-    __shared__ float red[4][64];
+    __shared__ float red[RPARTS][64];
     const int e = threadIdx.x & 63, part = threadIdx.x >> 6;
     const int idx = blockIdx.x * 64 + e;
     float s = 0.f;
@@ -264,11 +246,11 @@ __global__ __launch_bounds__(256) void convt2_wgrad_reduce_kernel(const float* _
         const int cip = imap ? imap[ci] : ci;      // logical -> padded position
         const int pair = (co >> 4) * n_ci_t + (cip >> 4);
         const float* src = ws + ((size_t)pair * gx) * (8 * 256) + tap * 256 + (cip & 15) * 16 + (co & 15);
-        for (int k = part; k < gx; k += 4) s += src[(size_t)k * (8 * 256)];
+        for (int k = part; k < gx; k += RPARTS) s += src[(size_t)k * (8 * 256)];
     }
     red[part][e] = s;
     __syncthreads();
-    if (part == 0 && ok) dw[((size_t)ci * Co + co) * 8 + tap] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    if (part == 0 && ok) dw[((size_t)ci * Co + co) * 8 + tap] = red_total(red, e);
 }
 
 inline int ct_wgrad_gx(int ntiles, int pairs) {
@@ -382,7 +364,7 @@ extern "C" int ctu_convt2_wgrad(const float* in, int in_cs, int cin_p, const flo
     const int gx = ct_wgrad_gx(p.ntiles, pairs);
     convt2_wgrad_kernel<<<dim3(gx, pairs), 256, 0, st>>>(p);
     CTU_CHECK_LAUNCH("convt2_wgrad");
-    convt2_wgrad_reduce_kernel<<<ceil_div(Ci * Co * 8, 64), 256, 0, st>>>(ws, dw, Ci, Co, imap, p.n_ci_t, gx);
+    convt2_wgrad_reduce_kernel<<<ceil_div(Ci * Co * 8, 64), 64 * RPARTS, 0, st>>>(ws, dw, Ci, Co, imap, p.n_ci_t, gx);
     CTU_CHECK_LAUNCH("convt2_wgrad_reduce");
     if (dbias) return ctu_channel_sum(gout, g_cs, cout_p, p.nvox * 8, ws, dbias, Co, stream);
     return CTU_OK;

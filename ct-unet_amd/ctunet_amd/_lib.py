@@ -19,6 +19,13 @@ F = C.c_float
 D = C.c_double
 Z = C.c_size_t
 
+class PackJob(C.Structure):
+    """ctu_pack_job of include/ctunet_hip.h."""
+    _fields_ = [("w", C.c_void_p), ("wp", C.c_void_p), ("cinv", C.c_void_p), ("kind", C.c_int), ("Co", C.c_int),
+                ("Ci", C.c_int), ("k", C.c_int), ("rin_p", C.c_int), ("nout_p", C.c_int), ("mode", C.c_int),
+                ("layout", C.c_int)]
+
+
 # name -> (restype, argtypes); mirrors include/ctunet_hip.h one to one
 SIGNATURES = {
     "ctu_last_error": (C.c_char_p, []),
@@ -32,6 +39,7 @@ SIGNATURES = {
     "ctu_conv3d_packed_floats": (Z, [I, I, I, I]),
     "ctu_conv3d_num_blocks": (I, [I, I, I, I, I, I, I]),
     "ctu_pack_conv3d_weight": (I, [P, P, I, I, I, P, I, I, I, I, P]),
+    "ctu_pack_batch": (I, [P, I, P]),
     "ctu_conv3d_fwd": (I, [P, I, I, P, P, I, P, P, I, P, I, I, P, I, I, I, I, I, I, P]),
     "ctu_conv3d_wgrad_ws_floats": (Z, [I, I, I, I, I, I, I]),
     "ctu_conv3d_wgrad": (I, [P, I, I, P, P, I, P, I, I, P, P, I, I, P, P, I, I, I, I, I, P]),

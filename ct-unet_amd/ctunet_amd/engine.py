@@ -85,16 +85,33 @@ class UNetEngine:
 
     def _packed(self, name: str, w: torch.Tensor, kind: str, imap, rin_p: int, nout_p: int, mode: int,
                 layout: int = 0) -> torch.Tensor:
+        """MFMA-ordered copy of a weight tensor, cached by (tensor version, address).  The first request of a key
+        packs it on the spot and records the job; refresh_packs() then re-packs every recorded job whose weight
+        changed in ONE launch at the start of the next forward (into the same buffers: stable pointers)."""
         key = (name, kind, mode, rin_p, nout_p, layout)
         hit = self._pack_cache.get(key)
         ver = (w._version, w.data_ptr())
         if hit is not None and hit[0] == ver:
             return hit[1]
         wd = w.detach()
-        wp = ops.pack_conv_w(wd, imap, rin_p, nout_p, mode, layout) if kind == "conv" else \
-            ops.pack_convt_w(wd, imap, rin_p, nout_p, mode)
-        self._pack_cache[key] = (ver, wp)
+        wp = hit[1] if hit is not None else torch.empty(ops.packed_floats(kind, w.shape[2], rin_p, nout_p, layout),
+                                                        dtype=torch.float32, device=w.device)
+        ops.pack_batch([(kind, wd.contiguous(), wp, imap, rin_p, nout_p, mode, layout)])
+        self._pack_cache[key] = (ver, wp, imap)
         return wp
+
+    def refresh_packs(self, P: Dict[str, torch.Tensor]) -> None:
+        jobs = []
+        for key, ent in self._pack_cache.items():
+            name, kind, mode, rin_p, nout_p, layout = key
+            w = P.get(name + ".weight")
+            if w is None or w.device != ent[1].device:
+                continue
+            ver = (w._version, w.data_ptr())
+            if ent[0] != ver:
+                jobs.append((kind, w.detach().contiguous(), ent[1], ent[2], rin_p, nout_p, mode, layout))
+                self._pack_cache[key] = (ver, ent[1], ent[2])
+        ops.pack_batch(jobs)
 
     # ------------------------------------------------------------------ forward pieces
     def _conv_bn(self, P, x: CL, conv: str, bn: str, cin: int, cout: int, imap, out: CL, vec4: torch.Tensor,
@@ -174,6 +191,7 @@ class UNetEngine:
             raise ValueError("Expected more than 1 value per channel when training (centre block)")
         ctx = {"recs": {}, "levels": [], "training": training, "chk": chk} if save else None
         n_upd = 1 if training else 0
+        self.refresh_packs(P)
         self._nbt: List[torch.Tensor] = []
 
         x = x.contiguous()

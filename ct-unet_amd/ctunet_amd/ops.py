@@ -174,6 +174,29 @@ def pack_conv_w(w: torch.Tensor, cinv: Optional[torch.Tensor], rin_p: int, nout_
     return wp
 
 
+def packed_floats(kind: str, k: int, rin_p: int, nout_p: int, layout: int) -> int:
+    lib = _lib.load()
+    return lib.ctu_conv3d_packed_floats(k, rin_p, nout_p, layout) if kind == "conv" else \
+        lib.ctu_convt_packed_floats(rin_p, nout_p)
+
+
+def pack_batch(jobs) -> None:
+    """jobs: list of (kind 'conv'|'convt', w, wp, cinv, rin_p, nout_p, mode, layout): every job in ONE launch."""
+    if not jobs:
+        return
+    arr = (_lib.PackJob * len(jobs))()
+    for a, (kind, w, wp, cinv, rin_p, nout_p, mode, layout) in zip(arr, jobs):
+        _need_cuda(w, "weight")
+        assert w.is_contiguous()
+        a.w, a.wp, a.cinv = w.data_ptr(), wp.data_ptr(), (None if cinv is None else cinv.data_ptr())
+        if kind == "conv":
+            a.kind, a.Co, a.Ci, a.k = 0, w.shape[0], w.shape[1], w.shape[2]
+        else:
+            a.kind, a.Ci, a.Co, a.k = 1, w.shape[0], w.shape[1], 2
+        a.rin_p, a.nout_p, a.mode, a.layout = rin_p, nout_p, mode, layout
+    _lib.check(_lib.load().ctu_pack_batch(arr, len(jobs), _stream()), "pack_batch")
+
+
 def conv_num_blocks(dims, nout_p: int, layout: int = 0, k: int = 3) -> int:
     """Rows of the BN partial-sum buffer a conv3d_fwd call with this geometry writes."""
     n, d, h, w = dims

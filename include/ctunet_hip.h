@@ -84,6 +84,17 @@ int ctu_pack_conv3d_weight(const float* w, float* wp, int Co, int Ci, int k,
                            const int32_t* cinv, int rin_p, int nout_p, int mode, int layout,
                            void* stream);
 
+/* Every weight tensor of a network in ONE launch (the job table travels in the kernel arguments).
+ * jobs: HOST array; kind 0 = Conv3d (ctu_pack_conv3d_weight semantics: w [Co,Ci,k,k,k], k, layout),
+ * kind 1 = ConvTranspose3d (ctu_pack_convt_weight semantics: w [Ci,Co,2,2,2]; k/layout ignored). */
+typedef struct {
+    const float* w;
+    float* wp;
+    const int32_t* cinv;
+    int kind, Co, Ci, k, rin_p, nout_p, mode, layout;
+} ctu_pack_job;
+int ctu_pack_batch(const ctu_pack_job* jobs, int n, void* stream);
+
 /* Implicit-GEMM 3D convolution on MFMA (v_mfma_f32_16x16x4_f32), stride 1, zero padding
  * (k-1)/2, NDHWC.  out[v, o] = bias[o] + sum_{tap,r} A(in[v+tap, r]) * wp[tap, r, o] with
  * A() the lazy-BN input transform.  Used for nn.Conv3d forward (models.py call sites
