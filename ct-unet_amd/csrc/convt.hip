@@ -20,6 +20,7 @@ struct CtP {
     const float* bias;
     float* out;              // fwd: output on the 2x grid; bwd-data: gin [V][out_cs]
     int in_cs, rin_p, in_relu, out_cs, nout_p, nbias;
+    int ntt_total;           // 16-wide output tiles in the packed weights (power of two)
     int N, D, H, W;          // coarse (input-side) grid
     int64_t nvox;            // N*D*H*W
 };
@@ -50,7 +51,8 @@ __global__ __launch_bounds__(256) void convt2_kernel(CtP p, int tps) {
     const int ng = p.rin_p >> 3;
     const int nq = p.rin_p >> 2;                      // float4 per voxel
     const bool has_xf = p.in_scale != nullptr;
-    const int wfl = ng * NTT * 128;
+    const int wfl = ng * NTT * 128;                   // this block's share of one tap: NTT of the ntt_total tiles
+    const int by = blockIdx.y;
     const int64_t vme = v0 + wave * 16 + m;           // this lane's voxel (column of the MFMA tile)
 
     f32x4 acc[NTT];
@@ -76,10 +78,13 @@ __global__ __launch_bounds__(256) void convt2_kernel(CtP p, int tps) {
             }
         }
         {
-            const float* wsrc = p.wp + (size_t)tap0 * wfl;
+            // packed weights: [tap][g][ntt_total][128]; this block takes tiles by*NTT .. by*NTT+NTT-1
             const int tot = tps * wfl;
-            for (int i = tid * 4; i < tot; i += 1024)
-                *reinterpret_cast<float4*>(&sW[i]) = *reinterpret_cast<const float4*>(wsrc + i);
+            for (int i = tid * 4; i < tot; i += 1024) {
+                const int tl = i / wfl, rem = i % wfl, g = rem / (NTT * 128), r = rem % (NTT * 128);
+                *reinterpret_cast<float4*>(&sW[i]) = *reinterpret_cast<const float4*>(
+                    p.wp + ((size_t)((tap0 + tl) * ng + g) * p.ntt_total + by * NTT) * 128 + r);
+            }
         }
         if (MODE == 0) __syncthreads();
         for (int tl = 0; tl < tps; ++tl) {
@@ -116,7 +121,7 @@ __global__ __launch_bounds__(256) void convt2_kernel(CtP p, int tps) {
                 float* orow = p.out + fine_vox(vme, p.D, p.H, p.W, tap) * p.out_cs;
 #pragma unroll
                 for (int nt = 0; nt < NTT; ++nt) {
-                    const int co = nt * 16 + kq * 4;            // this lane: channels co .. co+3 of voxel vme
+                    const int co = (by * NTT + nt) * 16 + kq * 4;   // this lane: channels co .. co+3 of voxel vme
                     if (co < p.nout_p) {
                         float4 o;
                         o.x = acc[nt][0] + ((p.bias && co + 0 < p.nbias) ? p.bias[co + 0] : 0.f);
@@ -133,7 +138,7 @@ __global__ __launch_bounds__(256) void convt2_kernel(CtP p, int tps) {
         float* orow = p.out + (size_t)vme * p.out_cs;
 #pragma unroll
         for (int nt = 0; nt < NTT; ++nt) {
-            const int co = nt * 16 + kq * 4;
+            const int co = (by * NTT + nt) * 16 + kq * 4;
             if (co < p.nout_p)
                 *reinterpret_cast<float4*>(orow + co) = make_float4(acc[nt][0], acc[nt][1], acc[nt][2], acc[nt][3]);
         }
@@ -165,92 +170,140 @@ struct CtWgP {
     int ntiles, n_ci_t;
 };
 
-// M = 16 input channels, N = 16 output channels, K = coarse voxels; one accumulator per tap.
-__global__ __launch_bounds__(256) void convt2_wgrad_kernel(CtWgP p) {
-    __shared__ __attribute__((aligned(16))) float sA[64 * 16];
-    __shared__ __attribute__((aligned(16))) float sG[8 * 64 * 16];
+// M = MI x 16 input channels, N = NJ x 16 output channels, K = coarse voxels; one accumulator per (tap, tile pair).
+// A block with 2 x 2 tiles reads the (8x larger) fine-grid gradient ONCE for 32 x 32 channels.  The bias gradient
+// (sum of gout over voxels) is accumulated by the staging threads from the values they load anyway.
+template <int MI, int NJ>
+__global__ __launch_bounds__(256) void convt2_wgrad_kernel(CtWgP p, float* __restrict__ wsb) {
+    constexpr int CA = 16 * MI, CG = 16 * NJ, QA = 4 * MI, QG = 4 * NJ;
+    __shared__ __attribute__((aligned(16))) float sA[64 * CA];
+    __shared__ __attribute__((aligned(16))) float sG[8 * 64 * CG];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, kq = lane >> 4;
-    const int cit = blockIdx.y % p.n_ci_t, cot = blockIdx.y / p.n_ci_t;
-    const int ci0 = cit * 16, co0 = cot * 16;
-    const int quad = tid & 3;
-    const bool a_ok = (ci0 + quad * 4) < p.cin_p, g_ok = (co0 + quad * 4) < p.cout_p;
+    const int cig = blockIdx.y % p.n_ci_t, cog = blockIdx.y / p.n_ci_t;
+    const int ci0 = cig * CA, co0 = cog * CG;
+    const int qa = tid % QA, qg = tid % QG;                    // 256 % QA == 0: fixed channel quad per thread
+    const bool a_ok = (ci0 + qa * 4) < p.cin_p, g_ok = (co0 + qg * 4) < p.cout_p;
     const bool has_xf = p.in_scale != nullptr;
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
     if (has_xf && a_ok) {
-        sc = *reinterpret_cast<const float4*>(p.in_scale + ci0 + quad * 4);
-        sh = *reinterpret_cast<const float4*>(p.in_shift + ci0 + quad * 4);
+        sc = *reinterpret_cast<const float4*>(p.in_scale + ci0 + qa * 4);
+        sh = *reinterpret_cast<const float4*>(p.in_shift + ci0 + qa * 4);
     }
-    f32x4 acc[8];
+    f32x4 acc[8][MI][NJ];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int a = 0; a < MI; ++a)
+#pragma unroll
+            for (int b = 0; b < NJ; ++b) acc[t][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 gsum = make_float4(0.f, 0.f, 0.f, 0.f);
 
     for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
         const int64_t v0 = (int64_t)tile * 64;
         __syncthreads();
-        {
-            const int vl = tid >> 2;
+        for (int it = tid; it < 64 * QA; it += 256) {
+            const int vl = it / QA;
             const int64_t v = v0 + vl;
             float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
             if (a_ok && v < p.nvox) {
-                val = *reinterpret_cast<const float4*>(p.in + (size_t)v * p.in_cs + ci0 + quad * 4);
+                val = *reinterpret_cast<const float4*>(p.in + (size_t)v * p.in_cs + ci0 + qa * 4);
                 if (has_xf) val = xform4(val, sc, sh, p.in_relu);
             }
-            *reinterpret_cast<float4*>(&sA[vl * 16 + quad * 4]) = val;
-#pragma unroll
-            for (int tap = 0; tap < 8; ++tap) {
-                float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (g_ok && v < p.nvox)
-                    gv = *reinterpret_cast<const float4*>(p.g + fine_vox(v, p.D, p.H, p.W, tap) * p.g_cs + co0 +
-                                                          quad * 4);
-                *reinterpret_cast<float4*>(&sG[(tap * 64 + vl) * 16 + quad * 4]) = gv;
-            }
+            *reinterpret_cast<float4*>(&sA[vl * CA + qa * 4]) = val;
+        }
+        for (int it = tid; it < 8 * 64 * QG; it += 256) {
+            const int r = it / QG, tap = r >> 6, vl = r & 63;
+            const int64_t v = v0 + vl;
+            float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (g_ok && v < p.nvox)
+                gv = *reinterpret_cast<const float4*>(p.g + fine_vox(v, p.D, p.H, p.W, tap) * p.g_cs + co0 + qg * 4);
+            *reinterpret_cast<float4*>(&sG[r * CG + qg * 4]) = gv;
+            gsum.x += gv.x; gsum.y += gv.y; gsum.z += gv.z; gsum.w += gv.w;
         }
         __syncthreads();
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int vl = (wave * 4 + ks) * 4 + kq;
-            const float a = sA[vl * 16 + i];
+            float a[MI];
+#pragma unroll
+            for (int x = 0; x < MI; ++x) a[x] = sA[vl * CA + x * 16 + i];
 #pragma unroll
             for (int tap = 0; tap < 8; ++tap) {
-                const float b = sG[(tap * 64 + vl) * 16 + i];
-                acc[tap] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[tap], 0, 0, 0);
+#pragma unroll
+                for (int y = 0; y < NJ; ++y) {
+                    const float b = sG[(tap * 64 + vl) * CG + y * 16 + i];
+#pragma unroll
+                    for (int x = 0; x < MI; ++x)
+                        acc[tap][x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[x], b, acc[tap][x][y], 0, 0, 0);
+                }
             }
         }
     }
-    // 4 waves -> one slab [8][16 ci][16 co] per block, summed through sG (8192 floats = 4 waves x 8 x 256)
-    __syncthreads();
+    // 4 waves -> one slab [8][MI][NJ][16 ci][16 co] per block, through sG (8 taps per round need 4*8*MI*NJ*256 floats)
+    float* dst = p.ws + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (8 * MI * NJ * 256);
+    constexpr int TPR = (8 * 64 * CG) / (4 * MI * NJ * 256);        // taps per round that fit in sG
+    static_assert(TPR >= 1, "reduction scratch");
+    for (int t0 = 0; t0 < 8; t0 += TPR) {
+        __syncthreads();
 #pragma unroll
-    for (int t = 0; t < 8; ++t)
+        for (int t = 0; t < 8; ++t)
+            if (t >= t0 && t < t0 + TPR)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sG[(wave * 8 + t) * 256 + (kq * 4 + r) * 16 + i] = acc[t][r];
-    __syncthreads();
-    float* dst = p.ws + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (8 * 256);
-    for (int e = tid; e < 8 * 256; e += 256)
-        dst[e] = (sG[e] + sG[2048 + e]) + (sG[4096 + e] + sG[6144 + e]);
+                for (int x = 0; x < MI; ++x)
+#pragma unroll
+                    for (int y = 0; y < NJ; ++y)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            sG[((wave * TPR + (t - t0)) * MI * NJ + x * NJ + y) * 256 + (kq * 4 + r) * 16 + i] = acc[t][x][y][r];
+        __syncthreads();
+        const int nel = ((8 - t0) < TPR ? (8 - t0) : TPR) * MI * NJ * 256, stride = TPR * MI * NJ * 256;
+        for (int e = tid; e < nel; e += 256)
+            dst[t0 * MI * NJ * 256 + e] = (sG[e] + sG[stride + e]) + (sG[2 * stride + e] + sG[3 * stride + e]);
+    }
+    // bias-gradient partials: threads with the same channel quad, only the blocks of the first ci group
+    if (cig == 0 && wsb) {
+        __syncthreads();
+        *reinterpret_cast<float4*>(&sA[tid * 4]) = gsum;
+        __syncthreads();
+        if (tid < CG) {
+            const int q = tid >> 2, c = tid & 3;
+            float t = 0.f;
+            for (int k = q; k < 256; k += QG) t += sA[k * 4 + c];
+            wsb[((size_t)cog * gridDim.x + blockIdx.x) * CG + tid] = t;
+        }
+    }
 }
 
-// dw[ci][co][tap]: a block owns 64 consecutive outputs (co fastest) and sums the gx slabs of their
-// (ci-tile, co-tile) with 4 thread groups in a fixed order.
-__global__ __launch_bounds__(1024) void convt2_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
-                                                                  int Ci, int Co, const int32_t* __restrict__ imap,
-                                                                  int n_ci_t, int gx) {
+// dw[ci][co][tap]: a block owns 64 consecutive outputs (co fastest) and sums the gx slabs of their tile group.
+template <int MI, int NJ>
+__global__ __launch_bounds__(1024) void convt2_wgrad_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ wsb,
+                                                                   float* __restrict__ dw, float* __restrict__ dbias, int Ci,
+                                                                   int Co, const int32_t* __restrict__ imap, int n_ci_t,
+                                                                   int gx) {
+    constexpr int CA = 16 * MI, CG = 16 * NJ, SL = 8 * MI * NJ * 256;
     __shared__ float red[RPARTS][64];
     const int e = threadIdx.x & 63, part = threadIdx.x >> 6;
     const int idx = blockIdx.x * 64 + e;
     float s = 0.f;
-    const bool ok = idx < Ci * Co * 8;
+    const int ndw = Ci * Co * 8;
+    const bool ok = idx < ndw, okb = dbias && idx >= ndw && idx < ndw + Co;
     int co = 0, ci = 0, tap = 0;
     if (ok) {
         co = idx % Co; ci = (idx / Co) % Ci; tap = idx / (Co * Ci);
         const int cip = imap ? imap[ci] : ci;      // logical -> padded position
-        const int pair = (co >> 4) * n_ci_t + (cip >> 4);
-        const float* src = ws + ((size_t)pair * gx) * (8 * 256) + tap * 256 + (cip & 15) * 16 + (co & 15);
-        for (int k = part; k < gx; k += RPARTS) s += src[(size_t)k * (8 * 256)];
+        const int cig = cip / CA, cog = co / CG, x = (cip % CA) >> 4, y = (co % CG) >> 4;
+        const float* src = ws + ((size_t)(cog * n_ci_t + cig) * gx) * SL + ((tap * MI + x) * NJ + y) * 256 + (cip & 15) * 16 + (co & 15);
+        for (int k = part; k < gx; k += RPARTS) s += src[(size_t)k * SL];
+    } else if (okb) {
+        co = idx - ndw;
+        const float* src = wsb + ((size_t)(co / CG) * gx) * CG + co % CG;
+        for (int k = part; k < gx; k += RPARTS) s += src[(size_t)k * CG];
     }
     red[part][e] = s;
     __syncthreads();
     if (part == 0 && ok) dw[((size_t)ci * Co + co) * 8 + tap] = red_total(red, e);
+    if (part == 0 && okb) dbias[co] = red_total(red, e);
 }
 
 inline int ct_wgrad_gx(int ntiles, int pairs) {
@@ -262,21 +315,26 @@ inline int ct_wgrad_gx(int ntiles, int pairs) {
 
 template <int MODE>
 int launch_convt(const CtP& p, hipStream_t st, const char* name) {
-    const int ntt = pick_ntt(p.nout_p);
+    const int ntt_total = pick_ntt(p.nout_p);
+    const unsigned grid = (unsigned)ceil_div64(p.nvox, 64);
+    int ntt = ntt_total;                                   // tiles per block: split across blockIdx.y until the grid fills the chip
+    while (ntt > 1 && (long)grid * (ntt_total / ntt) < 256) ntt >>= 1;
     const size_t a_b = (size_t)64 * (p.rin_p + 4) * sizeof(float);
-    const size_t w_b = (size_t)(p.rin_p / 8) * ntt * 128 * sizeof(float);      // one tap's packed weights
+    const size_t w_b = (size_t)(p.rin_p / 8) * ntt * 128 * sizeof(float);      // one tap's share of the packed weights
     int tps = 8;                                                                // taps staged per barrier pair
     while (tps > 1 && a_b + tps * w_b > 72 * 1024) tps >>= 1;
     const size_t lds = a_b + tps * w_b;
     CTU_REQUIRE(lds <= 160 * 1024, "%s: rin_p=%d nout_p=%d needs %zu B of LDS", name, p.rin_p, p.nout_p, lds);
     CTU_REQUIRE(p.out_cs % 4 == 0 && ((uintptr_t)p.out & 15) == 0, "%s: output must be 16-byte aligned", name);
-    const unsigned grid = (unsigned)ceil_div64(p.nvox, 64);
+    CtP q = p;
+    q.ntt_total = ntt_total;
+    const dim3 grid2(grid, ntt_total / ntt);
 #define CT_LAUNCH(N_)                                                                                             \
     do {                                                                                                          \
         if (lds > 64 * 1024)                                                                                      \
             (void)hipFuncSetAttribute((const void*)convt2_kernel<N_, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                       (int)lds);                                                                  \
-        convt2_kernel<N_, MODE><<<grid, 256, lds, st>>>(p, tps);                                                  \
+        convt2_kernel<N_, MODE><<<grid2, 256, lds, st>>>(q, tps);                                                 \
     } while (0)
     switch (ntt) {
         case 1: CT_LAUNCH(1); break;
@@ -338,13 +396,30 @@ extern "C" int ctu_convt2_bwd_data(const float* gout, int g_cs, int rout_p, cons
     return launch_convt<1>(p, (hipStream_t)stream, "convt2_bwd_data");
 }
 
+static void ct_wgrad_geom(int64_t nvox, int cin_p, int cout_p, int* mi, int* nj, int* n_ci_t, int* n_co_t, int* gx) {
+    *mi = cin_p > 16 ? 2 : 1;
+    *nj = cout_p > 16 ? 2 : 1;
+    *n_ci_t = ceil_div(cin_p, 16 * *mi);
+    *n_co_t = ceil_div(cout_p, 16 * *nj);
+    *gx = ct_wgrad_gx((int)ceil_div64(nvox, 64), *n_ci_t * *n_co_t);
+}
+
 extern "C" size_t ctu_convt2_wgrad_ws_floats(int N, int D, int H, int W, int cin_p, int cout_p) {
-    const int64_t nvox = (int64_t)N * D * H * W;
-    const int ntiles = (int)ceil_div64(nvox, 64);
-    const int pairs = ceil_div(cin_p, 16) * ceil_div(cout_p, 16);
-    const size_t slabs = (size_t)pairs * ct_wgrad_gx(ntiles, pairs) * 8 * 256;
-    const size_t bsum = (size_t)ctu_channel_sum_num_blocks(nvox * 8) * cout_p;
-    return slabs > bsum ? slabs : bsum;
+    int mi, nj, nci, nco, gx;
+    ct_wgrad_geom((int64_t)N * D * H * W, cin_p, cout_p, &mi, &nj, &nci, &nco, &gx);
+    return (size_t)nci * nco * gx * 8 * mi * nj * 256 + (size_t)nco * gx * 16 * nj;
+}
+
+template <int MI, int NJ>
+static int launch_ct_wgrad(CtWgP p, float* dw, float* dbias, int Ci, int Co, const int32_t* imap, int n_co_t, int gx,
+                           hipStream_t st) {
+    float* wsb = p.ws + (size_t)p.n_ci_t * n_co_t * gx * 8 * MI * NJ * 256;
+    convt2_wgrad_kernel<MI, NJ><<<dim3(gx, p.n_ci_t * n_co_t), 256, 0, st>>>(p, dbias ? wsb : nullptr);
+    CTU_CHECK_LAUNCH("convt2_wgrad");
+    convt2_wgrad_reduce_kernel<MI, NJ><<<ceil_div(Ci * Co * 8 + Co, 64), 64 * RPARTS, 0, st>>>(p.ws, wsb, dw, dbias, Ci, Co, imap,
+                                                                                           p.n_ci_t, gx);
+    CTU_CHECK_LAUNCH("convt2_wgrad_reduce");
+    return CTU_OK;
 }
 
 extern "C" int ctu_convt2_wgrad(const float* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
@@ -359,13 +434,10 @@ extern "C" int ctu_convt2_wgrad(const float* in, int in_cs, int cin_p, const flo
     p.in_cs = in_cs; p.cin_p = cin_p; p.in_relu = in_relu; p.g_cs = g_cs; p.cout_p = cout_p;
     p.N = N; p.D = D; p.H = H; p.W = W; p.nvox = (int64_t)N * D * H * W;
     p.ntiles = (int)ceil_div64(p.nvox, 64);
-    p.n_ci_t = ceil_div(cin_p, 16);
-    const int pairs = p.n_ci_t * ceil_div(cout_p, 16);
-    const int gx = ct_wgrad_gx(p.ntiles, pairs);
-    convt2_wgrad_kernel<<<dim3(gx, pairs), 256, 0, st>>>(p);
-    CTU_CHECK_LAUNCH("convt2_wgrad");
-    convt2_wgrad_reduce_kernel<<<ceil_div(Ci * Co * 8, 64), 64 * RPARTS, 0, st>>>(ws, dw, Ci, Co, imap, p.n_ci_t, gx);
-    CTU_CHECK_LAUNCH("convt2_wgrad_reduce");
-    if (dbias) return ctu_channel_sum(gout, g_cs, cout_p, p.nvox * 8, ws, dbias, Co, stream);
-    return CTU_OK;
+    int mi, nj, n_co_t, gx;
+    ct_wgrad_geom(p.nvox, cin_p, cout_p, &mi, &nj, &p.n_ci_t, &n_co_t, &gx);
+    if (mi == 1 && nj == 1) return launch_ct_wgrad<1, 1>(p, dw, dbias, Ci, Co, imap, n_co_t, gx, st);
+    if (mi == 1) return launch_ct_wgrad<1, 2>(p, dw, dbias, Ci, Co, imap, n_co_t, gx, st);
+    if (nj == 1) return launch_ct_wgrad<2, 1>(p, dw, dbias, Ci, Co, imap, n_co_t, gx, st);
+    return launch_ct_wgrad<2, 2>(p, dw, dbias, Ci, Co, imap, n_co_t, gx, st);
 }
