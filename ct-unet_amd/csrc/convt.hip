@@ -25,13 +25,17 @@ struct CtP {
     int64_t nvox;            // N*D*H*W
 };
 
-__device__ __forceinline__ size_t fine_vox(int64_t v, int D, int H, int W, int tap) {
-    const int w = (int)(v % W); int64_t t = v / W;
-    const int h = (int)(t % H); t /= H;
-    const int d = (int)(t % D);
-    const int64_t n = t / D;
-    return (((size_t)n * (2 * D) + 2 * d + (tap >> 2)) * (2 * H) + 2 * h + ((tap >> 1) & 1)) * (2 * W) + 2 * w +
-           (tap & 1);
+// Fine-grid voxel index of tap 0 for coarse voxel v (32-bit division: emulated 64-bit div/mod by runtime sizes is
+// ~10x more expensive and used to dominate these HBM-bound kernels), and the per-tap offset on the fine grid.
+__device__ __forceinline__ size_t fine_base(int64_t v, int D, int H, int W) {
+    const unsigned u = (unsigned)v;
+    const unsigned w = u % (unsigned)W, t1 = u / (unsigned)W;
+    const unsigned h = t1 % (unsigned)H, t2 = t1 / (unsigned)H;
+    const unsigned d = t2 % (unsigned)D, n = t2 / (unsigned)D;
+    return (((size_t)n * (2 * D) + 2 * d) * (2 * H) + 2 * h) * (size_t)(2 * W) + 2 * w;
+}
+__device__ __forceinline__ int tap_off(int tap, int H, int W) {
+    return ((tap >> 2) * (2 * H) + ((tap >> 1) & 1)) * (2 * W) + (tap & 1);
 }
 
 // MODE 0: forward (A staged once, one store per tap).  MODE 1: data gradient (A gathered per tap
@@ -54,6 +58,18 @@ __global__ __launch_bounds__(256) void convt2_kernel(CtP p, int tps) {
     const int wfl = ng * NTT * 128;                   // this block's share of one tap: NTT of the ntt_total tiles
     const int by = blockIdx.y;
     const int64_t vme = v0 + wave * 16 + m;           // this lane's voxel (column of the MFMA tile)
+    const size_t fme = vme < p.nvox ? fine_base(vme, p.D, p.H, p.W) : 0;
+    // MODE 1 staging: this thread's gather items (voxel of item k = (tid + 256 k) / nq) and their fine-grid bases
+    constexpr int GMAX = 8;                           // 64 * nq / 256 <= 8 for rin_p <= 128
+    size_t gbase[GMAX];
+    if (MODE == 1) {
+#pragma unroll
+        for (int k = 0; k < GMAX; ++k) {
+            const int it = tid + k * 256;
+            const int64_t v = v0 + it / nq;
+            gbase[k] = (it < 64 * nq && v < p.nvox) ? fine_base(v, p.D, p.H, p.W) : (size_t)-1;
+        }
+    }
 
     f32x4 acc[NTT];
 #pragma unroll
@@ -92,13 +108,17 @@ __global__ __launch_bounds__(256) void convt2_kernel(CtP p, int tps) {
             if (MODE == 1) {
                 // gather this tap's fine-grid voxels (the block's 64 coarse voxels) into sA
                 __syncthreads();
-                for (int it = tid; it < 64 * nq; it += 256) {
-                    const int vl = it / nq, qd = it % nq;
-                    const int64_t v = v0 + vl;
-                    float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (v < p.nvox)
-                        val = *reinterpret_cast<const float4*>(p.in + fine_vox(v, p.D, p.H, p.W, tap) * p.in_cs + qd * 4);
-                    *reinterpret_cast<float4*>(&sA[vl * AS + qd * 4]) = val;
+                const int toff = tap_off(tap, p.H, p.W);
+#pragma unroll
+                for (int k = 0; k < GMAX; ++k) {
+                    const int it = tid + k * 256;
+                    if (it < 64 * nq) {
+                        const int vl = it / nq, qd = it % nq;
+                        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (gbase[k] != (size_t)-1)
+                            val = *reinterpret_cast<const float4*>(p.in + (gbase[k] + toff) * p.in_cs + qd * 4);
+                        *reinterpret_cast<float4*>(&sA[vl * AS + qd * 4]) = val;
+                    }
                 }
                 __syncthreads();
             } else {
@@ -118,7 +138,7 @@ __global__ __launch_bounds__(256) void convt2_kernel(CtP p, int tps) {
                 }
             }
             if (MODE == 0 && vme < p.nvox) {
-                float* orow = p.out + fine_vox(vme, p.D, p.H, p.W, tap) * p.out_cs;
+                float* orow = p.out + (fme + tap_off(tap, p.H, p.W)) * p.out_cs;
 #pragma unroll
                 for (int nt = 0; nt < NTT; ++nt) {
                     const int co = (by * NTT + nt) * 16 + kq * 4;   // this lane: channels co .. co+3 of voxel vme
@@ -212,14 +232,20 @@ __global__ __launch_bounds__(256) void convt2_wgrad_kernel(CtWgP p, float* __res
             }
             *reinterpret_cast<float4*>(&sA[vl * CA + qa * 4]) = val;
         }
-        for (int it = tid; it < 8 * 64 * QG; it += 256) {
-            const int r = it / QG, tap = r >> 6, vl = r & 63;
+        // a thread owns channel quad qg of QG/4 voxels (vl = tid / QG + j * (256 / QG)); one 32-bit index decode per voxel
+#pragma unroll
+        for (int j = 0; j < QG / 4; ++j) {
+            const int vl = tid / QG + j * (256 / QG);
             const int64_t v = v0 + vl;
-            float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (g_ok && v < p.nvox)
-                gv = *reinterpret_cast<const float4*>(p.g + fine_vox(v, p.D, p.H, p.W, tap) * p.g_cs + co0 + qg * 4);
-            *reinterpret_cast<float4*>(&sG[r * CG + qg * 4]) = gv;
-            gsum.x += gv.x; gsum.y += gv.y; gsum.z += gv.z; gsum.w += gv.w;
+            const bool ok = g_ok && v < p.nvox;
+            const float* gsrc = p.g + (ok ? fine_base(v, p.D, p.H, p.W) : 0) * p.g_cs + co0 + qg * 4;
+#pragma unroll
+            for (int tap = 0; tap < 8; ++tap) {
+                float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok) gv = *reinterpret_cast<const float4*>(gsrc + (size_t)tap_off(tap, p.H, p.W) * p.g_cs);
+                *reinterpret_cast<float4*>(&sG[(tap * 64 + vl) * CG + qg * 4]) = gv;
+                gsum.x += gv.x; gsum.y += gv.y; gsum.z += gv.z; gsum.w += gv.w;
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -326,6 +352,7 @@ int launch_convt(const CtP& p, hipStream_t st, const char* name) {
     const size_t lds = a_b + tps * w_b;
     CTU_REQUIRE(lds <= 160 * 1024, "%s: rin_p=%d nout_p=%d needs %zu B of LDS", name, p.rin_p, p.nout_p, lds);
     CTU_REQUIRE(p.out_cs % 4 == 0 && ((uintptr_t)p.out & 15) == 0, "%s: output must be 16-byte aligned", name);
+    CTU_REQUIRE(p.nvox < (1LL << 31), "%s: more than 2^31 coarse voxels", name);
     CtP q = p;
     q.ntt_total = ntt_total;
     const dim3 grid2(grid, ntt_total / ntt);
@@ -434,6 +461,7 @@ extern "C" int ctu_convt2_wgrad(const float* in, int in_cs, int cin_p, const flo
     p.in_cs = in_cs; p.cin_p = cin_p; p.in_relu = in_relu; p.g_cs = g_cs; p.cout_p = cout_p;
     p.N = N; p.D = D; p.H = H; p.W = W; p.nvox = (int64_t)N * D * H * W;
     p.ntiles = (int)ceil_div64(p.nvox, 64);
+    CTU_REQUIRE(p.nvox < (1LL << 31), "convt2_wgrad: more than 2^31 coarse voxels");
     int mi, nj, n_co_t, gx;
     ct_wgrad_geom(p.nvox, cin_p, cout_p, &mi, &nj, &p.n_ci_t, &n_co_t, &gx);
     if (mi == 1 && nj == 1) return launch_ct_wgrad<1, 1>(p, dw, dbias, Ci, Co, imap, n_co_t, gx, st);
