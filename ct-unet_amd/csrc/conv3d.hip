@@ -40,7 +40,9 @@ __host__ __device__ inline void pick_tile(int W, int* td, int* th, int* tw) {
 
 constexpr int VS = 12;   // LDS floats per halo voxel (8 channels + 4 pad)
 
-template <int KS, int NT, int TD, int TH, int TW>
+// CCH = 8-channel chunks staged per barrier pair (4 on the small deep-level volumes, where the per-stage latency,
+// not the matrix pipe, sets the time).
+template <int KS, int NT, int TD, int TH, int TW, int CCH = 1>
 __global__ __launch_bounds__(256) void conv3d_fwd_kernel(ConvP p) {
     constexpr int PAD = (KS - 1) / 2;
     constexpr int HD = TD + KS - 1, HH = TH + KS - 1, HW = TW + KS - 1;
@@ -51,11 +53,14 @@ __global__ __launch_bounds__(256) void conv3d_fwd_kernel(ConvP p) {
     constexpr int MT = NMT / 4;
     constexpr int STAPS = Taps<KS>::STAPS, NSTAGE = Taps<KS>::NSTAGE;
     constexpr int WFL = STAPS * NT * 128;
-    constexpr int AITEMS = HV * 2;
+    constexpr int VSL = 8 * CCH + 4;                  // LDS floats per halo voxel
+    constexpr int AQ = 2 * CCH;                       // float4 per halo voxel
+    constexpr int AITEMS = HV * AQ;
     constexpr int AITER = (AITEMS + 255) / 256;
+    static_assert(CCH == 1 || NSTAGE == 1, "multi-chunk staging needs all taps' weights in LDS at once");
 
-    __shared__ __attribute__((aligned(16))) float sA[HV * VS];
-    __shared__ __attribute__((aligned(16))) float sW[WFL];
+    __shared__ __attribute__((aligned(16))) float sA[HV * VSL];
+    __shared__ __attribute__((aligned(16))) float sW[CCH * WFL];
     __shared__ float sRed[4 * NT * 16 * 2];
 
     const int tid = threadIdx.x;
@@ -76,7 +81,7 @@ __global__ __launch_bounds__(256) void conv3d_fwd_kernel(ConvP p) {
     for (int mt = 0; mt < MT; ++mt) {
         const int vt = (wave * MT + mt) * 16 + m;
         const int tw = vt % TW, th = (vt / TW) % TH, td = vt / (TW * TH);
-        abase[mt] = ((td * HH + th) * HW + tw) * VS + kq * 2;
+        abase[mt] = ((td * HH + th) * HW + tw) * VSL + kq * 2;
     }
     const int bbase = kq * 32 + m * 2;
 
@@ -87,11 +92,11 @@ __global__ __launch_bounds__(256) void conv3d_fwd_kernel(ConvP p) {
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nchunk = p.rin_p >> 3;
-    const int half = tid & 1;
+    const int half = tid % AQ;                        // this thread's channel quad inside a stage (256 % AQ == 0)
     const bool has_xf = p.in_scale != nullptr;
     const int n16 = p.n16;
 
-    for (int c = 0; c < nchunk; ++c) {
+    for (int c = 0; c < nchunk; c += CCH) {
         float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
         if (has_xf) {
             sc = *reinterpret_cast<const float4*>(p.in_scale + c * 8 + half * 4);
@@ -103,7 +108,7 @@ __global__ __launch_bounds__(256) void conv3d_fwd_kernel(ConvP p) {
 #pragma unroll
         for (int it = 0; it < AITER; ++it) {
             const int i = tid + it * 256;
-            const int v = i >> 1;
+            const int v = i / AQ;
             const int pw = v % HW, t2 = v / HW, ph = t2 % HH, pd = t2 / HH;
             const int gd = d0 + pd - PAD, gh = h0 + ph - PAD, gw = w0 + pw - PAD;
             float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -118,30 +123,33 @@ __global__ __launch_bounds__(256) void conv3d_fwd_kernel(ConvP p) {
 #pragma unroll
         for (int it = 0; it < AITER; ++it) {
             const int i = tid + it * 256;
-            if (i < AITEMS) *reinterpret_cast<float4*>(&sA[(i >> 1) * VS + half * 4]) = vals[it];
+            if (i < AITEMS) *reinterpret_cast<float4*>(&sA[(i / AQ) * VSL + half * 4]) = vals[it];
         }
         for (int s = 0; s < NSTAGE; ++s) {
             if (s > 0) __syncthreads();
             // packed weights: [chunk][stage][tap][n16 tile][128]; this block takes tiles by*NT .. by*NT+NT-1
-            const float* wsrc = p.wp + ((size_t)c * NSTAGE + s) * STAPS * n16 * 128 + (size_t)by * NT * 128;
-            for (int i = tid * 4; i < WFL; i += 1024) {
-                const int ts = i / (NT * 128), r = i % (NT * 128);
+            for (int i = tid * 4; i < CCH * WFL; i += 1024) {
+                const int g = i / WFL, j = i % WFL;
+                const float* wsrc = p.wp + ((size_t)(c + g) * NSTAGE + s) * STAPS * n16 * 128 + (size_t)by * NT * 128;
+                const int ts = j / (NT * 128), r = j % (NT * 128);
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (by * NT * 128 + r < n16 * 128) v = *reinterpret_cast<const float4*>(wsrc + (size_t)ts * n16 * 128 + r);
                 *reinterpret_cast<float4*>(&sW[i]) = v;
             }
             __syncthreads();
+#pragma unroll 1
+            for (int g = 0; g < CCH; ++g)
 #pragma unroll
             for (int ts = 0; ts < STAPS; ++ts) {
                 // tap (kd,kh,kw): with NSTAGE > 1 the stage index is kd
                 const int kd = (NSTAGE == 1) ? ts / (KS * KS) : s;
                 const int kh = (NSTAGE == 1) ? (ts / KS) % KS : ts / KS;
                 const int kw = ts % KS;
-                const int toff = ((kd * HH + kh) * HW + kw) * VS;
+                const int toff = ((kd * HH + kh) * HW + kw) * VSL + g * 8;
                 float2 b[NT];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    b[nt] = *reinterpret_cast<const float2*>(&sW[(ts * NT + nt) * 128 + bbase]);
+                    b[nt] = *reinterpret_cast<const float2*>(&sW[g * WFL + (ts * NT + nt) * 128 + bbase]);
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     const float2 a = *reinterpret_cast<const float2*>(&sA[abase[mt] + toff]);
@@ -988,7 +996,10 @@ static int launch_fwd(const ConvP& p0, int td, int th, int tw, hipStream_t st) {
     dim3 grid(p.N * p.tiles_d * p.tiles_h * p.tiles_w, ceil_div(p.nout_p, 16 * NT));
     if (tw == 16) conv3d_fwd_kernel<KS, NT, 4, 4, 16><<<grid, 256, 0, st>>>(p);
     else if (tw == 8) conv3d_fwd_kernel<KS, NT, 4, 8, 8><<<grid, 256, 0, st>>>(p);
-    else conv3d_fwd_kernel<KS, NT, 4, 4, 4><<<grid, 256, 0, st>>>(p);
+    else if (KS == 3 && NT == 1 && p.rin_p % 32 == 0) {
+        // small deep-level volumes: 32 channels per barrier pair (4x fewer exposed staging latencies)
+        if constexpr (KS == 3 && NT == 1) conv3d_fwd_kernel<3, 1, 4, 4, 4, 4><<<grid, 256, 0, st>>>(p);
+    } else conv3d_fwd_kernel<KS, NT, 4, 4, 4><<<grid, 256, 0, st>>>(p);
     CTU_CHECK_LAUNCH("conv3d_fwd");
     return CTU_OK;
 }
