@@ -38,7 +38,7 @@ __host__ __device__ inline void pick_tile(int W, int* td, int* th, int* tw) {
     else { *td = 4; *th = 4; *tw = 4; }
 }
 
-constexpr int VS = 12;   // LDS floats per halo voxel (8 channels + 4 pad)
+
 
 // CCH = 8-channel chunks staged per barrier pair (4 on the small deep-level volumes, where the per-stage latency,
 // not the matrix pipe, sets the time).
@@ -233,19 +233,32 @@ __global__ __launch_bounds__(256) void conv3d_fwd_kernel(ConvP p) {
 // PAIR = true : C_out = 8, N = (w-shift s, co), M = voxel pairs, 36 taps, box 4x4x32 (NT must be 1):
 //   out[(d,h,2m+s), co] = sum in[(d+kd, h+kh, 2m+kw') - pad][ci] * Wp[kd,kh,kw'][ci][(s,co)],
 //   Wp[..kw'][ci][(s,co)] = W[..kw'-s][ci][co] for 0 <= kw'-s <= 2, else 0  -> 1.5x fewer MFMAs than padding N.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 template <int NT, bool PAIR>
 __global__ __launch_bounds__(256) void conv3d_fwd_k3_persist(ConvP p, int ntiles, int tiles_per_block) {
+    constexpr int MT = 4;
     constexpr int TD = 4, TH = 4, TW = PAIR ? 32 : 16;
     constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2, HV = HD * HH * HW;
-    constexpr int MT = 4, NTAP = PAIR ? 36 : 27, KWN = PAIR ? 4 : 3;
+    constexpr int NWAVE = 16 / MT, NTHR = 64 * NWAVE;
+    constexpr int NTAP = PAIR ? 36 : 27, KWN = PAIR ? 4 : 3;
     constexpr int WFL = NTAP * NT * 128;
-    constexpr int AITEMS = HV * 2, AITER = (AITEMS + 255) / 256;
-    constexpr int WITER = (WFL / 4 + 255) / 256;
+    constexpr int AITEMS = HV * 2, AITER = (AITEMS + NTHR - 1) / NTHR;
+    constexpr int WITER = (WFL / 4 + NTHR - 1) / NTHR;
     static_assert(!PAIR || NT == 1, "pair layout has a single N tile");
 
-    __shared__ __attribute__((aligned(16))) float sA[HV * VS];
-    __shared__ __attribute__((aligned(16))) float sW[WFL];
-    __shared__ float sRed[4 * NT * 16 * 2];
+    // LDS tiles are indexed in float2 units so that every fragment read is a provably 8-byte-aligned ds_read_b64
+    // (the layouts are conflict-free for b64; the b32/read2_b32 forms the compiler falls back to are not).
+    // Voxel stride: 12 floats (6 float2) for 1-voxel lane stride, 10 floats (5 float2) for the pair layout's 2-voxel stride.
+    constexpr int VSK = PAIR ? 10 : 12, VS2 = VSK / 2;
+    __shared__ __attribute__((aligned(16))) v2f sA2[HV * VS2];
+    __shared__ __attribute__((aligned(16))) v2f sW2[WFL / 2];
+    // fragment reads go through volatile pointers: each is ONE ds_read_b64 that the compiler can neither split into the
+    // b32 / read2_b32 forms (half the bandwidth, bank-conflicting on these layouts) nor fuse into read2_b64
+    typedef const volatile __attribute__((address_space(3))) v2f* lds_v2f_ptr;
+    lds_v2f_ptr vA = (lds_v2f_ptr)sA2;
+    lds_v2f_ptr vW = (lds_v2f_ptr)sW2;
+    __shared__ float sRed[NWAVE * NT * 16 * 2];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = lane & 15, kq = lane >> 4;
@@ -256,17 +269,16 @@ __global__ __launch_bounds__(256) void conv3d_fwd_k3_persist(ConvP p, int ntiles
     const int half = tid & 1;
     const bool has_xf = p.in_scale != nullptr;
 
-    int abase[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) abase[mt] = ((wave * HH + mt) * HW + (PAIR ? 2 * m : m)) * VS + kq * 2;   // td = wave, th = mt
-    const int bbase = kq * 32 + m * 2;
+    // this wave owns box plane td = wave; its 4 M-tiles are the rows th = 0..3.  Per-lane base of row 0, tap (0,0,0):
+    const int rowbase = ((wave * HH) * HW + (PAIR ? 2 * m : m)) * VS2 + kq;                 // float2 units
+    const int bbase = kq * 16 + m;                                                          // float2 units
 
     // per-thread staging items: halo coordinates (packed) and the offset relative to the box origin
     int hoff[AITER];
     unsigned hpos[AITER];
 #pragma unroll
     for (int it = 0; it < AITER; ++it) {
-        const int i = tid + it * 256;
+        const int i = tid + it * NTHR;
         const int v = (i < AITEMS) ? (i >> 1) : 0;
         const int pw = v % HW, t2 = v / HW, ph = t2 % HH, pd = t2 / HH;
         hpos[it] = (unsigned)pd | ((unsigned)ph << 8) | ((unsigned)pw << 16);
@@ -310,7 +322,7 @@ __global__ __launch_bounds__(256) void conv3d_fwd_k3_persist(ConvP p, int ntiles
         vmask = 0;
 #pragma unroll
         for (int it = 0; it < AITER; ++it) {
-            const int i = tid + it * 256;
+            const int i = tid + it * NTHR;
             bool ok = i < AITEMS;
             if (!interior) {
                 const int gd = d0 + (int)(hpos[it] & 255u) - 1, gh = h0 + (int)((hpos[it] >> 8) & 255u) - 1,
@@ -329,7 +341,7 @@ __global__ __launch_bounds__(256) void conv3d_fwd_k3_persist(ConvP p, int ntiles
         const float* wsrc = p.wp + (size_t)cc * NTAP * n16 * 128 + (size_t)by * NT * 128;
 #pragma unroll
         for (int it = 0; it < WITER; ++it) {
-            const int i = (tid + it * 256) * 4;
+            const int i = (tid + it * NTHR) * 4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (i < WFL) {
                 const int ts = i / (NT * 128), r = i % (NT * 128);
@@ -341,8 +353,8 @@ __global__ __launch_bounds__(256) void conv3d_fwd_k3_persist(ConvP p, int ntiles
     auto store_w = [&]() {
 #pragma unroll
         for (int it = 0; it < WITER; ++it) {
-            const int i = (tid + it * 256) * 4;
-            if (i < WFL) *reinterpret_cast<float4*>(&sW[i]) = vw[it];
+            const int i = (tid + it * NTHR) * 4;
+            if (i < WFL) *reinterpret_cast<float4*>(&sW2[i >> 1]) = vw[it];
         }
     };
 
@@ -354,10 +366,17 @@ __global__ __launch_bounds__(256) void conv3d_fwd_k3_persist(ConvP p, int ntiles
         __syncthreads();                       // the previous stage's readers are done with sA / sW
 #pragma unroll
         for (int it = 0; it < AITER; ++it) {
-            const int i = tid + it * 256;
+            const int i = tid + it * NTHR;
             float4 val = va[it];
             if (has_xf && ((vmask >> it) & 1u)) val = xform4(val, sc, sh, p.in_relu);
-            if (i < AITEMS) *reinterpret_cast<float4*>(&sA[(i >> 1) * VS + half * 4]) = val;
+            if (i < AITEMS) {
+                if (PAIR) {                       // 40-byte voxel stride: two 8-byte stores
+                    sA2[(i >> 1) * VS2 + half * 2] = v2f{val.x, val.y};
+                    sA2[(i >> 1) * VS2 + half * 2 + 1] = v2f{val.z, val.w};
+                } else {
+                    *reinterpret_cast<float4*>(&sA2[(i >> 1) * VS2 + half * 2]) = val;
+                }
+            }
         }
         if (!hoist_w) store_w();
         __syncthreads();
@@ -369,32 +388,46 @@ __global__ __launch_bounds__(256) void conv3d_fwd_k3_persist(ConvP p, int ntiles
             load_a(ntile, nc);
             if (!hoist_w) load_w(nc);
         }
-        // ---- taps on the matrix cores: rows = output channels, columns = voxels (or voxel pairs)
+        // ---- taps on the matrix cores: rows = output channels, columns = voxels (or voxel pairs).
+        // Group (kd, kw): the 6 input rows th' = 0..5 feed the 3 kh taps of all 4 M-tiles (row th + kh), so each group
+        // needs 6 + 3*NT fragment reads for 12*NT*2 MFMAs; the next group's fragments are read before this group's MFMAs.
+        {
+            constexpr int NG = 3 * KWN;
+            v2f ar[2][6], br[2][3][NT];
+            auto load_group = [&](int gq, v2f (&aa)[6], v2f (&bb)[3][NT]) {
+                const int kd = gq / KWN, kw = gq % KWN;
 #pragma unroll
-        for (int ts = 0; ts < NTAP; ++ts) {
-            const int kd = ts / (3 * KWN), kh = (ts / KWN) % 3, kw = ts % KWN;
-            const int toff = ((kd * HH + kh) * HW + kw) * VS;
-            float2 b[NT], a[MT];
+                for (int r = 0; r < 6; ++r) aa[r] = vA[rowbase + ((kd * HH + r) * HW + kw) * VS2];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const float2*>(&sW[(ts * NT + nt) * 128 + bbase]);
+                for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const float2*>(&sA[abase[mt] + toff]);
+                    for (int nt = 0; nt < NT; ++nt) bb[kh][nt] = vW[(((kd * 3 + kh) * KWN + kw) * NT + nt) * 64 + bbase];
+            };
+            load_group(0, ar[0], br[0]);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+            for (int gq = 0; gq < NG; ++gq) {
+                if (gq + 1 < NG) load_group(gq + 1, ar[(gq + 1) & 1], br[(gq + 1) & 1]);
+                v2f (&aa)[6] = ar[gq & 1];
+                v2f (&bb)[3][NT] = br[gq & 1];
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[nt].x, a[mt].x, acc[mt][nt], 0, 0, 0);
+                for (int kh = 0; kh < 3; ++kh) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+                    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[nt].y, a[mt].y, acc[mt][nt], 0, 0, 0);
+                        for (int mt = 0; mt < MT; ++mt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bb[kh][nt].x, aa[mt + kh].x, acc[mt][nt], 0, 0, 0);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bb[kh][nt].y, aa[mt + kh].y, acc[mt][nt], 0, 0, 0);
+                }
+            }
         }
         if (c == nchunk - 1) {
             // ---- epilogue of this box: bias, one float4 store per lane and (mt, nt), BN partial sums
             int n_img, d0, h0, w0;
             tile_origin(tile, n_img, d0, h0, w0);
-            const int gd = d0 + wave;
             const int gw = PAIR ? (w0 + 2 * m + (kq >> 1)) : (w0 + m);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
@@ -407,7 +440,8 @@ __global__ __launch_bounds__(256) void conv3d_fwd_k3_persist(ConvP p, int ntiles
                 }
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
-                    const int gh = h0 + mt;
+                    const int g = wave * MT + mt;
+                    const int gd = d0 + (g >> 2), gh = h0 + (g & 3);
                     if (cok && gd < p.D && gh < p.H && gw < p.W) {
                         float4 o;
                         o.x = acc[mt][nt][0] + bv.x; o.y = acc[mt][nt][1] + bv.y;
@@ -448,7 +482,7 @@ __global__ __launch_bounds__(256) void conv3d_fwd_k3_persist(ConvP p, int ntiles
             if (co < p.nout_p) {
                 float a1 = 0.f, a2 = 0.f;
 #pragma unroll
-                for (int w = 0; w < 4; ++w) {
+                for (int w = 0; w < NWAVE; ++w) {
                     a1 += sRed[(w * NT * 16 + tid) * 2 + 0];
                     a2 += sRed[(w * NT * 16 + tid) * 2 + 1];
                 }
