@@ -235,8 +235,23 @@ __global__ __launch_bounds__(256) void conv3d_fwd_kernel(ConvP p) {
 //   Wp[..kw'][ci][(s,co)] = W[..kw'-s][ci][co] for 0 <= kw'-s <= 2, else 0  -> 1.5x fewer MFMAs than padding N.
 typedef float v2f __attribute__((ext_vector_type(2)));
 
+#ifdef CTU_STAMP
+// diagnostic build only (scripts/diag_stamp.hip): per-phase cycle sums of wave 0, written to a buffer of their own
+__device__ unsigned long long* g_stamp_out = nullptr;
+#define STAMP(var)                                                                   \
+    do {                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                           \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");  \
+        __builtin_amdgcn_sched_barrier(0);                                           \
+    } while (0)
+#else
+#define STAMP(var) do { } while (0)
+#endif
+
+// second launch bound = waves per SIMD the register allocation must allow: 3 resident blocks for the NT = 1 box
+// (45 KB of LDS each), 2 for the pair layout and NT = 2 (LDS- / accumulator-bound)
 template <int NT, bool PAIR>
-__global__ __launch_bounds__(256) void conv3d_fwd_k3_persist(ConvP p, int ntiles, int tiles_per_block) {
+__global__ __launch_bounds__(256, (NT == 1 && !PAIR) ? 3 : 2) void conv3d_fwd_k3_persist(ConvP p, int ntiles, int tiles_per_block) {
     constexpr int MT = 4;
     constexpr int TD = 4, TH = 4, TW = PAIR ? 32 : 16;
     constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2, HV = HD * HH * HW;
@@ -361,9 +376,14 @@ __global__ __launch_bounds__(256) void conv3d_fwd_k3_persist(ConvP p, int ntiles
     load_a(tile, 0);
     load_w(0);
     if (hoist_w) store_w();
+#ifdef CTU_STAMP
+    unsigned long long tq0 = 0, tq1 = 0, tq2 = 0, tq3 = 0, tq4 = 0, tq5 = 0, ph[5] = {0, 0, 0, 0, 0}, nst = 0;
+    STAMP(tq0);
+#endif
 
     while (true) {
         __syncthreads();                       // the previous stage's readers are done with sA / sW
+        STAMP(tq1);
 #pragma unroll
         for (int it = 0; it < AITER; ++it) {
             const int i = tid + it * NTHR;
@@ -380,6 +400,7 @@ __global__ __launch_bounds__(256) void conv3d_fwd_k3_persist(ConvP p, int ntiles
         }
         if (!hoist_w) store_w();
         __syncthreads();
+        STAMP(tq2);
         // ---- prefetch the next stage while this one computes
         int ntile = tile, nc = c + 1;
         if (nc == nchunk) { nc = 0; ntile = tile + 1; }
@@ -388,6 +409,7 @@ __global__ __launch_bounds__(256) void conv3d_fwd_k3_persist(ConvP p, int ntiles
             load_a(ntile, nc);
             if (!hoist_w) load_w(nc);
         }
+        STAMP(tq3);
         // ---- taps on the matrix cores: rows = output channels, columns = voxels (or voxel pairs).
         // Group (kd, kw): the 6 input rows th' = 0..5 feed the 3 kh taps of all 4 M-tiles (row th + kh), so each group
         // needs 6 + 3*NT fragment reads for 12*NT*2 MFMAs; the next group's fragments are read before this group's MFMAs.
@@ -424,6 +446,7 @@ __global__ __launch_bounds__(256) void conv3d_fwd_k3_persist(ConvP p, int ntiles
                 }
             }
         }
+        STAMP(tq4);
         if (c == nchunk - 1) {
             // ---- epilogue of this box: bias, one float4 store per lane and (mt, nt), BN partial sums
             int n_img, d0, h0, w0;
@@ -455,9 +478,21 @@ __global__ __launch_bounds__(256) void conv3d_fwd_k3_persist(ConvP p, int ntiles
                 }
             }
         }
+#ifdef CTU_STAMP
+        STAMP(tq5);
+        ph[0] += tq1 - tq0; ph[1] += tq2 - tq1; ph[2] += tq3 - tq2; ph[3] += tq4 - tq3; ph[4] += tq5 - tq4;
+        tq0 = tq5; ++nst;
+#endif
         if (!has_next) break;
         tile = ntile; c = nc;
     }
+#ifdef CTU_STAMP
+    if (g_stamp_out && tid == 0) {
+        unsigned long long* o = g_stamp_out + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 6;
+        for (int k = 0; k < 5; ++k) o[k] = ph[k];
+        o[5] = nst;
+    }
+#endif
     // ---- one BatchNorm partial row per block: reduce over the 16 voxel lanes, (pair: the two shifts,) the 4 waves
     if (p.stats) {
         __syncthreads();
