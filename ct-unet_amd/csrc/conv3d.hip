@@ -319,31 +319,45 @@ __global__ __launch_bounds__(256, (NT == 1 && !PAIR) ? 3 : 2) void conv3d_fwd_k3
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
     unsigned vmask = 0;
 
-    auto tile_origin = [&](int t, int& n_img, int& d0, int& h0, int& w0) {
-        const int tx = t % p.tiles_w; t /= p.tiles_w;
-        const int ty = t % p.tiles_h; t /= p.tiles_h;
-        const int tz = t % p.tiles_d; t /= p.tiles_d;
-        n_img = t; d0 = tz * TD; h0 = ty * TH; w0 = tx * TW;
+    // box coordinates advance incrementally (no div/mod per stage)
+    struct Box { int tx, ty, tz, n; };
+    auto box_of = [&](int t) {
+        Box b;
+        b.tx = t % p.tiles_w; t /= p.tiles_w;
+        b.ty = t % p.tiles_h; t /= p.tiles_h;
+        b.tz = t % p.tiles_d; b.n = t / p.tiles_d;
+        return b;
     };
-    auto load_a = [&](int t, int cc) {
-        int n_img, d0, h0, w0;
-        tile_origin(t, n_img, d0, h0, w0);
+    auto box_next = [&](Box b) {
+        if (++b.tx == p.tiles_w) { b.tx = 0; if (++b.ty == p.tiles_h) { b.ty = 0; if (++b.tz == p.tiles_d) { b.tz = 0; ++b.n; } } }
+        return b;
+    };
+    bool a_interior = false;                       // uniform: the staged box's halo lies inside the volume
+    auto load_a = [&](Box b, int cc) {
+        const int d0 = b.tz * TD, h0 = b.ty * TH, w0 = b.tx * TW;
         if (has_xf) {
             sc = *reinterpret_cast<const float4*>(p.in_scale + cc * 8 + half * 4);
             sh = *reinterpret_cast<const float4*>(p.in_shift + cc * 8 + half * 4);
         }
-        const float* base = p.in + ((((size_t)n_img * p.D + d0) * p.H + h0) * p.W + w0) * p.in_cs + cc * 8;
-        const bool interior = d0 >= 1 && h0 >= 1 && w0 >= 1 && d0 + TD < p.D && h0 + TH < p.H && w0 + TW < p.W;
+        const float* base = p.in + ((((size_t)b.n * p.D + d0) * p.H + h0) * p.W + w0) * p.in_cs + cc * 8;
+        a_interior = d0 >= 1 && h0 >= 1 && w0 >= 1 && d0 + TD < p.D && h0 + TH < p.H && w0 + TW < p.W;
+        if (a_interior) {                          // the common case: no per-item predicates
+#pragma unroll
+            for (int it = 0; it < AITER; ++it) {
+                if ((it + 1) * NTHR <= AITEMS || tid + it * NTHR < AITEMS)
+                    va[it] = *reinterpret_cast<const float4*>(base + hoff[it]);
+                else
+                    va[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            return;
+        }
         vmask = 0;
 #pragma unroll
         for (int it = 0; it < AITER; ++it) {
             const int i = tid + it * NTHR;
-            bool ok = i < AITEMS;
-            if (!interior) {
-                const int gd = d0 + (int)(hpos[it] & 255u) - 1, gh = h0 + (int)((hpos[it] >> 8) & 255u) - 1,
-                          gw = w0 + (int)(hpos[it] >> 16) - 1;
-                ok = ok && (unsigned)gd < (unsigned)p.D && (unsigned)gh < (unsigned)p.H && (unsigned)gw < (unsigned)p.W;
-            }
+            const int gd = d0 + (int)(hpos[it] & 255u) - 1, gh = h0 + (int)((hpos[it] >> 8) & 255u) - 1,
+                      gw = w0 + (int)(hpos[it] >> 16) - 1;
+            const bool ok = i < AITEMS && (unsigned)gd < (unsigned)p.D && (unsigned)gh < (unsigned)p.H && (unsigned)gw < (unsigned)p.W;
             float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
             if (ok) {
                 val = *reinterpret_cast<const float4*>(base + hoff[it]);
@@ -352,16 +366,16 @@ __global__ __launch_bounds__(256, (NT == 1 && !PAIR) ? 3 : 2) void conv3d_fwd_k3
             va[it] = val;
         }
     };
+    const bool w_full = (by + 1) * NT <= n16;      // uniform: every N tile of this block exists
     auto load_w = [&](int cc) {
         const float* wsrc = p.wp + (size_t)cc * NTAP * n16 * 128 + (size_t)by * NT * 128;
 #pragma unroll
         for (int it = 0; it < WITER; ++it) {
             const int i = (tid + it * NTHR) * 4;
+            const int ts = i / (NT * 128), r = i % (NT * 128);
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < WFL) {
-                const int ts = i / (NT * 128), r = i % (NT * 128);
-                if (by * NT * 128 + r < n16 * 128) v = *reinterpret_cast<const float4*>(wsrc + (size_t)ts * n16 * 128 + r);
-            }
+            if (((it + 1) * NTHR * 4 <= WFL || i < WFL) && (w_full || by * NT * 128 + r < n16 * 128))
+                v = *reinterpret_cast<const float4*>(wsrc + (ts * n16 * 128 + r));
             vw[it] = v;
         }
     };
@@ -373,7 +387,8 @@ __global__ __launch_bounds__(256, (NT == 1 && !PAIR) ? 3 : 2) void conv3d_fwd_k3
         }
     };
 
-    load_a(tile, 0);
+    Box box = box_of(tile);
+    load_a(box, 0);
     load_w(0);
     if (hoist_w) store_w();
 #ifdef CTU_STAMP
@@ -384,12 +399,13 @@ __global__ __launch_bounds__(256, (NT == 1 && !PAIR) ? 3 : 2) void conv3d_fwd_k3
     while (true) {
         __syncthreads();                       // the previous stage's readers are done with sA / sW
         STAMP(tq1);
+        const bool cur_interior = a_interior;   // of the box now in va[] (load_a below overwrites the flag)
 #pragma unroll
         for (int it = 0; it < AITER; ++it) {
             const int i = tid + it * NTHR;
             float4 val = va[it];
-            if (has_xf && ((vmask >> it) & 1u)) val = xform4(val, sc, sh, p.in_relu);
-            if (i < AITEMS) {
+            if (has_xf && (cur_interior || ((vmask >> it) & 1u))) val = xform4(val, sc, sh, p.in_relu);
+            if ((it + 1) * NTHR <= AITEMS || i < AITEMS) {
                 if (PAIR) {                       // 40-byte voxel stride: two 8-byte stores
                     sA2[(i >> 1) * VS2 + half * 2] = v2f{val.x, val.y};
                     sA2[(i >> 1) * VS2 + half * 2 + 1] = v2f{val.z, val.w};
@@ -403,10 +419,11 @@ __global__ __launch_bounds__(256, (NT == 1 && !PAIR) ? 3 : 2) void conv3d_fwd_k3
         STAMP(tq2);
         // ---- prefetch the next stage while this one computes
         int ntile = tile, nc = c + 1;
-        if (nc == nchunk) { nc = 0; ntile = tile + 1; }
+        Box nbox = box;
+        if (nc == nchunk) { nc = 0; ntile = tile + 1; nbox = box_next(box); }
         const bool has_next = ntile < tile_end;
         if (has_next) {
-            load_a(ntile, nc);
+            load_a(nbox, nc);
             if (!hoist_w) load_w(nc);
         }
         STAMP(tq3);
@@ -449,9 +466,11 @@ __global__ __launch_bounds__(256, (NT == 1 && !PAIR) ? 3 : 2) void conv3d_fwd_k3
         STAMP(tq4);
         if (c == nchunk - 1) {
             // ---- epilogue of this box: bias, one float4 store per lane and (mt, nt), BN partial sums
-            int n_img, d0, h0, w0;
-            tile_origin(tile, n_img, d0, h0, w0);
+            const int n_img = box.n, d0 = box.tz * TD, h0 = box.ty * TH, w0 = box.tx * TW;
             const int gw = PAIR ? (w0 + 2 * m + (kq >> 1)) : (w0 + m);
+            const bool box_full = d0 + TD <= p.D && h0 + TH <= p.H && w0 + TW <= p.W;      // uniform
+            float* obase = p.out + ((((size_t)n_img * p.D + d0 + wave) * p.H + h0) * p.W + gw) * p.out_cs;
+            const int orow = p.W * p.out_cs;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int co = PAIR ? (kq & 1) * 4 : (by * NT + nt) * 16 + kq * 4;
@@ -463,14 +482,12 @@ __global__ __launch_bounds__(256, (NT == 1 && !PAIR) ? 3 : 2) void conv3d_fwd_k3
                 }
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
-                    const int g = wave * MT + mt;
-                    const int gd = d0 + (g >> 2), gh = h0 + (g & 3);
-                    if (cok && gd < p.D && gh < p.H && gw < p.W) {
+                    // this wave's M-tile mt is box plane td = wave, row th = mt
+                    if (cok && (box_full || (d0 + wave < p.D && h0 + mt < p.H && gw < p.W))) {
                         float4 o;
                         o.x = acc[mt][nt][0] + bv.x; o.y = acc[mt][nt][1] + bv.y;
                         o.z = acc[mt][nt][2] + bv.z; o.w = acc[mt][nt][3] + bv.w;
-                        const size_t vox = (((size_t)n_img * p.D + gd) * p.H + gh) * p.W + gw;
-                        *reinterpret_cast<float4*>(p.out + vox * p.out_cs + co) = o;
+                        *reinterpret_cast<float4*>(obase + mt * orow + co) = o;
                         s1[nt][0] += o.x; s1[nt][1] += o.y; s1[nt][2] += o.z; s1[nt][3] += o.w;
                         s2[nt][0] += o.x * o.x; s2[nt][1] += o.y * o.y; s2[nt][2] += o.z * o.z; s2[nt][3] += o.w * o.w;
                     }
@@ -484,7 +501,7 @@ __global__ __launch_bounds__(256, (NT == 1 && !PAIR) ? 3 : 2) void conv3d_fwd_k3
         tq0 = tq5; ++nst;
 #endif
         if (!has_next) break;
-        tile = ntile; c = nc;
+        tile = ntile; c = nc; box = nbox;
     }
 #ifdef CTU_STAMP
     if (g_stamp_out && tid == 0) {
