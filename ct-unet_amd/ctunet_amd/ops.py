@@ -48,16 +48,28 @@ class KernelTimer:
 
     def __init__(self):
         self.records = []
+        self.details = []
 
     def begin(self):
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
         return ev
 
-    def end(self, tag, flops, nbytes, start):
+    def end(self, tag, flops, nbytes, start, detail=None):
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
         self.records.append((tag, flops, nbytes, start, ev))
+        self.details.append(detail)
+
+    def by_layer(self):
+        """{(tag, detail): dict(launches, total_ms, flops)} -- per-geometry split of ``summary`` (dev tool)."""
+        out = {}
+        for (tag, fl, nb, a, b), det in zip(self.records, self.details):
+            d = out.setdefault((tag, det), dict(launches=0, total_ms=0.0, flops=0.0))
+            d["launches"] += 1
+            d["total_ms"] += a.elapsed_time(b)
+            d["flops"] += fl
+        return out
 
     def summary(self):
         """{tag: dict(launches, total_ms, avg_ms, flops, bytes)} -- call after a device synchronize."""
@@ -217,7 +229,7 @@ def conv3d_fwd(x: CL, wp: torch.Tensor, bias: Optional[torch.Tensor], out: CL, k
         ci, co = algo_ch if algo_ch is not None else (x.cp, out.cp)
         vox = n * d * h * w
         TIMER.end(lib.ctu_conv3d_fwd_kernel_name(n, d, h, w, k, out.cp, layout).decode(), 2.0 * ci * co * k ** 3 * vox,
-                  4.0 * vox * (ci + co), t0)
+                  4.0 * vox * (ci + co), t0, (w, x.cp, out.cp))
 
 
 def conv3d_wgrad(x: CL, g: CL, co: int, ci: int, k: int, cinv: Optional[torch.Tensor], ws: torch.Tensor,
@@ -235,7 +247,7 @@ def conv3d_wgrad(x: CL, g: CL, co: int, ci: int, k: int, cinv: Optional[torch.Te
     if t0 is not None:
         vox = n * d * h * w
         TIMER.end(lib.ctu_conv3d_wgrad_kernel_name(w, k, x.cp, g.cp).decode() + " (+slab reduce)",
-                  2.0 * ci * co * k ** 3 * vox, 4.0 * vox * (ci + co), t0)
+                  2.0 * ci * co * k ** 3 * vox, 4.0 * vox * (ci + co), t0, (w, x.cp, g.cp))
     return dw, db
 
 
