@@ -33,19 +33,15 @@ void ctu_set_error(const char* fmt, ...);
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
-// lazy-BN input transform on 4 consecutive channels
+// lazy-BN input transform on 4 consecutive channels: 2 packed FMAs + 4 max (the clamp bound is -inf without ReLU,
+// so there is no branch; __builtin_elementwise_max avoids the extra canonicalising max of fmaxf)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float4 xform4(float4 v, float4 sc, float4 sh, int relu) {
-    v.x = fmaf(v.x, sc.x, sh.x);
-    v.y = fmaf(v.y, sc.y, sh.y);
-    v.z = fmaf(v.z, sc.z, sh.z);
-    v.w = fmaf(v.w, sc.w, sh.w);
-    if (relu) {
-        v.x = fmaxf(v.x, 0.f);
-        v.y = fmaxf(v.y, 0.f);
-        v.z = fmaxf(v.z, 0.f);
-        v.w = fmaxf(v.w, 0.f);
-    }
-    return v;
+    const float lo = relu ? 0.f : -__builtin_inff();
+    const f32x2 l2 = {lo, lo};
+    const f32x2 a = __builtin_elementwise_max(__builtin_elementwise_fma(f32x2{v.x, v.y}, f32x2{sc.x, sc.y}, f32x2{sh.x, sh.y}), l2);
+    const f32x2 b = __builtin_elementwise_max(__builtin_elementwise_fma(f32x2{v.z, v.w}, f32x2{sc.z, sc.w}, f32x2{sh.z, sh.w}), l2);
+    return make_float4(a.x, a.y, b.x, b.y);
 }
 
 // slab reductions: RPARTS thread groups of 64 stride over the partial slabs, then a fixed-order sum

@@ -15,6 +15,19 @@
 #include "common.h"
 #include "pack.h"
 
+#ifndef CTU_K3S_OCC
+#define CTU_K3S_OCC 2
+#endif
+#ifndef CTU_K3S_ALL
+#define CTU_K3S_ALL 0
+#endif
+#ifndef CTU_WG_OCC
+#define CTU_WG_OCC 2
+#endif
+#ifndef CTU_WG_BLOCKS
+#define CTU_WG_BLOCKS 512
+#endif
+
 namespace {
 
 struct ConvP {
@@ -610,7 +623,7 @@ struct WgP {
 // One block: one (ci-tile of 16, co-tile of 16) pair, KDS kd-planes of taps, a strided set of
 // spatial tiles.  MFMA view: M = 16 input channels, N = 16 output channels, K = voxels.
 template <int KS, int KDS, int TD, int TH, int TW>
-__global__ __launch_bounds__(256) void conv3d_wgrad_kernel(WgP p) {
+__global__ __launch_bounds__(256, CTU_WG_OCC) void conv3d_wgrad_kernel(WgP p) {
     constexpr int PAD = (KS - 1) / 2;
     constexpr int HD = TD + KDS - 1, HH = TH + KS - 1, HW = TW + KS - 1;
     constexpr int HV = HD * HH * HW;
@@ -742,7 +755,7 @@ __global__ __launch_bounds__(1024) void conv3d_wgrad_reduce_kernel(const float* 
 }
 
 inline int wgrad_gx(int ntiles, int pairs_z) {
-    int gx = 512 / pairs_z;
+    int gx = CTU_WG_BLOCKS / pairs_z;
     if (gx < 1) gx = 1;
     if (gx > ntiles) gx = ntiles;
     return gx;
@@ -762,11 +775,12 @@ inline int wgrad_gx(int ntiles, int pairs_z) {
 //   SM = 2, SN = 1 (8 -> C): t0 = 0 gives kw 0,1; t0 = 1 keeps s=1 (kw 2)  -> 18
 // Persistent blocks walk contiguous voxel boxes with register prefetch of the next box.
 template <int SM, int SN>
-__global__ __launch_bounds__(256) void conv3d_wgrad_k3s_kernel(WgP p, int tiles_per_block) {
+__global__ __launch_bounds__(256, CTU_K3S_OCC) void conv3d_wgrad_k3s_kernel(WgP p, int tiles_per_block) {
     constexpr int TD = 4, TH = 4, TW = 16, HD = 6, HH = 6, HW = 18, HV = HD * HH * HW;
     constexpr int CM = 16 / SM, CN = 16 / SN;        // channels per block on the input / output side
     constexpr int GW = TW + (SN - 1), GV = TD * TH * GW;
-    constexpr int NMF = (SM == 2 && SN == 2) ? 9 : 18;
+    constexpr int QN = (SM == 2 && SN == 2) ? 1 : ((SM == 1 && SN == 1) ? 3 : 2);     // w positions per (kd, kh) row
+    constexpr int NMF = 9 * QN;
     constexpr int AQ = CM / 4, GQ = CN / 4;
     constexpr int AITEMS = HV * AQ, AITER = (AITEMS + 255) / 256;
     constexpr int GITEMS = GV * GQ, GITER = (GITEMS + 255) / 256;
@@ -797,94 +811,211 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_k3s_kernel(WgP p, int tiles_
     const int tile_end = min(p.ntiles, tile + tiles_per_block);
     float4 va[AITER], vg[GITER];
 
-    // staging items: position inside the (haloed) box, packed, and the offset relative to the box origin
-    int aoff[AITER], goff[GITER];
-    unsigned apos[AITER], gpos[GITER];
+    // staging items: BYTE offsets relative to the box's halo origin (non-negative, so the loads take the
+    // scalar-base + 32-bit-offset addressing form and cost no VALU address arithmetic)
+    unsigned aoff[AITER], goff[GITER];
+    constexpr int FPW = 5;                         // 6-bit halo-face codes per 32-bit word
+    unsigned fw[(AITER + FPW - 1) / FPW], gw0 = 0; // gw0 bit it: gradient item it is the w-shift column (SN = 2)
+#pragma unroll
+    for (int q = 0; q < (AITER + FPW - 1) / FPW; ++q) fw[q] = 0;
 #pragma unroll
     for (int it = 0; it < AITER; ++it) {
         const int e = tid + it * 256, v = (e < AITEMS) ? e / AQ : 0;
         const int pw = v % HW, t2 = v / HW, ph = t2 % HH, pd = t2 / HH;
-        apos[it] = (unsigned)pd | ((unsigned)ph << 8) | ((unsigned)pw << 16);
-        aoff[it] = (((pd - 1) * p.H + (ph - 1)) * p.W + (pw - 1)) * p.in_cs + ci0 + aq * 4;
+        aoff[it] = (unsigned)(((pd * p.H + ph) * p.W + pw) * p.in_cs + ci0 + aq * 4) * 4u;
+        const unsigned face = (pd == 0 ? 1u : 0u) | (pd == HD - 1 ? 2u : 0u) | (ph == 0 ? 4u : 0u) | (ph == HH - 1 ? 8u : 0u) |
+                              (pw == 0 ? 16u : 0u) | (pw == HW - 1 ? 32u : 0u);
+        fw[it / FPW] |= face << (6 * (it % FPW));
     }
 #pragma unroll
     for (int it = 0; it < GITER; ++it) {
         const int e = tid + it * 256, v = (e < GITEMS) ? e / GQ : 0;
         const int tw = v % GW, th = (v / GW) % TH, td = v / (GW * TH);
-        gpos[it] = (unsigned)td | ((unsigned)th << 8) | ((unsigned)tw << 16);
-        goff[it] = ((td * p.H + th) * p.W + tw - (SN - 1)) * p.g_cs + co0 + gq * 4;
+        goff[it] = (unsigned)(((td * p.H + th) * p.W + tw) * p.g_cs + co0 + gq * 4) * 4u;
+        if (SN == 2 && tw == 0) gw0 |= 1u << it;
     }
+    // a full box's only out-of-volume items sit on halo faces that coincide with volume faces: a load from the box
+    // origin (always inside) stands in for them and the LDS write zeroes them
+    const unsigned safe_a = (unsigned)(((p.H + 1) * p.W + 1) * p.in_cs + ci0 + aq * 4) * 4u;
+    const unsigned safe_g = (unsigned)((SN - 1) * p.g_cs + co0 + gq * 4) * 4u;
+    const bool ch_full = ci0 + CM <= p.cin_p && co0 + CN <= p.cout_p;       // uniform
 
-    auto load = [&](int t) {
-        const int tx = t % p.tiles_w; t /= p.tiles_w;
-        const int ty = t % p.tiles_h; t /= p.tiles_h;
-        const int tz = t % p.tiles_d; t /= p.tiles_d;
-        const int n_img = t, d0 = tz * TD, h0 = ty * TH, w0 = tx * TW;
-        const size_t org = (((size_t)n_img * p.D + d0) * p.H + h0) * p.W + w0;
-        const float* abase = p.in + org * p.in_cs;
-        const float* gbase = p.g + org * p.g_cs;
+    // box coordinates advance incrementally (no div/mod per box)
+    struct Box { int tx, ty, tz, n; };
+    Box box;
+    {
+        int t = tile;
+        box.tx = t % p.tiles_w; t /= p.tiles_w;
+        box.ty = t % p.tiles_h; t /= p.tiles_h;
+        box.tz = t % p.tiles_d; box.n = t / p.tiles_d;
+    }
+    auto box_next = [&](Box b) {
+        if (++b.tx == p.tiles_w) { b.tx = 0; if (++b.ty == p.tiles_h) { b.ty = 0; if (++b.tz == p.tiles_d) { b.tz = 0; ++b.n; } } }
+        return b;
+    };
+
+    // The loads only FETCH (raw values + a validity bit per item); the lazy-BatchNorm transform happens when the
+    // values are written to LDS one stage later, so no wave ever waits for global memory inside load().
+    unsigned amask = 0, gmask = 0;                 // bit it: item it of va[] / vg[] lies inside the volume
+    bool all_valid = false;                        // uniform: every item of the staged box is valid
+    auto load = [&](Box b) {
+        const int d0 = b.tz * TD, h0 = b.ty * TH, w0 = b.tx * TW;
+        const long long org = (((long long)b.n * p.D + d0) * p.H + h0) * p.W + w0;
+        const char* abase = reinterpret_cast<const char*>(p.in + (org - ((long long)p.H * p.W + p.W + 1)) * p.in_cs);
+        const char* gbase = reinterpret_cast<const char*>(p.g + (org - (SN - 1)) * p.g_cs);
         const bool interior = d0 >= 1 && h0 >= 1 && w0 >= 1 && d0 + TD < p.D && h0 + TH < p.H && w0 + TW < p.W;
+        all_valid = interior && ch_full;
+        if (all_valid) {                           // the common case: no per-item predicates (uniform branch)
+#pragma unroll
+            for (int it = 0; it < AITER; ++it)
+                if ((it + 1) * 256 <= AITEMS || tid + it * 256 < AITEMS) va[it] = *reinterpret_cast<const float4*>(abase + aoff[it]);
+#pragma unroll
+            for (int it = 0; it < GITER; ++it)
+                if ((it + 1) * 256 <= GITEMS || tid + it * 256 < GITEMS) vg[it] = *reinterpret_cast<const float4*>(gbase + goff[it]);
+            return;
+        }
+        amask = 0; gmask = 0;
+        if (ch_full && d0 + TD <= p.D && h0 + TH <= p.H && w0 + TW <= p.W) {       // full border box: branch-free
+            const unsigned bface = (d0 == 0 ? 1u : 0u) | (d0 + TD == p.D ? 2u : 0u) | (h0 == 0 ? 4u : 0u) |
+                                   (h0 + TH == p.H ? 8u : 0u) | (w0 == 0 ? 16u : 0u) | (w0 + TW == p.W ? 32u : 0u);
+#pragma unroll
+            for (int it = 0; it < AITER; ++it) {
+                const bool ok = (fw[it / FPW] & (bface << (6 * (it % FPW)))) == 0u;
+                va[it] = *reinterpret_cast<const float4*>(abase + (ok ? aoff[it] : safe_a));
+                amask |= ok ? (1u << it) : 0u;
+            }
+#pragma unroll
+            for (int it = 0; it < GITER; ++it) {
+                const bool ok = !((bface & 16u) && ((gw0 >> it) & 1u));
+                vg[it] = *reinterpret_cast<const float4*>(gbase + (ok ? goff[it] : safe_g));
+                gmask |= ok ? (1u << it) : 0u;
+            }
+            return;
+        }
 #pragma unroll
         for (int it = 0; it < AITER; ++it) {
-            const int e = tid + it * 256;
-            bool ok = e < AITEMS && a_ok;
-            if (!interior) {
-                const int gd = d0 + (int)(apos[it] & 255u) - 1, gh = h0 + (int)((apos[it] >> 8) & 255u) - 1,
-                          gw = w0 + (int)(apos[it] >> 16) - 1;
-                ok = ok && (unsigned)gd < (unsigned)p.D && (unsigned)gh < (unsigned)p.H && (unsigned)gw < (unsigned)p.W;
-            }
+            const int e = tid + it * 256, v = e / AQ;
+            const int pw = v % HW, t2 = v / HW, ph = t2 % HH, pd = t2 / HH;
+            const int gd = d0 + pd - 1, gh = h0 + ph - 1, gw = w0 + pw - 1;
+            const bool ok = e < AITEMS && a_ok && (unsigned)gd < (unsigned)p.D && (unsigned)gh < (unsigned)p.H &&
+                            (unsigned)gw < (unsigned)p.W;
             float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
             if (ok) {
                 val = *reinterpret_cast<const float4*>(abase + aoff[it]);
-                if (has_xf) val = xform4(val, sc, sh, p.in_relu);
+                amask |= 1u << it;
             }
             va[it] = val;
         }
 #pragma unroll
         for (int it = 0; it < GITER; ++it) {
-            const int e = tid + it * 256;
-            bool ok = e < GITEMS && g_ok;
-            if (!interior) {
-                const int gd = d0 + (int)(gpos[it] & 255u), gh = h0 + (int)((gpos[it] >> 8) & 255u),
-                          gw = w0 + (int)(gpos[it] >> 16) - (SN - 1);
-                ok = ok && gd < p.D && gh < p.H && (unsigned)gw < (unsigned)p.W;
-            }
+            const int e = tid + it * 256, v = e / GQ;
+            const int tw = v % GW, th = (v / GW) % TH, td = v / (GW * TH);
+            const int gd = d0 + td, gh = h0 + th, gw = w0 + tw - (SN - 1);
+            const bool ok = e < GITEMS && g_ok && gd < p.D && gh < p.H && (unsigned)gw < (unsigned)p.W;
             float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) val = *reinterpret_cast<const float4*>(gbase + goff[it]);
+            if (ok) {
+                val = *reinterpret_cast<const float4*>(gbase + goff[it]);
+                gmask |= 1u << it;
+            }
             vg[it] = val;
         }
     };
 
-    if (tile < tile_end) load(tile);
+    // fragment reads: one ds_read_b32 each at a compile-time offset from two per-lane bases, issued one K-step ahead
+    typedef const volatile __attribute__((address_space(3))) float* lds_f_ptr;
+    lds_f_ptr vA = (lds_f_ptr)sA + ((wave * HH * HW + kq) * CM + i);
+    lds_f_ptr vG = (lds_f_ptr)sG + ((wave * TH * GW + kq + (SN - 1)) * CN + boff);
+
+    if (tile < tile_end) load(box);
+#ifdef CTU_STAMP
+    unsigned long long tq0 = 0, tq1 = 0, tq2 = 0, tq3 = 0, tq4 = 0, ph[5] = {0, 0, 0, 0, 0}, nst = 0;
+    STAMP(tq0);
+#endif
     while (tile < tile_end) {
         __syncthreads();
+        STAMP(tq1);
+        if (all_valid) {
 #pragma unroll
-        for (int it = 0; it < AITER; ++it) {
-            const int e = tid + it * 256;
-            if (e < AITEMS) *reinterpret_cast<float4*>(&sA[e * 4]) = va[it];
+            for (int it = 0; it < AITER; ++it) {
+                const int e = tid + it * 256;
+                if ((it + 1) * 256 <= AITEMS || e < AITEMS)
+                    *reinterpret_cast<float4*>(&sA[e * 4]) = has_xf ? xform4(va[it], sc, sh, p.in_relu) : va[it];
+            }
+        } else {                                   // padding / absent channels are zeros AFTER the transform
+#pragma unroll
+            for (int it = 0; it < AITER; ++it) {
+                const int e = tid + it * 256;
+                const float4 t = has_xf ? xform4(va[it], sc, sh, p.in_relu) : va[it];
+                const bool ok = (amask >> it) & 1u;
+                if ((it + 1) * 256 <= AITEMS || e < AITEMS)
+                    *reinterpret_cast<float4*>(&sA[e * 4]) = make_float4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f);
+            }
         }
 #pragma unroll
         for (int it = 0; it < GITER; ++it) {
             const int e = tid + it * 256;
-            if (e < GITEMS) *reinterpret_cast<float4*>(&sG[e * 4]) = vg[it];
+            const bool ok = all_valid || ((gmask >> it) & 1u);
+            if ((it + 1) * 256 <= GITEMS || e < GITEMS)
+                *reinterpret_cast<float4*>(&sG[e * 4]) =
+                    make_float4(ok ? vg[it].x : 0.f, ok ? vg[it].y : 0.f, ok ? vg[it].z : 0.f, ok ? vg[it].w : 0.f);
         }
         __syncthreads();
-        if (tile + 1 < tile_end) load(tile + 1);
-#pragma unroll 2
-        for (int ks = 0; ks < 16; ++ks) {
-            const int th = ks >> 2, tw = (ks & 3) * 4 + kq;           // td = wave
-            const float b = sG[((wave * TH + th) * GW + tw + (SN - 1)) * CN + boff];
-            const int ab = ((wave * HH + th) * HW + tw) * CM + i;
+        STAMP(tq2);
+        box = box_next(box);
+        if (tile + 1 < tile_end) load(box);
+        STAMP(tq3);
+        {
+            // plane td = wave: 16 K-steps of 4 voxels (row th = ks / 4, columns (ks % 4) * 4 + kq).  The 16 * NMF
+            // (K-step, tap) MFMAs form one flat stream; their A fragments go through a ring of R registers that is
+            // refilled R entries ahead (the slot an MFMA has just consumed), the B fragment one K-step ahead.
+            constexpr int R = 12, NJ = 16 * NMF;
+            float ar[R], br[2];
+            auto a_read = [&](int j) -> float {
+                const int ks = j / NMF, t = j % NMF;
+                const int th = ks >> 2, tw4 = (ks & 3) * 4;
+                const int r = t / QN, q = t % QN, kd = r / 3, kh = r % 3;
+                return vA[((kd * HH + th + kh) * HW + tw4 + q) * CM];
+            };
+            auto b_read = [&](int ks) -> float { return vG[((ks >> 2) * GW + (ks & 3) * 4) * CN]; };
+            br[0] = b_read(0);
 #pragma unroll
-            for (int t = 0; t < NMF; ++t) {
-                const int r = (NMF == 9) ? t : t / 2, q = (NMF == 9) ? 0 : t % 2;
-                const int kd = r / 3, kh = r % 3;
-                const float a = sA[ab + ((kd * HH + kh) * HW + q) * CM];
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
+            for (int j = 0; j < R; ++j) ar[j] = a_read(j);
+            // the whole ring is in flight before the first MFMA (one exposed LDS latency per box): a fake use of
+            // every slot keeps the scheduler from trickling the fill reads in between the first MFMAs
+            static_assert(R == 12, "fake-use list");
+            asm volatile("" : "+v"(ar[0]), "+v"(ar[1]), "+v"(ar[2]), "+v"(ar[3]), "+v"(ar[4]), "+v"(ar[5]), "+v"(ar[6]),
+                         "+v"(ar[7]), "+v"(ar[8]), "+v"(ar[9]), "+v"(ar[10]), "+v"(ar[11]), "+v"(br[0]));
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                if (ks + 1 < 16) {
+                    br[(ks + 1) & 1] = b_read(ks + 1);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+#pragma unroll
+                for (int t = 0; t < NMF; ++t) {
+                    const int j = ks * NMF + t;
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[j % R], br[ks & 1], acc[t], 0, 0, 0);
+                    if (j + R < NJ) ar[j % R] = a_read(j + R);
+                    // pin the order: MFMA, then the refill of the slot it consumed
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (j + R < NJ) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
             }
         }
+#ifdef CTU_STAMP
+        STAMP(tq4);
+        ph[0] += tq1 - tq0; ph[1] += tq2 - tq1; ph[2] += tq3 - tq2; ph[3] += tq4 - tq3;
+        tq0 = tq4; ++nst;
+#endif
         ++tile;
     }
+#ifdef CTU_STAMP
+    if (g_stamp_out && tid == 0) {
+        unsigned long long* o = g_stamp_out + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 6;
+        for (int k = 0; k < 5; ++k) o[k] = ph[k];
+        o[5] = nst;
+    }
+#endif
     // 4 waves -> one slab [NMF][16][16] per block (through sA, 4 * NMF * 256 floats <= HV * CM for CM = 8 needs rounds)
     constexpr int RT = (HV * CM / 1024) < NMF ? (HV * CM / 1024) : NMF;
     static_assert(RT >= 1, "reduction scratch");
@@ -909,7 +1040,8 @@ template <int SM, int SN>
 __global__ __launch_bounds__(1024) void conv3d_wgrad_k3s_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
                                                                       int Co, int Ci, const int32_t* __restrict__ cinv,
                                                                       int cin_p, int n_ci_g, int gx) {
-    constexpr int NMF = (SM == 2 && SN == 2) ? 9 : 18;
+    constexpr int QN = (SM == 2 && SN == 2) ? 1 : ((SM == 1 && SN == 1) ? 3 : 2);
+    constexpr int NMF = 9 * QN;
     constexpr int CM = 16 / SM, CN = 16 / SN;
     __shared__ float red[RPARTS][64];
     const int e = threadIdx.x & 63, part = threadIdx.x >> 6;
@@ -925,12 +1057,13 @@ __global__ __launch_bounds__(1024) void conv3d_wgrad_k3s_reduce_kernel(const flo
     if (part != 0 || el >= NMF * 256) return;
     const float tot = red_total(red, e);
     const int t = el >> 8, i = (el >> 4) & 15, j = el & 15;
-    const int r = (NMF == 9) ? t : t / 2, q = (NMF == 9) ? 0 : t % 2;
+    const int r = t / QN, q = t % QN;
     const int sm = (SM == 2) ? i / 8 : 0, cil = (SM == 2) ? i % 8 : i;
     const int sn = (SN == 2) ? j / 8 : 0, col = (SN == 2) ? j % 8 : j;
     int kw;
     bool ok = true;
-    if (SM == 2 && SN == 2) { kw = sm + sn; ok = !(sm == 0 && sn == 1); }
+    if (SM == 1 && SN == 1) kw = q;
+    else if (SM == 2 && SN == 2) { kw = sm + sn; ok = !(sm == 0 && sn == 1); }
     else if (SN == 2) { if (q == 0) { kw = 0; ok = sn == 0; } else kw = 1 + sn; }
     else { if (q == 0) kw = sm; else { kw = 2; ok = sm == 1; } }
     const int cig = pair % n_ci_g, cog = pair / n_ci_g;
@@ -941,7 +1074,7 @@ __global__ __launch_bounds__(1024) void conv3d_wgrad_k3s_reduce_kernel(const flo
 
 template <int SM, int SN>
 static int launch_wgrad_k3s(WgP p, float* dw, int Co, int Ci, const int32_t* cinv, hipStream_t st) {
-    constexpr int NMF = (SM == 2 && SN == 2) ? 9 : 18;
+    constexpr int NMF = (SM == 2 && SN == 2) ? 9 : ((SM == 1 && SN == 1) ? 27 : 18);
     p.tiles_d = ceil_div(p.D, 4); p.tiles_h = ceil_div(p.H, 4); p.tiles_w = ceil_div(p.W, 16);
     p.ntiles = p.N * p.tiles_d * p.tiles_h * p.tiles_w;
     p.n_ci_t = ceil_div(p.cin_p, 16 / SM);
@@ -977,7 +1110,7 @@ extern "C" const char* ctu_conv3d_fwd_kernel_name(int N, int D, int H, int W, in
 
 extern "C" const char* ctu_conv3d_wgrad_kernel_name(int W, int k, int cin_p, int cout_p) {
     static thread_local char buf[64];
-    if (k == 3 && W >= 16 && (cin_p == 8 || cout_p == 8))
+    if (k == 3 && W >= 16 && (CTU_K3S_ALL || cin_p == 8 || cout_p == 8))
         snprintf(buf, sizeof(buf), "conv3d_wgrad_k3s_kernel<%d, %d>", cin_p == 8 ? 2 : 1, cout_p == 8 ? 2 : 1);
     else {
         int td, th, tw;
@@ -1204,12 +1337,14 @@ extern "C" int ctu_conv3d_wgrad(const float* in, int in_cs, int cin_p, const flo
     p.N = N; p.D = D; p.H = H; p.W = W;
     int gz, gx, bt;
     wgrad_geom(N, D, H, W, k, cin_p, cout_p, &p.ntiles, &p.n_ci_t, &p.n_co_t, &gz, &gx, &bt);
-    if (k == 3 && W >= 16 && (cin_p == 8 || cout_p == 8)) {
-        // narrow layers: (shift, channel) MFMA tiles; workspace need is below the generic bound
+    if (k == 3 && W >= 16 && (CTU_K3S_ALL || cin_p == 8 || cout_p == 8)) {
+        // persistent, software-pipelined kernel; 8-channel sides use (shift, channel) MFMA tiles.
+        // Workspace need is at most the generic bound.
         int rc2;
         if (cin_p == 8 && cout_p == 8) rc2 = launch_wgrad_k3s<2, 2>(p, dw, Co, Ci, cinv, st);
         else if (cout_p == 8) rc2 = launch_wgrad_k3s<1, 2>(p, dw, Co, Ci, cinv, st);
-        else rc2 = launch_wgrad_k3s<2, 1>(p, dw, Co, Ci, cinv, st);
+        else if (cin_p == 8) rc2 = launch_wgrad_k3s<2, 1>(p, dw, Co, Ci, cinv, st);
+        else rc2 = launch_wgrad_k3s<1, 1>(p, dw, Co, Ci, cinv, st);
         if (rc2 != CTU_OK) return rc2;
         if (dbias) return ctu_channel_sum(gout, g_cs, cout_p, (int64_t)N * D * H * W, ws, dbias, Co, stream);
         return CTU_OK;

@@ -4,7 +4,9 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "ct-unet_amd")]
 import torch
-from ctunet_amd import ops
+from ctunet_amd import ops, _lib
+if os.environ.get("CTU_LIB"):          # dev: A/B a differently built library
+    _lib.LIB_PATH = os.environ["CTU_LIB"]
 
 op, ci, co, s = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 k = int(sys.argv[5]) if len(sys.argv) > 5 else 3

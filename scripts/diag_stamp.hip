@@ -6,6 +6,7 @@
 #include "conv3d.hip"
 #include <vector>
 #include <cstdlib>
+#include <algorithm>
 
 int main(int argc, char** argv) {
     const int cin_p = atoi(argv[1]), nout_p = atoi(argv[2]), S = atoi(argv[3]), layout = atoi(argv[4]);
@@ -26,6 +27,15 @@ int main(int argc, char** argv) {
     const size_t ndbg = (size_t)4096 * 6;
     hipMalloc(&dbg, ndbg * 8); hipMemset(dbg, 0, ndbg * 8);
     hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_out), &dbg, sizeof(dbg));
+    if (argc > 5) {             // 6th argument: time conv3d_wgrad (in = activations, "out" buffer = upstream gradient)
+        hipMemcpy(out, h.data(), std::min(h.size(), vox * nout_p) * 4, hipMemcpyHostToDevice);
+        float *ws, *dw;
+        hipMalloc(&ws, ctu_conv3d_wgrad_ws_floats(1, S, S, S, 3, cin_p, nout_p) * 4);
+        hipMalloc(&dw, (size_t)cin_p * nout_p * 27 * 4);
+        for (int it = 0; it < 5; ++it)
+            if (ctu_conv3d_wgrad(in, cin_p, cin_p, nullptr, nullptr, 0, out, nout_p, nout_p, dw, nullptr, nout_p, cin_p, nullptr, ws,
+                                 1, S, S, S, 3, nullptr)) { printf("error: %s\n", ctu_last_error()); return 1; }
+    } else
     for (int it = 0; it < 5; ++it)
         if (ctu_conv3d_fwd(in, cin_p, cin_p, nullptr, nullptr, 0, wp, nullptr, 0, out, nout_p, nout_p, stats, 1, S, S, S, 3, layout, nullptr)) {
             printf("error: %s\n", ctu_last_error()); return 1;

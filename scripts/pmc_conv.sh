@@ -1,11 +1,11 @@
+# dev: SQ instruction-mix / stall counters of one conv layer through scripts/bench_layer.py
+#   usage: bash scripts/pmc_conv.sh <op> "<cin> <cout> <size>" <tag>
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+OP=$1; L=$2; T=$3
 A="SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_WAVES"
-B="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES"
-C="SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_SALU SQ_WAIT_ANY SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_MISC SQ_LDS_IDX_ACTIVE"
-for L in "8 8 128" "16 16 64" "8 32 128"; do
-  T=$(echo $L | tr ' ' '_')
-  timeout -k 10 120 rocprofv3 --kernel-trace --pmc $A --output-format csv -d gpurun_out/pmcA_$T -o r -- python scripts/bench_layer.py fwd $L 3 5 > gpurun_out/pmcA_$T.log 2>&1 &&
-  timeout -k 10 120 rocprofv3 --kernel-trace --pmc $B --output-format csv -d gpurun_out/pmcB_$T -o r -- python scripts/bench_layer.py fwd $L 3 5 > gpurun_out/pmcB_$T.log 2>&1 &&
-  timeout -k 10 120 rocprofv3 --kernel-trace --pmc $C --output-format csv -d gpurun_out/pmcC_$T -o r -- python scripts/bench_layer.py fwd $L 3 5 > gpurun_out/pmcC_$T.log 2>&1 || exit 1
+B="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VMEM"
+C="SQ_INST_CYCLES_VMEM_RD SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_INST_LEVEL_VMEM SQ_WAIT_ANY SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA SQ_IFETCH"
+for P in A B C; do
+  eval CN=\$$P
+  timeout -k 10 120 rocprofv3 --kernel-trace --pmc $CN --output-format csv -d gpurun_out/pmc${P}_$T -o r -- python scripts/bench_layer.py $OP $L 3 5 > gpurun_out/pmc${P}_$T.log 2>&1 || exit 1
 done
-ls gpurun_out | grep pmc
