@@ -19,7 +19,7 @@
 #define CTU_K3S_OCC 2
 #endif
 #ifndef CTU_K3S_ALL
-#define CTU_K3S_ALL 0
+#define CTU_K3S_ALL 1
 #endif
 #ifndef CTU_WG_OCC
 #define CTU_WG_OCC 2
@@ -754,6 +754,9 @@ __global__ __launch_bounds__(1024) void conv3d_wgrad_reduce_kernel(const float* 
     }
 }
 
+// k = 3 layers at least 16 voxels wide take the persistent, software-pipelined weight-gradient kernel
+inline bool use_k3s(int k, int W, int cin_p, int cout_p) { return k == 3 && W >= 16 && (CTU_K3S_ALL || cin_p == 8 || cout_p == 8); }
+
 inline int wgrad_gx(int ntiles, int pairs_z) {
     int gx = CTU_WG_BLOCKS / pairs_z;
     if (gx < 1) gx = 1;
@@ -776,7 +779,9 @@ inline int wgrad_gx(int ntiles, int pairs_z) {
 // Persistent blocks walk contiguous voxel boxes with register prefetch of the next box.
 template <int SM, int SN>
 __global__ __launch_bounds__(256, CTU_K3S_OCC) void conv3d_wgrad_k3s_kernel(WgP p, int tiles_per_block) {
-    constexpr int TD = 4, TH = 4, TW = 16, HD = 6, HH = 6, HW = 18, HV = HD * HH * HW;
+    // box: 4 x 4 x 16 voxels; 4 x 4 x 8 for the full 16 x 16 channel tile, whose 27 accumulators leave fewer staging registers
+    constexpr int TD = 4, TH = 4, TW = (SM == 1) ? 8 : 16, HD = 6, HH = 6, HW = TW + 2, HV = HD * HH * HW;
+    constexpr int KPR = TW / 4, NKS = TH * KPR;       // K-steps (4 voxels) per row / per plane
     constexpr int CM = 16 / SM, CN = 16 / SN;        // channels per block on the input / output side
     constexpr int GW = TW + (SN - 1), GV = TD * TH * GW;
     constexpr int QN = (SM == 2 && SN == 2) ? 1 : ((SM == 1 && SN == 1) ? 3 : 2);     // w positions per (kd, kh) row
@@ -965,18 +970,18 @@ __global__ __launch_bounds__(256, CTU_K3S_OCC) void conv3d_wgrad_k3s_kernel(WgP 
         if (tile + 1 < tile_end) load(box);
         STAMP(tq3);
         {
-            // plane td = wave: 16 K-steps of 4 voxels (row th = ks / 4, columns (ks % 4) * 4 + kq).  The 16 * NMF
+            // plane td = wave: NKS K-steps of 4 voxels (row th = ks / KPR, columns (ks % KPR) * 4 + kq).  The NKS * NMF
             // (K-step, tap) MFMAs form one flat stream; their A fragments go through a ring of R registers that is
             // refilled R entries ahead (the slot an MFMA has just consumed), the B fragment one K-step ahead.
-            constexpr int R = 12, NJ = 16 * NMF;
+            constexpr int R = 12, NJ = NKS * NMF;
             float ar[R], br[2];
             auto a_read = [&](int j) -> float {
                 const int ks = j / NMF, t = j % NMF;
-                const int th = ks >> 2, tw4 = (ks & 3) * 4;
+                const int th = ks / KPR, tw4 = (ks % KPR) * 4;
                 const int r = t / QN, q = t % QN, kd = r / 3, kh = r % 3;
                 return vA[((kd * HH + th + kh) * HW + tw4 + q) * CM];
             };
-            auto b_read = [&](int ks) -> float { return vG[((ks >> 2) * GW + (ks & 3) * 4) * CN]; };
+            auto b_read = [&](int ks) -> float { return vG[((ks / KPR) * GW + (ks % KPR) * 4) * CN]; };
             br[0] = b_read(0);
 #pragma unroll
             for (int j = 0; j < R; ++j) ar[j] = a_read(j);
@@ -986,8 +991,8 @@ __global__ __launch_bounds__(256, CTU_K3S_OCC) void conv3d_wgrad_k3s_kernel(WgP 
             asm volatile("" : "+v"(ar[0]), "+v"(ar[1]), "+v"(ar[2]), "+v"(ar[3]), "+v"(ar[4]), "+v"(ar[5]), "+v"(ar[6]),
                          "+v"(ar[7]), "+v"(ar[8]), "+v"(ar[9]), "+v"(ar[10]), "+v"(ar[11]), "+v"(br[0]));
 #pragma unroll
-            for (int ks = 0; ks < 16; ++ks) {
-                if (ks + 1 < 16) {
+            for (int ks = 0; ks < NKS; ++ks) {
+                if (ks + 1 < NKS) {
                     br[(ks + 1) & 1] = b_read(ks + 1);
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
@@ -1072,21 +1077,32 @@ __global__ __launch_bounds__(1024) void conv3d_wgrad_k3s_reduce_kernel(const flo
     if (ok && ci >= 0 && co < Co) dw[((size_t)co * Ci + ci) * 27 + r * 3 + kw] = tot;
 }
 
+// geometry of the persistent k = 3 kernel for a layer: tile shape (SM, SN), box width, boxes, channel-tile pairs, grid
+struct K3sGeom { int sm, sn, tw, ntiles, n_ci_g, pairs, gx, tpb, nmf; };
+static K3sGeom k3s_geom(int N, int D, int H, int W, int cin_p, int cout_p) {
+    K3sGeom g;
+    g.sm = cin_p == 8 ? 2 : 1; g.sn = cout_p == 8 ? 2 : 1;
+    g.tw = (g.sm == 1) ? 8 : 16;
+    g.nmf = (g.sm == 2 && g.sn == 2) ? 9 : ((g.sm == 1 && g.sn == 1) ? 27 : 18);
+    g.ntiles = N * ceil_div(D, 4) * ceil_div(H, 4) * ceil_div(W, g.tw);
+    g.n_ci_g = ceil_div(cin_p, 16 / g.sm);
+    g.pairs = g.n_ci_g * ceil_div(cout_p, 16 / g.sn);
+    g.gx = wgrad_gx(g.ntiles, g.pairs);
+    g.tpb = ceil_div(g.ntiles, g.gx);
+    g.gx = ceil_div(g.ntiles, g.tpb);
+    return g;
+}
+
 template <int SM, int SN>
 static int launch_wgrad_k3s(WgP p, float* dw, int Co, int Ci, const int32_t* cinv, hipStream_t st) {
-    constexpr int NMF = (SM == 2 && SN == 2) ? 9 : ((SM == 1 && SN == 1) ? 27 : 18);
-    p.tiles_d = ceil_div(p.D, 4); p.tiles_h = ceil_div(p.H, 4); p.tiles_w = ceil_div(p.W, 16);
-    p.ntiles = p.N * p.tiles_d * p.tiles_h * p.tiles_w;
-    p.n_ci_t = ceil_div(p.cin_p, 16 / SM);
-    const int n_co_g = ceil_div(p.cout_p, 16 / SN);
-    const int pairs = p.n_ci_t * n_co_g;
-    int gx = wgrad_gx(p.ntiles, pairs);
-    const int tpb = ceil_div(p.ntiles, gx);
-    gx = ceil_div(p.ntiles, tpb);
-    conv3d_wgrad_k3s_kernel<SM, SN><<<dim3(gx, pairs), 256, 0, st>>>(p, tpb);
+    const K3sGeom g = k3s_geom(p.N, p.D, p.H, p.W, p.cin_p, p.cout_p);
+    p.tiles_d = ceil_div(p.D, 4); p.tiles_h = ceil_div(p.H, 4); p.tiles_w = ceil_div(p.W, g.tw);
+    p.ntiles = g.ntiles;
+    p.n_ci_t = g.n_ci_g;
+    conv3d_wgrad_k3s_kernel<SM, SN><<<dim3(g.gx, g.pairs), 256, 0, st>>>(p, g.tpb);
     CTU_CHECK_LAUNCH("conv3d_wgrad_k3s");
-    conv3d_wgrad_k3s_reduce_kernel<SM, SN><<<dim3(ceil_div(NMF * 256, 64), pairs), 64 * RPARTS, 0, st>>>(p.ws, dw, Co, Ci, cinv, p.cin_p,
-                                                                                              p.n_ci_t, gx);
+    conv3d_wgrad_k3s_reduce_kernel<SM, SN><<<dim3(ceil_div(g.nmf * 256, 64), g.pairs), 64 * RPARTS, 0, st>>>(
+        p.ws, dw, Co, Ci, cinv, p.cin_p, p.n_ci_t, g.gx);
     CTU_CHECK_LAUNCH("conv3d_wgrad_k3s_reduce");
     return CTU_OK;
 }
@@ -1110,7 +1126,7 @@ extern "C" const char* ctu_conv3d_fwd_kernel_name(int N, int D, int H, int W, in
 
 extern "C" const char* ctu_conv3d_wgrad_kernel_name(int W, int k, int cin_p, int cout_p) {
     static thread_local char buf[64];
-    if (k == 3 && W >= 16 && (CTU_K3S_ALL || cin_p == 8 || cout_p == 8))
+    if (use_k3s(k, W, cin_p, cout_p))
         snprintf(buf, sizeof(buf), "conv3d_wgrad_k3s_kernel<%d, %d>", cin_p == 8 ? 2 : 1, cout_p == 8 ? 2 : 1);
     else {
         int td, th, tw;
@@ -1297,7 +1313,11 @@ extern "C" size_t ctu_conv3d_wgrad_ws_floats(int N, int D, int H, int W, int k, 
     if (k != 3 && k != 5) return 0;
     int ntiles, nci, nco, gz, gx, bt;
     wgrad_geom(N, D, H, W, k, cin_p, cout_p, &ntiles, &nci, &nco, &gz, &gx, &bt);
-    const size_t slabs = (size_t)gz * nci * nco * gx * bt * 256;
+    size_t slabs = (size_t)gz * nci * nco * gx * bt * 256;
+    if (use_k3s(k, W, cin_p, cout_p)) {
+        const K3sGeom g = k3s_geom(N, D, H, W, cin_p, cout_p);
+        slabs = (size_t)g.pairs * g.gx * g.nmf * 256;
+    }
     const size_t bsum = (size_t)ctu_channel_sum_num_blocks((int64_t)N * D * H * W) * cout_p;
     return slabs > bsum ? slabs : bsum;
 }
@@ -1337,7 +1357,7 @@ extern "C" int ctu_conv3d_wgrad(const float* in, int in_cs, int cin_p, const flo
     p.N = N; p.D = D; p.H = H; p.W = W;
     int gz, gx, bt;
     wgrad_geom(N, D, H, W, k, cin_p, cout_p, &p.ntiles, &p.n_ci_t, &p.n_co_t, &gz, &gx, &bt);
-    if (k == 3 && W >= 16 && (CTU_K3S_ALL || cin_p == 8 || cout_p == 8)) {
+    if (use_k3s(k, W, cin_p, cout_p)) {
         // persistent, software-pipelined kernel; 8-channel sides use (shift, channel) MFMA tiles.
         // Workspace need is at most the generic bound.
         int rc2;
