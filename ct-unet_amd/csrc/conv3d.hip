@@ -301,17 +301,25 @@ __global__ __launch_bounds__(256, (NT == 1 && !PAIR) ? 3 : 2) void conv3d_fwd_k3
     const int rowbase = ((wave * HH) * HW + (PAIR ? 2 * m : m)) * VS2 + kq;                 // float2 units
     const int bbase = kq * 16 + m;                                                          // float2 units
 
-    // per-thread staging items: halo coordinates (packed) and the offset relative to the box origin
-    int hoff[AITER];
-    unsigned hpos[AITER];
+    // per-thread staging items: BYTE offsets relative to the box's halo origin (non-negative: the loads take the
+    // scalar-base + 32-bit-offset form, no VALU address arithmetic) and 6-bit halo-face codes, 5 per word
+    unsigned hoff[AITER];
+    constexpr int FPW = 5, NFW = (AITER + FPW - 1) / FPW;
+    unsigned fw[NFW];
+#pragma unroll
+    for (int q = 0; q < NFW; ++q) fw[q] = 0;
 #pragma unroll
     for (int it = 0; it < AITER; ++it) {
         const int i = tid + it * NTHR;
         const int v = (i < AITEMS) ? (i >> 1) : 0;
         const int pw = v % HW, t2 = v / HW, ph = t2 % HH, pd = t2 / HH;
-        hpos[it] = (unsigned)pd | ((unsigned)ph << 8) | ((unsigned)pw << 16);
-        hoff[it] = (((pd - 1) * p.H + (ph - 1)) * p.W + (pw - 1)) * p.in_cs + half * 4;
+        hoff[it] = (unsigned)(((pd * p.H + ph) * p.W + pw) * p.in_cs + half * 4) * 4u;
+        const unsigned face = (pd == 0 ? 1u : 0u) | (pd == HD - 1 ? 2u : 0u) | (ph == 0 ? 4u : 0u) | (ph == HH - 1 ? 8u : 0u) |
+                              (pw == 0 ? 16u : 0u) | (pw == HW - 1 ? 32u : 0u);
+        fw[it / FPW] |= face << (6 * (it % FPW));
     }
+    // stands in for the out-of-volume items of a full border box: the box origin, always inside the volume
+    const unsigned safe_off = (unsigned)(((p.H + 1) * p.W + 1) * p.in_cs + half * 4) * 4u;
 
     f32x4 acc[MT][NT];
     float s1[NT][4], s2[NT][4];
@@ -352,7 +360,8 @@ __global__ __launch_bounds__(256, (NT == 1 && !PAIR) ? 3 : 2) void conv3d_fwd_k3
             sc = *reinterpret_cast<const float4*>(p.in_scale + cc * 8 + half * 4);
             sh = *reinterpret_cast<const float4*>(p.in_shift + cc * 8 + half * 4);
         }
-        const float* base = p.in + ((((size_t)b.n * p.D + d0) * p.H + h0) * p.W + w0) * p.in_cs + cc * 8;
+        const long long org = (((long long)b.n * p.D + d0) * p.H + h0) * p.W + w0 - ((long long)p.H * p.W + p.W + 1);
+        const char* base = reinterpret_cast<const char*>(p.in + org * p.in_cs + cc * 8);      // halo origin of the box
         a_interior = d0 >= 1 && h0 >= 1 && w0 >= 1 && d0 + TD < p.D && h0 + TH < p.H && w0 + TW < p.W;
         if (a_interior) {                          // the common case: no per-item predicates
 #pragma unroll
@@ -365,11 +374,24 @@ __global__ __launch_bounds__(256, (NT == 1 && !PAIR) ? 3 : 2) void conv3d_fwd_k3
             return;
         }
         vmask = 0;
+        if (d0 + TD <= p.D && h0 + TH <= p.H && w0 + TW <= p.W) {
+            // full border box: the only out-of-volume items sit on halo faces that coincide with volume faces; they
+            // load the box origin instead (branch-free) and are zeroed when written to LDS
+            const unsigned bface = (d0 == 0 ? 1u : 0u) | (d0 + TD == p.D ? 2u : 0u) | (h0 == 0 ? 4u : 0u) |
+                                   (h0 + TH == p.H ? 8u : 0u) | (w0 == 0 ? 16u : 0u) | (w0 + TW == p.W ? 32u : 0u);
 #pragma unroll
-        for (int it = 0; it < AITER; ++it) {
-            const int i = tid + it * NTHR;
-            const int gd = d0 + (int)(hpos[it] & 255u) - 1, gh = h0 + (int)((hpos[it] >> 8) & 255u) - 1,
-                      gw = w0 + (int)(hpos[it] >> 16) - 1;
+            for (int it = 0; it < AITER; ++it) {
+                const bool ok = (fw[it / FPW] & (bface << (6 * (it % FPW)))) == 0u;
+                va[it] = *reinterpret_cast<const float4*>(base + (ok ? hoff[it] : safe_off));
+                vmask |= ok ? (1u << it) : 0u;
+            }
+            return;
+        }
+#pragma unroll
+        for (int it = 0; it < AITER; ++it) {       // ragged box (volume not a multiple of the box): per-item bounds
+            const int i = tid + it * NTHR, v = i >> 1;
+            const int pw = v % HW, t2 = v / HW, ph = t2 % HH, pd = t2 / HH;
+            const int gd = d0 + pd - 1, gh = h0 + ph - 1, gw = w0 + pw - 1;
             const bool ok = i < AITEMS && (unsigned)gd < (unsigned)p.D && (unsigned)gh < (unsigned)p.H && (unsigned)gw < (unsigned)p.W;
             float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
             if (ok) {
@@ -388,7 +410,7 @@ __global__ __launch_bounds__(256, (NT == 1 && !PAIR) ? 3 : 2) void conv3d_fwd_k3
             const int ts = i / (NT * 128), r = i % (NT * 128);
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (((it + 1) * NTHR * 4 <= WFL || i < WFL) && (w_full || by * NT * 128 + r < n16 * 128))
-                v = *reinterpret_cast<const float4*>(wsrc + (ts * n16 * 128 + r));
+                v = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(wsrc) + (unsigned)(ts * n16 * 128 + r) * 4u);
             vw[it] = v;
         }
     };
@@ -412,18 +434,33 @@ __global__ __launch_bounds__(256, (NT == 1 && !PAIR) ? 3 : 2) void conv3d_fwd_k3
     while (true) {
         __syncthreads();                       // the previous stage's readers are done with sA / sW
         STAMP(tq1);
-        const bool cur_interior = a_interior;   // of the box now in va[] (load_a below overwrites the flag)
+        {
+            auto put = [&](int it, float4 val) {
+                const int i = tid + it * NTHR;
+                if ((it + 1) * NTHR <= AITEMS || i < AITEMS) {
+                    if (PAIR) {                       // 40-byte voxel stride: two 8-byte stores
+                        sA2[(i >> 1) * VS2 + half * 2] = v2f{val.x, val.y};
+                        sA2[(i >> 1) * VS2 + half * 2 + 1] = v2f{val.z, val.w};
+                    } else {
+                        *reinterpret_cast<float4*>(&sA2[(i >> 1) * VS2 + half * 2]) = val;
+                    }
+                }
+            };
+            if (a_interior) {                          // (the flag still describes the box now in va[])
 #pragma unroll
-        for (int it = 0; it < AITER; ++it) {
-            const int i = tid + it * NTHR;
-            float4 val = va[it];
-            if (has_xf && (cur_interior || ((vmask >> it) & 1u))) val = xform4(val, sc, sh, p.in_relu);
-            if ((it + 1) * NTHR <= AITEMS || i < AITEMS) {
-                if (PAIR) {                       // 40-byte voxel stride: two 8-byte stores
-                    sA2[(i >> 1) * VS2 + half * 2] = v2f{val.x, val.y};
-                    sA2[(i >> 1) * VS2 + half * 2 + 1] = v2f{val.z, val.w};
-                } else {
-                    *reinterpret_cast<float4*>(&sA2[(i >> 1) * VS2 + half * 2]) = val;
+                for (int it = 0; it < AITER; ++it) put(it, has_xf ? xform4(va[it], sc, sh, p.in_relu) : va[it]);
+            } else if (has_xf) {                       // padding voxels are zeros AFTER the BatchNorm/ReLU transform
+#pragma unroll
+                for (int it = 0; it < AITER; ++it) {
+                    const float4 t = xform4(va[it], sc, sh, p.in_relu);
+                    const bool ok = (vmask >> it) & 1u;
+                    put(it, make_float4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f));
+                }
+            } else {
+#pragma unroll
+                for (int it = 0; it < AITER; ++it) {
+                    const bool ok = (vmask >> it) & 1u;
+                    put(it, make_float4(ok ? va[it].x : 0.f, ok ? va[it].y : 0.f, ok ? va[it].z : 0.f, ok ? va[it].w : 0.f));
                 }
             }
         }
