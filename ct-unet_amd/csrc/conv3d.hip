@@ -817,7 +817,7 @@ inline int wgrad_gx(int ntiles, int pairs_z) {
 template <int SM, int SN>
 __global__ __launch_bounds__(256, CTU_K3S_OCC) void conv3d_wgrad_k3s_kernel(WgP p, int tiles_per_block) {
     // box: 4 x 4 x 16 voxels; 4 x 4 x 8 for the full 16 x 16 channel tile, whose 27 accumulators leave fewer staging registers
-    constexpr int TD = 4, TH = 4, TW = (SM == 1) ? 8 : 16, HD = 6, HH = 6, HW = TW + 2, HV = HD * HH * HW;
+    constexpr int TD = 4, TH = 4, TW = (SM == 2 && SN == 2) ? 16 : 8, HD = 6, HH = 6, HW = TW + 2, HV = HD * HH * HW;
     constexpr int KPR = TW / 4, NKS = TH * KPR;       // K-steps (4 voxels) per row / per plane
     constexpr int CM = 16 / SM, CN = 16 / SN;        // channels per block on the input / output side
     constexpr int GW = TW + (SN - 1), GV = TD * TH * GW;
@@ -827,8 +827,13 @@ __global__ __launch_bounds__(256, CTU_K3S_OCC) void conv3d_wgrad_k3s_kernel(WgP 
     constexpr int AITEMS = HV * AQ, AITER = (AITEMS + 255) / 256;
     constexpr int GITEMS = GV * GQ, GITER = (GITEMS + 255) / 256;
 
-    __shared__ __attribute__((aligned(16))) float sA[HV * CM];
-    __shared__ __attribute__((aligned(16))) float sG[GV * CN];
+    // two LDS stages: while the MFMAs read stage cur, the prefetched next box is transformed and written into stage
+    // cur ^ 1 between them (ONE barrier per box, no exposed write phase).  Every thread stores every item slot
+    // (the slots beyond the box are padding), so the MFMA loop is a single basic block.
+    constexpr int SAF = AITER * 256 * 4, SGF = GITER * 256 * 4;     // floats per stage
+    static_assert(SAF >= HV * CM && SGF >= GV * CN, "stage size");
+    __shared__ __attribute__((aligned(16))) float sA[2 * SAF];
+    __shared__ __attribute__((aligned(16))) float sG[2 * SGF];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, kq = lane >> 4;
@@ -842,11 +847,12 @@ __global__ __launch_bounds__(256, CTU_K3S_OCC) void conv3d_wgrad_k3s_kernel(WgP 
 
     const int aq = tid % AQ, gq = tid % GQ;          // 256 % AQ == 0: a thread keeps its channel quad
     const bool a_ok = (ci0 + aq * 4) < p.cin_p, g_ok = (co0 + gq * 4) < p.cout_p;
-    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);      // identity without transform
     if (has_xf && a_ok) {
         sc = *reinterpret_cast<const float4*>(p.in_scale + ci0 + aq * 4);
         sh = *reinterpret_cast<const float4*>(p.in_shift + ci0 + aq * 4);
     }
+    const int xf_relu = has_xf ? p.in_relu : 0;
     const int boff = (SN == 2) ? ((i < 8) ? i : i - 16) : i;
 
     int tile = blockIdx.x * tiles_per_block;
@@ -899,41 +905,35 @@ __global__ __launch_bounds__(256, CTU_K3S_OCC) void conv3d_wgrad_k3s_kernel(WgP 
     // The loads only FETCH (raw values + a validity bit per item); the lazy-BatchNorm transform happens when the
     // values are written to LDS one stage later, so no wave ever waits for global memory inside load().
     unsigned amask = 0, gmask = 0;                 // bit it: item it of va[] / vg[] lies inside the volume
-    bool all_valid = false;                        // uniform: every item of the staged box is valid
-    auto load = [&](Box b) {
+    const char* pf_abase = nullptr;                // uniform state of the box being fetched
+    const char* pf_gbase = nullptr;
+    unsigned pf_bface = 0;
+    // prep(): scalar part of a fetch.  Returns whether the box is full (inside the volume up to its halo faces), the
+    // precondition of the branch-free per-item forms below; ragged boxes go through load_ragged().
+    auto prep = [&](Box b) -> bool {
         const int d0 = b.tz * TD, h0 = b.ty * TH, w0 = b.tx * TW;
         const long long org = (((long long)b.n * p.D + d0) * p.H + h0) * p.W + w0;
-        const char* abase = reinterpret_cast<const char*>(p.in + (org - ((long long)p.H * p.W + p.W + 1)) * p.in_cs);
-        const char* gbase = reinterpret_cast<const char*>(p.g + (org - (SN - 1)) * p.g_cs);
-        const bool interior = d0 >= 1 && h0 >= 1 && w0 >= 1 && d0 + TD < p.D && h0 + TH < p.H && w0 + TW < p.W;
-        all_valid = interior && ch_full;
-        if (all_valid) {                           // the common case: no per-item predicates (uniform branch)
-#pragma unroll
-            for (int it = 0; it < AITER; ++it)
-                if ((it + 1) * 256 <= AITEMS || tid + it * 256 < AITEMS) va[it] = *reinterpret_cast<const float4*>(abase + aoff[it]);
-#pragma unroll
-            for (int it = 0; it < GITER; ++it)
-                if ((it + 1) * 256 <= GITEMS || tid + it * 256 < GITEMS) vg[it] = *reinterpret_cast<const float4*>(gbase + goff[it]);
-            return;
-        }
+        pf_abase = reinterpret_cast<const char*>(p.in + (org - ((long long)p.H * p.W + p.W + 1)) * p.in_cs);
+        pf_gbase = reinterpret_cast<const char*>(p.g + (org - (SN - 1)) * p.g_cs);
+        pf_bface = (d0 == 0 ? 1u : 0u) | (d0 + TD == p.D ? 2u : 0u) | (h0 == 0 ? 4u : 0u) | (h0 + TH == p.H ? 8u : 0u) |
+                   (w0 == 0 ? 16u : 0u) | (w0 + TW == p.W ? 32u : 0u);
         amask = 0; gmask = 0;
-        if (ch_full && d0 + TD <= p.D && h0 + TH <= p.H && w0 + TW <= p.W) {       // full border box: branch-free
-            const unsigned bface = (d0 == 0 ? 1u : 0u) | (d0 + TD == p.D ? 2u : 0u) | (h0 == 0 ? 4u : 0u) |
-                                   (h0 + TH == p.H ? 8u : 0u) | (w0 == 0 ? 16u : 0u) | (w0 + TW == p.W ? 32u : 0u);
-#pragma unroll
-            for (int it = 0; it < AITER; ++it) {
-                const bool ok = (fw[it / FPW] & (bface << (6 * (it % FPW)))) == 0u;
-                va[it] = *reinterpret_cast<const float4*>(abase + (ok ? aoff[it] : safe_a));
-                amask |= ok ? (1u << it) : 0u;
-            }
-#pragma unroll
-            for (int it = 0; it < GITER; ++it) {
-                const bool ok = !((bface & 16u) && ((gw0 >> it) & 1u));
-                vg[it] = *reinterpret_cast<const float4*>(gbase + (ok ? goff[it] : safe_g));
-                gmask |= ok ? (1u << it) : 0u;
-            }
-            return;
-        }
+        return ch_full && d0 + TD <= p.D && h0 + TH <= p.H && w0 + TW <= p.W;
+    };
+    // a full box's only out-of-volume items sit on halo faces that coincide with volume faces: they fetch the box
+    // origin instead (no branch) and are zeroed when written to LDS
+    auto fetch_a = [&](int it) {
+        const bool ok = (fw[it / FPW] & (pf_bface << (6 * (it % FPW)))) == 0u;
+        va[it] = *reinterpret_cast<const float4*>(pf_abase + (ok ? aoff[it] : safe_a));
+        amask |= ok ? (1u << it) : 0u;
+    };
+    auto fetch_g = [&](int it) {
+        const bool ok = !((pf_bface & 16u) && ((gw0 >> it) & 1u));
+        vg[it] = *reinterpret_cast<const float4*>(pf_gbase + (ok ? goff[it] : safe_g));
+        gmask |= ok ? (1u << it) : 0u;
+    };
+    auto load_ragged = [&](Box b) {                // per-item bounds checks (volume not a multiple of the box, channel tails)
+        const int d0 = b.tz * TD, h0 = b.ty * TH, w0 = b.tx * TW;
 #pragma unroll
         for (int it = 0; it < AITER; ++it) {
             const int e = tid + it * 256, v = e / AQ;
@@ -943,7 +943,7 @@ __global__ __launch_bounds__(256, CTU_K3S_OCC) void conv3d_wgrad_k3s_kernel(WgP 
                             (unsigned)gw < (unsigned)p.W;
             float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
             if (ok) {
-                val = *reinterpret_cast<const float4*>(abase + aoff[it]);
+                val = *reinterpret_cast<const float4*>(pf_abase + aoff[it]);
                 amask |= 1u << it;
             }
             va[it] = val;
@@ -956,7 +956,7 @@ __global__ __launch_bounds__(256, CTU_K3S_OCC) void conv3d_wgrad_k3s_kernel(WgP 
             const bool ok = e < GITEMS && g_ok && gd < p.D && gh < p.H && (unsigned)gw < (unsigned)p.W;
             float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
             if (ok) {
-                val = *reinterpret_cast<const float4*>(gbase + goff[it]);
+                val = *reinterpret_cast<const float4*>(pf_gbase + goff[it]);
                 gmask |= 1u << it;
             }
             vg[it] = val;
@@ -968,98 +968,124 @@ __global__ __launch_bounds__(256, CTU_K3S_OCC) void conv3d_wgrad_k3s_kernel(WgP 
     lds_f_ptr vA = (lds_f_ptr)sA + ((wave * HH * HW + kq) * CM + i);
     lds_f_ptr vG = (lds_f_ptr)sG + ((wave * TH * GW + kq + (SN - 1)) * CN + boff);
 
-    if (tile < tile_end) load(box);
-#ifdef CTU_STAMP
-    unsigned long long tq0 = 0, tq1 = 0, tq2 = 0, tq3 = 0, tq4 = 0, ph[5] = {0, 0, 0, 0, 0}, nst = 0;
-    STAMP(tq0);
-#endif
+    // one staged item -> LDS stage st: transform (identity scale/shift without BatchNorm), zero what lies outside
+    auto put_a = [&](int it, int st) {
+        const float4 t = xform4(va[it], sc, sh, xf_relu);
+        const bool ok = (amask >> it) & 1u;
+        *reinterpret_cast<float4*>(&sA[st * SAF + (tid + it * 256) * 4]) =
+            make_float4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f);
+    };
+    auto put_g = [&](int it, int st) {
+        const bool ok = (gmask >> it) & 1u;
+        *reinterpret_cast<float4*>(&sG[st * SGF + (tid + it * 256) * 4]) =
+            make_float4(ok ? vg[it].x : 0.f, ok ? vg[it].y : 0.f, ok ? vg[it].z : 0.f, ok ? vg[it].w : 0.f);
+    };
+
+    // One box: NKS K-steps of 4 voxels per wave (plane td = wave, row th = ks / KPR, columns (ks % KPR) * 4 + kq).
+    // The NKS * NMF (K-step, tap) MFMAs form one flat stream; their A fragments go through a ring of R registers
+    // refilled R entries ahead (the slot an MFMA has just consumed), the B fragment one K-step ahead.  Between the
+    // MFMAs of the first half of the K-steps the next box's global loads are issued (FETCH), between those of the
+    // second half that box is transformed and written to the other LDS stage -- no phase of its own for either.
+    constexpr bool INLOOP_FETCH = (SM == 2 && SN == 2);      // (the wider tiles run out of registers)
+    int cur = 0;
+    auto stage = [&](auto fetch_tag) {
+        constexpr bool FETCH = decltype(fetch_tag)::value;
+        constexpr int R = 12, NJ = NKS * NMF;
+        constexpr int KW0 = NKS / 2, NIT = AITER + GITER;
+        constexpr int IPF = (NIT + KW0 - 1) / KW0, IPK = (NIT + (NKS - KW0) - 1) / (NKS - KW0);
+        lds_f_ptr cA = vA + cur * SAF;
+        lds_f_ptr cG = vG + cur * SGF;
+        float ar[R], br[2];
+        auto a_read = [&](int j) -> float {
+            const int ks = j / NMF, t = j % NMF;
+            const int th = ks / KPR, tw4 = (ks % KPR) * 4;
+            const int r = t / QN, q = t % QN, kd = r / 3, kh = r % 3;
+            return cA[((kd * HH + th + kh) * HW + tw4 + q) * CM];
+        };
+        auto b_read = [&](int ks) -> float { return cG[((ks / KPR) * GW + (ks % KPR) * 4) * CN]; };
+        br[0] = b_read(0);
+#pragma unroll
+        for (int j = 0; j < R; ++j) ar[j] = a_read(j);
+        // the whole ring is in flight before the first MFMA (one exposed LDS latency per box): a fake use of
+        // every slot keeps the scheduler from trickling the fill reads in between the first MFMAs
+        static_assert(R == 12, "fake-use list");
+        asm volatile("" : "+v"(ar[0]), "+v"(ar[1]), "+v"(ar[2]), "+v"(ar[3]), "+v"(ar[4]), "+v"(ar[5]), "+v"(ar[6]),
+                     "+v"(ar[7]), "+v"(ar[8]), "+v"(ar[9]), "+v"(ar[10]), "+v"(ar[11]), "+v"(br[0]));
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            if (ks + 1 < NKS) {
+                br[(ks + 1) & 1] = b_read(ks + 1);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < NMF; ++t) {
+                const int j = ks * NMF + t;
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[j % R], br[ks & 1], acc[t], 0, 0, 0);
+                if (j + R < NJ) ar[j % R] = a_read(j + R);
+                // pin the order: MFMA, then the refill of the slot it consumed
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (j + R < NJ) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            if (FETCH && ks < KW0) {
+#pragma unroll
+                for (int q = 0; q < IPF; ++q) {
+                    const int it = ks * IPF + q;
+                    if (it < AITER) fetch_a(it);
+                    else if (it < NIT) fetch_g(it - AITER);
+                }
+            }
+            if (ks >= KW0) {
+#pragma unroll
+                for (int q = 0; q < IPK; ++q) {
+                    const int it = (ks - KW0) * IPK + q;
+                    if (it < AITER) put_a(it, cur ^ 1);
+                    else if (it < NIT) put_g(it - AITER, cur ^ 1);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    if (tile < tile_end) {
+        if (prep(box)) {
+#pragma unroll
+            for (int it = 0; it < AITER; ++it) fetch_a(it);
+#pragma unroll
+            for (int it = 0; it < GITER; ++it) fetch_g(it);
+        } else {
+            load_ragged(box);
+        }
+#pragma unroll
+        for (int it = 0; it < AITER; ++it) put_a(it, 0);
+#pragma unroll
+        for (int it = 0; it < GITER; ++it) put_g(it, 0);
+    }
+    __syncthreads();
     while (tile < tile_end) {
-        __syncthreads();
-        STAMP(tq1);
-        if (all_valid) {
-#pragma unroll
-            for (int it = 0; it < AITER; ++it) {
-                const int e = tid + it * 256;
-                if ((it + 1) * 256 <= AITEMS || e < AITEMS)
-                    *reinterpret_cast<float4*>(&sA[e * 4]) = has_xf ? xform4(va[it], sc, sh, p.in_relu) : va[it];
-            }
-        } else {                                   // padding / absent channels are zeros AFTER the transform
-#pragma unroll
-            for (int it = 0; it < AITER; ++it) {
-                const int e = tid + it * 256;
-                const float4 t = has_xf ? xform4(va[it], sc, sh, p.in_relu) : va[it];
-                const bool ok = (amask >> it) & 1u;
-                if ((it + 1) * 256 <= AITEMS || e < AITEMS)
-                    *reinterpret_cast<float4*>(&sA[e * 4]) = make_float4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f);
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < GITER; ++it) {
-            const int e = tid + it * 256;
-            const bool ok = all_valid || ((gmask >> it) & 1u);
-            if ((it + 1) * 256 <= GITEMS || e < GITEMS)
-                *reinterpret_cast<float4*>(&sG[e * 4]) =
-                    make_float4(ok ? vg[it].x : 0.f, ok ? vg[it].y : 0.f, ok ? vg[it].z : 0.f, ok ? vg[it].w : 0.f);
-        }
-        __syncthreads();
-        STAMP(tq2);
         box = box_next(box);
-        if (tile + 1 < tile_end) load(box);
-        STAMP(tq3);
-        {
-            // plane td = wave: NKS K-steps of 4 voxels (row th = ks / KPR, columns (ks % KPR) * 4 + kq).  The NKS * NMF
-            // (K-step, tap) MFMAs form one flat stream; their A fragments go through a ring of R registers that is
-            // refilled R entries ahead (the slot an MFMA has just consumed), the B fragment one K-step ahead.
-            constexpr int R = 12, NJ = NKS * NMF;
-            float ar[R], br[2];
-            auto a_read = [&](int j) -> float {
-                const int ks = j / NMF, t = j % NMF;
-                const int th = ks / KPR, tw4 = (ks % KPR) * 4;
-                const int r = t / QN, q = t % QN, kd = r / 3, kh = r % 3;
-                return vA[((kd * HH + th + kh) * HW + tw4 + q) * CM];
-            };
-            auto b_read = [&](int ks) -> float { return vG[((ks / KPR) * GW + (ks % KPR) * 4) * CN]; };
-            br[0] = b_read(0);
-#pragma unroll
-            for (int j = 0; j < R; ++j) ar[j] = a_read(j);
-            // the whole ring is in flight before the first MFMA (one exposed LDS latency per box): a fake use of
-            // every slot keeps the scheduler from trickling the fill reads in between the first MFMAs
-            static_assert(R == 12, "fake-use list");
-            asm volatile("" : "+v"(ar[0]), "+v"(ar[1]), "+v"(ar[2]), "+v"(ar[3]), "+v"(ar[4]), "+v"(ar[5]), "+v"(ar[6]),
-                         "+v"(ar[7]), "+v"(ar[8]), "+v"(ar[9]), "+v"(ar[10]), "+v"(ar[11]), "+v"(br[0]));
-#pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) {
-                if (ks + 1 < NKS) {
-                    br[(ks + 1) & 1] = b_read(ks + 1);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
-#pragma unroll
-                for (int t = 0; t < NMF; ++t) {
-                    const int j = ks * NMF + t;
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[j % R], br[ks & 1], acc[t], 0, 0, 0);
-                    if (j + R < NJ) ar[j % R] = a_read(j + R);
-                    // pin the order: MFMA, then the refill of the slot it consumed
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    if (j + R < NJ) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
-            }
+        bool full = false;
+        if (tile + 1 < tile_end) {
+            full = prep(box);
+            if (!full) load_ragged(box);
         }
-#ifdef CTU_STAMP
-        STAMP(tq4);
-        ph[0] += tq1 - tq0; ph[1] += tq2 - tq1; ph[2] += tq3 - tq2; ph[3] += tq4 - tq3;
-        tq0 = tq4; ++nst;
-#endif
+        // (after the last box the second half rewrites stale registers into the unread stage)
+        if (INLOOP_FETCH && full) {
+            stage(std::true_type{});
+        } else {
+            if (INLOOP_FETCH == false && full) {
+#pragma unroll
+                for (int it = 0; it < AITER; ++it) fetch_a(it);
+#pragma unroll
+                for (int it = 0; it < GITER; ++it) fetch_g(it);
+            }
+            stage(std::false_type{});
+        }
+        __syncthreads();                           // stage cur fully read, stage cur ^ 1 fully written
+        cur ^= 1;
         ++tile;
     }
-#ifdef CTU_STAMP
-    if (g_stamp_out && tid == 0) {
-        unsigned long long* o = g_stamp_out + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 6;
-        for (int k = 0; k < 5; ++k) o[k] = ph[k];
-        o[5] = nst;
-    }
-#endif
     // 4 waves -> one slab [NMF][16][16] per block (through sA, 4 * NMF * 256 floats <= HV * CM for CM = 8 needs rounds)
-    constexpr int RT = (HV * CM / 1024) < NMF ? (HV * CM / 1024) : NMF;
+    constexpr int RT = (2 * SAF / 1024) < NMF ? (2 * SAF / 1024) : NMF;
     static_assert(RT >= 1, "reduction scratch");
     const size_t slab = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
     float* dst = p.ws + slab * (NMF * 256);
@@ -1119,7 +1145,7 @@ struct K3sGeom { int sm, sn, tw, ntiles, n_ci_g, pairs, gx, tpb, nmf; };
 static K3sGeom k3s_geom(int N, int D, int H, int W, int cin_p, int cout_p) {
     K3sGeom g;
     g.sm = cin_p == 8 ? 2 : 1; g.sn = cout_p == 8 ? 2 : 1;
-    g.tw = (g.sm == 1) ? 8 : 16;
+    g.tw = (g.sm == 2 && g.sn == 2) ? 16 : 8;
     g.nmf = (g.sm == 2 && g.sn == 2) ? 9 : ((g.sm == 1 && g.sn == 1) ? 27 : 18);
     g.ntiles = N * ceil_div(D, 4) * ceil_div(H, 4) * ceil_div(W, g.tw);
     g.n_ci_g = ceil_div(cin_p, 16 / g.sm);
