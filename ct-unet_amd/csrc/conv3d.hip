@@ -633,13 +633,14 @@ __global__ void pack_conv_w_kernel(const float* __restrict__ w, float* __restric
 // Launch shape: output-channel tiles per block (NT) and spatial tile.  Big volumes take the widest tile
 // and up to 4 N-tiles per block (best operand reuse); small volumes (the 8^3/16^3 bottleneck levels)
 // shrink both so that the grid still covers the 256 CUs.
-inline void pick_launch(int N, int D, int H, int W, int nout_p, int* nt, int* td, int* th, int* tw) {
+inline void pick_launch(int N, int D, int H, int W, int k, int nout_p, int* nt, int* td, int* th, int* tw) {
     const int n16 = (nout_p + 15) / 16;
     *nt = n16 == 1 ? 1 : (n16 == 2 ? 2 : 4);
     pick_tile(W, td, th, tw);
     auto blocks = [&](int nt_, int td_, int th_, int tw_) {
         return (long)N * ceil_div(D, td_) * ceil_div(H, th_) * ceil_div(W, tw_) * ceil_div(n16, nt_);
     };
+    if (k == 3 && *tw == 16 && *nt > 2) *nt = 2;    // k = 3 at this width runs the persistent kernel (at most 2 N-tiles)
     while (blocks(*nt, *td, *th, *tw) < 256 && *nt > 1) *nt >>= 1;
     if (blocks(*nt, *td, *th, *tw) < 256 && *tw > 4) { *td = 4; *th = 4; *tw = 4; }
 }
@@ -1181,7 +1182,7 @@ extern "C" const char* ctu_conv3d_fwd_kernel_name(int N, int D, int H, int W, in
     static thread_local char buf[64];
     if (layout == 1) return "conv3d_fwd_k3_persist<1, true>";
     int nt, td, th, tw;
-    pick_launch(N, D, H, W, nout_p, &nt, &td, &th, &tw);
+    pick_launch(N, D, H, W, k, nout_p, &nt, &td, &th, &tw);
     if (k == 3 && tw == 16 && nt <= 2) snprintf(buf, sizeof(buf), "conv3d_fwd_k3_persist<%d, false>", nt);
     else snprintf(buf, sizeof(buf), "conv3d_fwd_kernel<%d, %d, %d, %d, %d>", k, nt, td, th, tw);
     return buf;
@@ -1224,7 +1225,7 @@ extern "C" int ctu_conv3d_num_blocks(int N, int D, int H, int W, int k, int nout
         return gx;                                   // the persistent kernels write ONE stats row per block
     }
     int nt, td, th, tw;
-    pick_launch(N, D, H, W, nout_p, &nt, &td, &th, &tw);
+    pick_launch(N, D, H, W, k, nout_p, &nt, &td, &th, &tw);
     const int ntiles = N * ceil_div(D, td) * ceil_div(H, th) * ceil_div(W, tw);
     if (use_persist(k, nt, tw)) {
         persist_grid(ntiles, ceil_div(ceil_div(nout_p, 16), nt), nt == 1 ? 3 : 2, &gx, &tpb);
@@ -1334,7 +1335,7 @@ extern "C" int ctu_conv3d_fwd(const float* in, int in_cs, int rin_p, const float
     }
     CTU_REQUIRE(layout == 0, "conv3d_fwd: unknown layout %d", layout);
     int NT, td, th, tw;
-    pick_launch(N, D, H, W, nout_p, &NT, &td, &th, &tw);
+    pick_launch(N, D, H, W, k, nout_p, &NT, &td, &th, &tw);
     if (use_persist(k, NT, tw)) {
         // large layers: persistent, register-prefetching kernel
         p.n16 = ceil_div(p.nout_p, 16);
