@@ -252,6 +252,28 @@ __global__ void maxpool2_fwd_kernel(const float* __restrict__ in, int in_cs, int
     *reinterpret_cast<float4*>(out + ovox * out_cs + qd * 4) = best;
 }
 
+// ---- additive skip connections (UNet(cat=False), models.py:250-251): out = act(a) + act(b), act = lazy BN + ReLU
+__global__ void skip_add_kernel(const float* __restrict__ a, int a_cs, const float* __restrict__ a_scale,
+                                const float* __restrict__ a_shift, int a_relu, const float* __restrict__ b, int b_cs,
+                                const float* __restrict__ b_scale, const float* __restrict__ b_shift, int b_relu,
+                                float* __restrict__ out, int out_cs, int cp, int64_t nvox) {
+    const int nq = cp >> 2;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nvox * nq) return;
+    const int qd = (int)(idx % nq);
+    const int64_t v = idx / nq;
+    float4 x = *reinterpret_cast<const float4*>(a + v * a_cs + qd * 4);
+    if (a_scale)
+        x = xform4(x, *reinterpret_cast<const float4*>(a_scale + qd * 4), *reinterpret_cast<const float4*>(a_shift + qd * 4), a_relu);
+    if (b) {
+        float4 y = *reinterpret_cast<const float4*>(b + v * b_cs + qd * 4);
+        if (b_scale)
+            y = xform4(y, *reinterpret_cast<const float4*>(b_scale + qd * 4), *reinterpret_cast<const float4*>(b_shift + qd * 4), b_relu);
+        x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
+    }
+    *reinterpret_cast<float4*>(out + v * out_cs + qd * 4) = x;
+}
+
 __global__ void maxpool2_bwd_kernel(const float* __restrict__ in, int in_cs, int cp, const float* __restrict__ scale,
                                     const float* __restrict__ shift, int relu, const float* __restrict__ gout,
                                     int gout_cs, float* __restrict__ gin, int gin_cs, int accumulate, int N, int D,
@@ -500,6 +522,20 @@ extern "C" int ctu_maxpool2_bwd(const float* in, int in_cs, int cp, const float*
     maxpool2_bwd_kernel<<<(unsigned)ceil_div64(total, EW_BLOCK), EW_BLOCK, 0, (hipStream_t)stream>>>(
         in, in_cs, cp, in_scale, in_shift, in_relu, gout, gout_cs, gin, gin_cs, accumulate, N, D, H, W);
     CTU_CHECK_LAUNCH("maxpool2_bwd");
+    return CTU_OK;
+}
+
+extern "C" int ctu_skip_add(const float* a, int a_cs, const float* a_scale, const float* a_shift, int a_relu,
+                            const float* b, int b_cs, const float* b_scale, const float* b_shift, int b_relu,
+                            float* out, int out_cs, int cp, int64_t nvox, void* stream) {
+    CTU_REQUIRE(a && out, "skip_add: null pointer");
+    CTU_REQUIRE(cp % 4 == 0 && cp > 0 && a_cs % 4 == 0 && out_cs % 4 == 0 && (!b || b_cs % 4 == 0), "skip_add: channel counts / strides must be multiples of 4");
+    CTU_REQUIRE((a_scale == nullptr) == (a_shift == nullptr) && (b_scale == nullptr) == (b_shift == nullptr), "skip_add: scale/shift come in pairs");
+    if (nvox <= 0) return CTU_OK;
+    const int64_t total = nvox * (cp >> 2);
+    skip_add_kernel<<<(unsigned)ceil_div64(total, EW_BLOCK), EW_BLOCK, 0, (hipStream_t)stream>>>(
+        a, a_cs, a_scale, a_shift, a_relu, b, b_cs, b_scale, b_shift, b_relu, out, out_cs, cp, nvox);
+    CTU_CHECK_LAUNCH("skip_add");
     return CTU_OK;
 }
 

@@ -51,6 +51,7 @@ class NetPlan:
     head: str
     act: int             # bit0 softmax, bit1 sigmoid
     head_mode: int       # 0 plain, 1 SP re-encoding, 2 SP + softmax
+    skip: str = "cat"    # how a decoder level meets its encoder skip (models.py:247-253): "cat" | "add" | "none"
 
 
 class _ConvRec:
@@ -270,8 +271,17 @@ class UNetEngine:
                                                       v1, training, n_upd, save)
             a2, recs[(blk.prefix, 2)] = self._conv_bn(P, a1, f"{blk.prefix}.4", f"{blk.prefix}.5", blk.cout, blk.cout, None,
                                                       CL(cat[i], 0, cp), xf[i][:, :cp], training, n_upd, save)
-            cur = CL(cat[i], 0, 2 * cp, xf[i][0], xf[i][1], True)
-            cur_segs = ((blk.cout, 0), (blk.cout, cp))
+            if plan.skip == "cat":               # free concat: both producers wrote channel slices of cat[i]
+                cur = CL(cat[i], 0, 2 * cp, xf[i][0], xf[i][1], True)
+                cur_segs = ((blk.cout, 0), (blk.cout, cp))
+            elif plan.skip == "none":
+                cur = CL(cat[i], 0, cp, xf[i][0][:cp], xf[i][1][:cp], True)
+                cur_segs = ((blk.cout, 0),)
+            else:                                # "add": the sum of two differently normalised tensors is materialised
+                cur = CL(torch.empty((n, dd, hh, ww, cp), dtype=torch.float32, device=dev), 0, cp)
+                ops.skip_add(CL(cat[i], 0, cp, xf[i][0][:cp], xf[i][1][:cp], True),
+                             CL(cat[i], cp, cp, xf[i][0][cp:], xf[i][1][cp:], True), cur)
+                cur_segs = ((blk.cout, 0),)
         # ---- head
         imap_h, _ = self._maps(cur_segs, cur.cp, dev)
         if self._nbt:
@@ -359,8 +369,21 @@ class UNetEngine:
         gcat = [torch.empty_like(c) for c in cat]
         wl, bl = P[plan.head + ".weight"], P[plan.head + ".bias"]
         w2 = wl.detach().reshape(wl.shape[0], wl.shape[1])
+        def g_skip_target(level: int) -> CL:
+            """Where the gradient w.r.t. the tensor a decoder level hands on (cat / sum / plain output) is written."""
+            full = gcat[level].shape[-1]
+            return CL(gcat[level], 0, full if plan.skip == "cat" else full // 2)
+
+        def g_skip_fanout(level: int):
+            """additive skip: d(sum) reaches both addends -- copy it into the encoder half before the decoder's
+            BatchNorm backward overwrites the first half in place"""
+            if plan.skip == "add":
+                half = gcat[level].shape[-1] // 2
+                ops.skip_add(CL(gcat[level], 0, half), None, CL(gcat[level], half, half))
+
         dwl, dbl = ops.head_bwd(head_in, w2, bl.detach(), ctx["imap_h"], plan.act, plan.head_mode, g0.contiguous(),
-                                None if g1 is None else g1.contiguous(), CL(gcat[0], 0, gcat[0].shape[-1]))
+                                None if g1 is None else g1.contiguous(), g_skip_target(0))
+        g_skip_fanout(0)
         grads[plan.head + ".weight"], grads[plan.head + ".bias"] = dwl.reshape(wl.shape), dbl
         emit()
 
@@ -378,19 +401,23 @@ class UNetEngine:
             self._conv_bn_bwd(P, r1, g_u1, g_up, grads, ws, part)
             x_in = ctx["dec_in"][j]
             ct = blk.cin
-            segs = ((plan.dec[j - 1].cout, 0), (plan.dec[j - 1].cout, pad8(plan.dec[j - 1].cout))) if j > 0 else \
-                ((ct, 0),)
+            if j > 0 and plan.skip == "cat":
+                segs = ((plan.dec[j - 1].cout, 0), (plan.dec[j - 1].cout, pad8(plan.dec[j - 1].cout)))
+            else:
+                segs = ((ct, 0),)
             imap_t, cinv_t = self._maps(segs, x_in.cp, dev)
             wt = P[f"{blk.prefix}.0.weight"]
             dwt, dbt = ops.convt_wgrad(x_in, g_up, ct, ct, imap_t, ws)
             grads[f"{blk.prefix}.0.weight"], grads[f"{blk.prefix}.0.bias"] = dwt, dbt
             wpd = self._packed(f"{blk.prefix}.0", wt, "convt", cinv_t, g_up.cp, x_in.cp, 1)
             if j > 0:
-                gin = CL(gcat[i + 1], 0, gcat[i + 1].shape[-1])
+                gin = g_skip_target(i + 1)
             else:
                 gin = CL(torch.empty_like(x_in.buf), 0, x_in.cp)
                 g_deep = gin
             ops.convt_bwd_data(g_up, wpd, gin)
+            if j > 0:
+                g_skip_fanout(i + 1)
             emit()
         g_pool = g_deep
         if plan.center_live:
@@ -407,7 +434,7 @@ class UNetEngine:
             cp = pad8(blk.cout)
             r1, r2 = recs[(blk.prefix, 1)], recs[(blk.prefix, 2)]
             g_d2 = CL(gcat[i], cp, cp)
-            ops.maxpool_bwd(ctx["dskip"][i], g_pool, g_d2, True)
+            ops.maxpool_bwd(ctx["dskip"][i], g_pool, g_d2, plan.skip != "none")     # accumulate onto the skip's gradient
             g_d1 = CL(torch.empty_like(r1.y.buf), 0, cp)
             self._conv_bn_bwd(P, r2, g_d2, g_d1, grads, ws, part)
             if i > 0:

@@ -12,8 +12,8 @@ Reference: /root/reference/ctunet/pytorch/models.py
   recAE_v2_fixed :441-538, UNet4_2IC :541-557.
 
 Not supported (dead or unreachable in the reference): ``residual=True``,
-``fc_layer`` -- both crash in the reference itself -- and ``cat=False`` /
-``use_skip_connections=False`` / ``dropout_p>0`` (no shipped class sets them); they raise
+``fc_layer`` -- both crash in the reference itself -- and ``dropout_p>0`` (no shipped class sets
+it; its random mask could not be compared with the reference's anyway); they raise
 ``NotImplementedError`` here instead of silently computing something else.
 """
 from __future__ import annotations
@@ -138,9 +138,6 @@ class UNet(_HipNet):
             raise NotImplementedError("ctunet_amd: residual=True crashes in the reference itself (SURVEY 2.1)")
         if fc_layer:
             raise NotImplementedError("ctunet_amd: fc_layer is dead code in the reference (SURVEY 2.1)")
-        if not (use_skip_connections and cat):
-            raise NotImplementedError("ctunet_amd: only use_skip_connections=True, cat=True (every shipped class) "
-                                      "is implemented")
         if out_channels > 4:
             raise NotImplementedError("ctunet_amd: the output head supports at most 4 channels")
         self.chk = use_checkpoint
@@ -160,20 +157,22 @@ class UNet(_HipNet):
         for i in range(n - 1, -1, -1):
             # deepest up-block takes the pooled encoder output (NOT the centre block, models.py:241);
             # the others take [previous up-block | encoder skip] = 4 * widths[i] channels.
-            c_in = widths[i] if i == n - 1 else 4 * widths[i]
+            # (models.py:209-217: half of that when the skip is added instead of concatenated, or absent)
+            c_in = widths[i] if i == n - 1 else (4 if (use_skip_connections and cat) else 2) * widths[i]
             ups.append(UNetBlock(c_in, widths[i], kern_sz_conv, kern_sz_upconv, padding, stride_conv, stride_upconv,
                                  dropout_p, True))
         self.u_blocks = nn.ModuleList(ups)
-        self.last_conv = _ConvParams(2 * i_size, out_channels, 1, True)
+        self.last_conv = _ConvParams(2 * i_size if (use_skip_connections and cat) else i_size, out_channels, 1, True)
 
         enc = [BlockPlan(f"d_blocks.{i}.block", 0, input_channels if i == 0 else widths[i - 1], widths[i])
                for i in range(n)]
-        dec = [BlockPlan(f"u_blocks.{j}.block", 1, widths[n - 1 - j] if j == 0 else 4 * widths[n - 1 - j],
+        fan = 4 if (use_skip_connections and cat) else 2
+        dec = [BlockPlan(f"u_blocks.{j}.block", 1, widths[n - 1 - j] if j == 0 else fan * widths[n - 1 - j],
                          widths[n - 1 - j]) for j in range(n)]
         self._plan = NetPlan(k=kern_sz_conv, conv_bias=False, in_ch=input_channels, out_ch=out_channels, enc=enc,
                              center=BlockPlan("cblock.block", 0, widths[n - 1], widths[n]), center_live=False, dec=dec,
                              head="last_conv", act=(1 if apply_softmax else 0) | (2 if apply_sigmoid else 0),
-                             head_mode=0)
+                             head_mode=0, skip="none" if not use_skip_connections else ("cat" if cat else "add"))
 
     def forward(self, x):
         return self._run(x)

@@ -486,6 +486,17 @@ def loss_bwd(pred, target, ce_lambda, dice_lambda, dice_softmax, ws, gscale: Opt
 
 
 # ---------------------------------------------------------------------------- misc
+
+def skip_add(a: CL, b: Optional[CL], out: CL) -> None:
+    """out = act(a) + act(b) (additive skip, UNet(cat=False)); b None: out = act(a) (channel-slice copy)."""
+    assert out.dims == a.dims and out.cp == a.cp and (b is None or (b.dims == a.dims and b.cp == a.cp))
+    _lib.check(_lib.load().ctu_skip_add(a.ptr, a.cs, _ptr(a.scale), _ptr(a.shift), int(a.relu),
+                                        0 if b is None else b.ptr, 0 if b is None else b.cs,
+                                        _ptr(b.scale) if b is not None else 0, _ptr(b.shift) if b is not None else 0,
+                                        int(b.relu) if b is not None else 0, out.ptr, out.cs, out.cp, a.nvox, _stream()),
+               "skip_add")
+
+
 def channel_sum(x: CL, c: int) -> torch.Tensor:
     lib = _lib.load()
     nb = lib.ctu_channel_sum_num_blocks(x.nvox)

@@ -252,6 +252,12 @@ int ctu_loss_bwd(const float* pred, const float* target, int N, int64_t V, float
                  float* gpred, int accumulate, void* stream);
 
 /* -------------------------------------------------------------- utilities ---- */
+/* Additive skip connection, UNet(cat=False): out = act_a(a) + act_b(b) on channels-last tensors, where act_x is the
+ * lazy BatchNorm(+ReLU) transform of that operand (scale/shift NULL: identity).  b == NULL: out = act_a(a), which is
+ * also the strided channel-slice copy the backward of the add uses (/root/reference/ctunet/pytorch/models.py:250-251). */
+int ctu_skip_add(const float* a, int a_cs, const float* a_scale, const float* a_shift, int a_relu,
+                 const float* b, int b_cs, const float* b_scale, const float* b_shift, int b_relu,
+                 float* out, int out_cs, int cp, int64_t nvox, void* stream);
 /* Per-channel sum over voxels of a channels-last tensor: out[c] = sum_v x[v,c] (bias grads). */
 int ctu_channel_sum_num_blocks(int64_t nvox);
 int ctu_channel_sum(const float* x, int cs, int cp, int64_t nvox, float* partials,

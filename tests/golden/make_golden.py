@@ -11,8 +11,8 @@ files.  Nothing from the reference's source text is stored.
 
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
 
-torch 2.10.0+rocm7.0 CPU, 8 threads.  Fixtures: tiny_unet.npz, tiny_unet_sp.npz,
-tiny_legacy.npz, losses.npz, class_checksums.json, ini_params.json.
+torch 2.10.0+rocm7.0 CPU, 8 threads.  Fixtures: tiny_unet.npz, tiny_unet_add.npz,
+tiny_unet_noskip.npz, tiny_unet_sp.npz, tiny_legacy.npz, losses.npz, class_checksums.json, ini_params.json.
 """
 import glob
 import importlib.util
@@ -129,6 +129,31 @@ def tiny_generic(ref, U, PH):
     rec["chk_dead_grad_is_none"] = np.array([int(p.grad is None) for n_, p in net2.named_parameters() if n_.startswith("cblock.")])
     np.savez_compressed(f"{HERE}/tiny_unet.npz", **rec)
     print("tiny_unet", rec["eval_out0"].mean(), rec["train_loss"])
+
+
+def tiny_skip_modes(ref, U, PH):
+    """UNet(cat=False) (additive skips, models.py:250-251) and UNet(use_skip_connections=False) (models.py:252-253):
+    options no shipped class sets but that are live in UNet.__init__/forward.  apply_softmax is switched on for the
+    first so the softmax-then-sigmoid head (models.py:258-259) is pinned as well."""
+    for tag, kw in (("add", dict(cat=False, apply_softmax=True)), ("noskip", dict(use_skip_connections=False))):
+        torch.manual_seed(17)
+        net = ref.UNet(input_channels=1, out_channels=2, n_blocks=2, i_size=3, use_checkpoint=False, **kw)
+        randomize_bn(net, 13)
+        x = torch.randn(2, 1, 16, 16, 16, generator=gen(23))
+        tgt = onehot_target(x.shape, 33)
+        rec = {"x": x.numpy(), "target": tgt.numpy()}
+        rec.update({"sd." + k: v for k, v in to_np(net.state_dict()).items()})
+        net.eval()
+        with torch.no_grad():
+            rec["eval_out0"] = net(x).numpy()
+
+        def loss_fn(out):
+            h = Holder(1.0, 1.0)
+            PH.ProblemHandler.comp_losses_metrics(h, out, tgt, 0, 1)
+            return h.pt_loss
+        rec.update(step_record(net, x, loss_fn))
+        np.savez_compressed(f"{HERE}/tiny_unet_{tag}.npz", **rec)
+        print("tiny_unet_" + tag, rec["eval_out0"].mean(), rec["train_loss"])
 
 
 def tiny_sp(ref, U, PH):
@@ -283,7 +308,11 @@ def ini_params(ref, U, PH):
 
 if __name__ == "__main__":
     ref, U, PH = load_ref()
+    if len(sys.argv) > 1 and sys.argv[1] == "skip_modes":      # only the fixtures added last
+        tiny_skip_modes(ref, U, PH)
+        sys.exit(0)
     tiny_generic(ref, U, PH)
+    tiny_skip_modes(ref, U, PH)
     tiny_sp(ref, U, PH)
     tiny_legacy(ref, U, PH)
     losses(ref, U, PH)

@@ -9,7 +9,7 @@ import re
 import pytest
 import torch
 
-from util import GOLDEN, load_json
+from util import load_npz, GOLDEN, load_json
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "ctunet_hip.h")
@@ -95,10 +95,23 @@ def test_state_dict_and_seeded_init_match_reference(name):
 
 def test_unsupported_options_raise():
     import ctunet_amd
-    for kw in (dict(residual=True), dict(fc_layer=[8, 4]), dict(cat=False), dict(use_skip_connections=False),
-               dict(dropout_p=0.5), dict(kern_sz_conv=7, padding=3), dict(out_channels=5)):
+    for kw in (dict(residual=True), dict(fc_layer=[8, 4]), dict(dropout_p=0.5), dict(kern_sz_conv=7, padding=3),
+               dict(out_channels=5)):
         with pytest.raises(NotImplementedError):
             ctunet_amd.UNet(**kw)
+
+
+def test_skip_mode_state_dicts_match_reference_fixtures():
+    """UNet(cat=False) / UNet(use_skip_connections=False): the channel plan (models.py:207-224) halves the decoder
+    inputs and the head input; keys and shapes must equal the reference's state dict recorded in the fixtures."""
+    import ctunet_amd
+    for name, kw in (("tiny_unet_add.npz", dict(cat=False, apply_softmax=True)),
+                     ("tiny_unet_noskip.npz", dict(use_skip_connections=False))):
+        rec = load_npz(name)
+        net = ctunet_amd.UNet(input_channels=1, out_channels=2, n_blocks=2, i_size=3, use_checkpoint=False, **kw)
+        want = {k[3:]: v.shape for k, v in rec.items() if k.startswith("sd.")}
+        got = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+        assert got == {k: tuple(s) for k, s in want.items()}
 
 
 def test_ini_parser_matches_reference():

@@ -43,6 +43,12 @@ def _tiny(name):
     _, M, _, _ = _mods()
     if name == "tiny_unet.npz":
         return M.UNet(input_channels=1, out_channels=2, n_blocks=2, i_size=3, use_checkpoint=False)
+    if name == "tiny_unet_add.npz":          # additive skips + softmax-then-sigmoid head (models.py:250-251,258-259)
+        return M.UNet(input_channels=1, out_channels=2, n_blocks=2, i_size=3, use_checkpoint=False, cat=False,
+                      apply_softmax=True)
+    if name == "tiny_unet_noskip.npz":       # no skip connections (models.py:252-253)
+        return M.UNet(input_channels=1, out_channels=2, n_blocks=2, i_size=3, use_checkpoint=False,
+                      use_skip_connections=False)
     if name == "tiny_unet_sp.npz":
         class TinySP(M.UNetSP):
             def __init__(self):
@@ -52,7 +58,8 @@ def _tiny(name):
     return M.recAE_v2_fixed(input_channels=1, i_size=1, use_checkpoint=False)
 
 
-@pytest.mark.parametrize("name", ["tiny_unet.npz", "tiny_unet_sp.npz", "tiny_legacy.npz"])
+@pytest.mark.parametrize("name", ["tiny_unet.npz", "tiny_unet_add.npz", "tiny_unet_noskip.npz", "tiny_unet_sp.npz",
+                                  "tiny_legacy.npz"])
 def test_tiny_nets_against_reference_fixtures(name):
     _, M, L, PH = _mods()
     rec = load_npz(name)

@@ -400,3 +400,27 @@ def test_layout_roundtrip_and_errors():
         ops.ncdhw_to_cl(x)                       # CPU tensor: no fallback
     with pytest.raises(_lib.CtuError):
         ops.pack_conv_w(torch.zeros(4, 4, 7, 7, 7).cuda(), None, 8, 8, 0)     # k=7 unsupported -> loud error
+
+
+@pytest.mark.parametrize("shape", [(1, 8, 4, 4, 4), (2, 12, 2, 6, 10)])
+def test_skip_add(shape):
+    """ctu_skip_add: out = act(a) + act(b) on channel SLICES of one wide buffer (UNet(cat=False), models.py:250-251)
+    and its b = None form (strided slice copy).  fp32 reference: relu(a*sa+sha) + relu(b*sb+shb), 1-ulp fma slack."""
+    ops = _ops()
+    n, c, d, h, w = shape
+    cp = ops.pad8(c)
+    a, b = torch.randn(shape, generator=g(5)), torch.randn(shape, generator=g(6))
+    sa, sha = xf_vectors(c, cp, 7)
+    sb, shb = xf_vectors(c, cp, 8)
+    wide = torch.zeros(n, d, h, w, 2 * cp, device="cuda")
+    wide[..., :c] = a.permute(0, 2, 3, 4, 1).cuda()
+    wide[..., cp:cp + c] = b.permute(0, 2, 3, 4, 1).cuda()
+    ca = ops.CL(wide, 0, cp, sa.cuda(), sha.cuda(), True)
+    cb = ops.CL(wide, cp, cp, sb.cuda(), shb.cuda(), True)
+    out = ops.CL(torch.empty(n, d, h, w, cp, device="cuda"), 0, cp)
+    ops.skip_add(ca, cb, out)
+    v = lambda t: t[:c].view(1, -1, 1, 1, 1)
+    ref = F.relu(a * v(sa) + v(sha)) + F.relu(b * v(sb) + v(shb))
+    assert torch.allclose(from_cl(out, c), ref, rtol=1e-6, atol=1e-6)
+    ops.skip_add(ops.CL(wide, 0, cp), None, ops.CL(wide, cp, cp))          # slice copy, bit exact
+    assert torch.equal(wide[..., cp:], wide[..., :cp])

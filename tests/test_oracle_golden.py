@@ -12,6 +12,8 @@ from util import CLASS_INPUT, close_summary, gen, load_json, load_npz, onehot_ta
 
 TINY = {
     "tiny_unet.npz": O.NetSpec(in_ch=1, out_ch=2, n_blocks=2, i_size=3),
+    "tiny_unet_add.npz": O.NetSpec(in_ch=1, out_ch=2, n_blocks=2, i_size=3, cat=False, apply_softmax=True),
+    "tiny_unet_noskip.npz": O.NetSpec(in_ch=1, out_ch=2, n_blocks=2, i_size=3, skip=False),
     "tiny_unet_sp.npz": O.NetSpec(in_ch=2, out_ch=3, n_blocks=2, i_size=3, head="sp"),
     "tiny_legacy.npz": O.NetSpec(family="legacy", in_ch=1, out_ch=2, i_size=1, k=5, pad=2),
 }
