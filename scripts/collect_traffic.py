@@ -11,7 +11,7 @@ import collections, csv, glob, json, sys
 
 
 def per_kernel(d, counter):
-    f = glob.glob(f"{d}/*/*counter_collection.csv")[0]
+    f = (glob.glob(f"{d}/*counter_collection.csv") + glob.glob(f"{d}/*/*counter_collection.csv"))[0]
     agg = collections.defaultdict(lambda: [0.0, 0])
     disp = collections.defaultdict(float)
     for r in csv.DictReader(open(f)):
