@@ -163,7 +163,8 @@ __global__ void bn_relu_bwd_reduce_kernel(const float* __restrict__ y, int y_cs,
 __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nb, int C, int cp, double count,
                                        const float* __restrict__ gamma, const float* __restrict__ invstd,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                       float* __restrict__ coef) {
+                                       float* __restrict__ coef, const float* __restrict__ mean,
+                                       float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps) {
     const int c = blockIdx.x;
     __shared__ double r1[EW_BLOCK], r2[EW_BLOCK];
     double s1 = 0.0, s2 = 0.0;
@@ -185,6 +186,16 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int n
             coef[c] = gamma[c] * invstd[c];
             coef[cp + c] = (float)(r1[0] / count);
             coef[2 * cp + c] = (float)(r2[0] / count);
+            if (rmean) {
+                // the running-stat update torch.utils.checkpoint's recompute repeats in backward (models.py:232-255):
+                // same batch statistics as the forward update; the biased variance is recovered from invstd
+                const double istd = (double)invstd[c];
+                double var = 1.0 / (istd * istd) - (double)eps;
+                if (var < 0.0) var = 0.0;
+                const float unb = (float)(var * (count / (count > 1.0 ? count - 1.0 : 1.0)));
+                rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean[c];
+                rvar[c] = (1.f - momentum) * rvar[c] + momentum * unb;
+            }
         } else {
             coef[c] = 0.f; coef[cp + c] = 0.f; coef[2 * cp + c] = 0.f;
         }
@@ -482,10 +493,14 @@ extern "C" int ctu_bn_relu_bwd_reduce(const float* y, int y_cs, const float* ga,
 }
 
 extern "C" int ctu_bn_bwd_finalize(const float* partials, int nb, int C, int cp, double count, const float* gamma,
-                                   const float* invstd, float* dgamma, float* dbeta, float* coef, void* stream) {
+                                   const float* invstd, float* dgamma, float* dbeta, float* coef, const float* mean,
+                                   float* running_mean, float* running_var, float momentum, float eps, void* stream) {
     CTU_REQUIRE(partials && gamma && invstd && dgamma && dbeta && coef, "bn_bwd_finalize: null pointer");
+    CTU_REQUIRE((running_mean == nullptr) == (running_var == nullptr) && (!running_mean || mean),
+                "bn_bwd_finalize: the running-stat replay needs mean, running_mean and running_var together");
     bn_bwd_finalize_kernel<<<cp, EW_BLOCK, 0, (hipStream_t)stream>>>(partials, nb, C, cp, count, gamma, invstd, dgamma,
-                                                                    dbeta, coef);
+                                                                    dbeta, coef, mean, running_mean, running_var,
+                                                                    momentum, eps);
     CTU_CHECK_LAUNCH("bn_bwd_finalize");
     return CTU_OK;
 }

@@ -53,7 +53,7 @@ SIGNATURES = {
     "ctu_bn_eval_affine": (I, [P, P, P, P, F, I, I, P, P, P]),
     "ctu_bn_bwd_num_blocks": (I, [L]),
     "ctu_bn_relu_bwd_reduce": (I, [P, I, P, I, I, P, P, P, P, L, P, P]),
-    "ctu_bn_bwd_finalize": (I, [P, I, I, I, D, P, P, P, P, P, P]),
+    "ctu_bn_bwd_finalize": (I, [P, I, I, I, D, P, P, P, P, P, P, P, P, F, F, P]),
     "ctu_bn_relu_bwd_apply": (I, [P, I, P, I, I, P, P, P, P, P, L, P]),
     "ctu_maxpool2_fwd": (I, [P, I, I, P, P, I, P, I, I, I, I, I, P]),
     "ctu_maxpool2_bwd": (I, [P, I, I, P, P, I, P, I, P, I, I, I, I, I, I, P]),

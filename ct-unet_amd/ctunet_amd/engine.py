@@ -63,6 +63,7 @@ class UNetEngine:
     def __init__(self, plan: NetPlan):
         self.plan = plan
         self._pack_cache: Dict[Tuple, Tuple[int, torch.Tensor]] = {}
+        self._replay_stats = False
         self._imaps: Dict[Tuple, torch.Tensor] = {}
 
     # ------------------------------------------------------------------ small helpers
@@ -299,7 +300,10 @@ class UNetEngine:
         """ga: gradient w.r.t. the ACTIVATED output (overwritten with the raw-output gradient).
         gin: where to write the gradient w.r.t. this conv's activated input (None: not needed)."""
         k = self.plan.k
-        dg, db = ops.bn_relu_bwd(rec.y, ga, rec.vec, P[rec.bn + ".weight"].detach(), rec.cout, part)
+        # use_checkpoint=True: the recompute in backward repeats every live BN's running-stat update
+        # (models.py:232-255; SURVEY K10) -- folded into this BN's backward finalize
+        replay = (P[rec.bn + ".running_mean"], P[rec.bn + ".running_var"], BN_MOMENTUM, BN_EPS) if self._replay_stats else None
+        dg, db = ops.bn_relu_bwd(rec.y, ga, rec.vec, P[rec.bn + ".weight"].detach(), rec.cout, part, replay)
         grads[rec.bn + ".weight"], grads[rec.bn + ".bias"] = dg, db
         if rec.first is not None:                  # direct C_in <= 2 kernels; gin is a request flag here
             grads[rec.conv + ".weight"] = ops.conv_first_wgrad(rec.first, ga, rec.cout, ws)
@@ -348,20 +352,11 @@ class UNetEngine:
         part = torch.empty(part_n, dtype=torch.float32, device=dev)
 
         # the second running-stat update that torch.utils.checkpoint's recompute performs
-        # (models.py:232-255).  The dead centre block is never recomputed.
-        if ctx["training"] and ctx["chk"]:
-            scratch = {}
-            nbt = []
-            for r in recs.values():
-                if r is None or r.stats is None:
-                    continue
-                cp = r.y.cp
-                sv = scratch.get(cp)
-                if sv is None:
-                    sv = scratch[cp] = torch.empty((4, cp), dtype=torch.float32, device=dev)
-                ops.bn_finalize_into(r.stats, r.nblk, r.cout, cp, r.y.nvox, P[r.bn + ".weight"], P[r.bn + ".bias"],
-                                     P[r.bn + ".running_mean"], P[r.bn + ".running_var"], BN_MOMENTUM, BN_EPS, 1, sv)
-                nbt.append(P[r.bn + ".num_batches_tracked"])
+        # (models.py:232-255) rides on each live BN's backward finalize; the dead centre block is
+        # never recomputed and has no backward.
+        self._replay_stats = bool(ctx["training"] and ctx["chk"])
+        if self._replay_stats:
+            nbt = [P[r.bn + ".num_batches_tracked"] for r in recs.values() if r is not None and r.stats is not None]
             if nbt:
                 torch._foreach_add_(nbt, 1)
 

@@ -340,8 +340,11 @@ def bn_eval_affine(gamma, beta, rmean, rvar, eps, c, cp):
     return vec
 
 
-def bn_relu_bwd(y: CL, ga: CL, vec: torch.Tensor, gamma: torch.Tensor, c: int, partials: torch.Tensor):
-    """In place: ga <- gradient w.r.t. the raw conv output y.  Returns (dgamma, dbeta)."""
+def bn_relu_bwd(y: CL, ga: CL, vec: torch.Tensor, gamma: torch.Tensor, c: int, partials: torch.Tensor,
+                replay=None):
+    """In place: ga <- gradient w.r.t. the raw conv output y.  Returns (dgamma, dbeta).
+    replay = (running_mean, running_var, momentum, eps): also apply the running-stat update a second time (the one
+    torch.utils.checkpoint's recompute performs in backward, models.py:232-255)."""
     lib = _lib.load()
     nvox = y.nvox
     cp = y.cp
@@ -353,8 +356,10 @@ def bn_relu_bwd(y: CL, ga: CL, vec: torch.Tensor, gamma: torch.Tensor, c: int, p
                                           st), "bn_relu_bwd_reduce")
     dgb = torch.empty((2, c), dtype=torch.float32, device=y.buf.device)
     coef = torch.empty((3, cp), dtype=torch.float32, device=y.buf.device)
+    rm, rv, mom, eps = replay if replay is not None else (None, None, 0.0, 0.0)
     _lib.check(lib.ctu_bn_bwd_finalize(partials.data_ptr(), nb, c, cp, float(nvox), gamma.data_ptr(), istd,
-                                       dgb[0].data_ptr(), dgb[1].data_ptr(), coef.data_ptr(), st), "bn_bwd_finalize")
+                                       dgb[0].data_ptr(), dgb[1].data_ptr(), coef.data_ptr(), mu, _ptr(rm), _ptr(rv),
+                                       mom, eps, st), "bn_bwd_finalize")
     _lib.check(lib.ctu_bn_relu_bwd_apply(y.ptr, y.cs, ga.ptr, ga.cs, cp, sc, sh, mu, istd, coef.data_ptr(), nvox, st),
                "bn_relu_bwd_apply")
     return dgb[0], dgb[1]

@@ -170,9 +170,13 @@ int ctu_bn_bwd_num_blocks(int64_t nvox);
 int ctu_bn_relu_bwd_reduce(const float* y, int y_cs, const float* ga, int g_cs, int cp,
                            const float* scale, const float* shift, const float* mean,
                            const float* invstd, int64_t nvox, float* partials, void* stream);
+/* running_mean/running_var non-NULL: additionally replay the running-statistics update once, with the batch
+ * statistics saved by ctu_bn_finalize (mean, invstd) -- the second update torch.utils.checkpoint's recompute
+ * performs in backward when use_checkpoint=True (models.py:232-255). */
 int ctu_bn_bwd_finalize(const float* partials, int nb, int C, int cp, double count,
                         const float* gamma, const float* invstd,
-                        float* dgamma, float* dbeta, float* coef, void* stream);
+                        float* dgamma, float* dbeta, float* coef, const float* mean,
+                        float* running_mean, float* running_var, float momentum, float eps, void* stream);
 int ctu_bn_relu_bwd_apply(const float* y, int y_cs, float* ga, int g_cs, int cp,
                           const float* scale, const float* shift, const float* mean,
                           const float* invstd, const float* coef, int64_t nvox, void* stream);
