@@ -113,25 +113,63 @@ __global__ __launch_bounds__(HB) void head_fwd_kernel(HeadP p, float* __restrict
 }
 
 // partial layout per block: [MAXCO*CP dW][MAXCO db]
+// Backward with CP/4 lanes per voxel: every lane owns one channel quad (16-byte coalesced loads/stores, ~50 VGPRs so
+// the streaming loop is hidden by occupancy instead of being latency-bound at one voxel per 64-accumulator thread).
+// Logits are quad partial sums reduced across the voxel's lanes; block partials keep the layout above.
 template <int CP>
-__global__ __launch_bounds__(HB) void head_bwd_kernel(HeadP p, const float* __restrict__ g0,
-                                                      const float* __restrict__ g1, float* __restrict__ gin,
-                                                      int gin_cs, float* __restrict__ partials) {
+__global__ __launch_bounds__(HB) void head_bwd_q_kernel(HeadP p, const float* __restrict__ g0,
+                                                        const float* __restrict__ g1, float* __restrict__ gin,
+                                                        int gin_cs, float* __restrict__ partials) {
+    constexpr int Q = CP / 4;
     __shared__ float sWp[MAXCO * CP];
     __shared__ float sB[MAXCO];
     __shared__ float sRed[HB / 64][MAXCO * CP + MAXCO];
     head_load_weights<CP>(p, sWp, sB);
-    float dw[MAXCO][CP], db[MAXCO];
+    const int qd = threadIdx.x % Q;
+    float wq[MAXCO][4], dw[MAXCO][4], db[MAXCO];
 #pragma unroll
     for (int co = 0; co < MAXCO; ++co) {
         db[co] = 0.f;
 #pragma unroll
-        for (int c = 0; c < CP; ++c) dw[co][c] = 0.f;
+        for (int j = 0; j < 4; ++j) { wq[co][j] = sWp[co * CP + qd * 4 + j]; dw[co][j] = 0.f; }
     }
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.in_scale) {
+        sc = *reinterpret_cast<const float4*>(p.in_scale + qd * 4);
+        sh = *reinterpret_cast<const float4*>(p.in_shift + qd * 4);
+    }
+    const int xrelu = p.in_scale ? p.in_relu : 0;
     const int64_t total = (int64_t)p.N * p.V;
-    for (int64_t gv = (int64_t)blockIdx.x * HB + threadIdx.x; gv < total; gv += (int64_t)gridDim.x * HB) {
-        float a[CP], lg[MAXCO], u[MAXCO], y[MAXCO], gy[MAXCO];
-        head_point<CP>(p, sWp, sB, gv, a, lg, u, y);
+    constexpr int VPB = HB / Q;                       // voxels per block and iteration
+    for (int64_t gv = (int64_t)blockIdx.x * VPB + threadIdx.x / Q; gv < total; gv += (int64_t)gridDim.x * VPB) {
+        const float4 a = xform4(*reinterpret_cast<const float4*>(p.in + (size_t)gv * p.in_cs + qd * 4), sc, sh, xrelu);
+        float lg[MAXCO], u[MAXCO], y[MAXCO], gy[MAXCO];
+#pragma unroll
+        for (int co = 0; co < MAXCO; ++co) {
+            float s = 0.f;
+            if (co < p.Co) {
+                s = fmaf(a.w, wq[co][3], fmaf(a.z, wq[co][2], fmaf(a.y, wq[co][1], a.x * wq[co][0])));
+#pragma unroll
+                for (int o = 1; o < Q; o <<= 1) s += __shfl_xor(s, o);
+                s += sB[co];
+            }
+            lg[co] = s;
+        }
+        if (p.act & 1) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int co = 0; co < MAXCO; ++co) if (co < p.Co) mx = fmaxf(mx, lg[co]);
+            float den = 0.f;
+#pragma unroll
+            for (int co = 0; co < MAXCO; ++co) { u[co] = (co < p.Co) ? expf(lg[co] - mx) : 0.f; den += u[co]; }
+#pragma unroll
+            for (int co = 0; co < MAXCO; ++co) u[co] /= den;
+        } else {
+#pragma unroll
+            for (int co = 0; co < MAXCO; ++co) u[co] = lg[co];
+        }
+#pragma unroll
+        for (int co = 0; co < MAXCO; ++co) y[co] = (p.act & 2) ? 1.f / (1.f + expf(-u[co])) : u[co];
         const int64_t n = gv / p.V, v = gv % p.V;
         if (p.head_mode == 0) {
 #pragma unroll
@@ -162,34 +200,27 @@ __global__ __launch_bounds__(HB) void head_bwd_kernel(HeadP p, const float* __re
 #pragma unroll
             for (int co = 0; co < MAXCO; ++co) gl[co] = (co < p.Co) ? gu[co] : 0.f;
         }
-        float* gdst = gin + (size_t)gv * gin_cs;
-#pragma unroll
-        for (int qd = 0; qd < CP / 4; ++qd) {
-            float4 o;
-            float* op = &o.x;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float s = 0.f;
-#pragma unroll
-                for (int co = 0; co < MAXCO; ++co) s = fmaf(gl[co], sWp[co * CP + qd * 4 + j], s);
-                op[j] = s;
-            }
-            *reinterpret_cast<float4*>(gdst + qd * 4) = o;
-        }
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float av[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
         for (int co = 0; co < MAXCO; ++co) {
-            db[co] += gl[co];
+            o.x = fmaf(gl[co], wq[co][0], o.x); o.y = fmaf(gl[co], wq[co][1], o.y);
+            o.z = fmaf(gl[co], wq[co][2], o.z); o.w = fmaf(gl[co], wq[co][3], o.w);
+            if (qd == 0) db[co] += gl[co];
 #pragma unroll
-            for (int c = 0; c < CP; ++c) dw[co][c] = fmaf(gl[co], a[c], dw[co][c]);
+            for (int j = 0; j < 4; ++j) dw[co][j] = fmaf(gl[co], av[j], dw[co][j]);
         }
+        *reinterpret_cast<float4*>(gin + (size_t)gv * gin_cs + qd * 4) = o;
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int co = 0; co < MAXCO; ++co) {
 #pragma unroll
-        for (int c = 0; c < CP; ++c) {
-            const float s = wave_sum(dw[co][c]);
-            if (lane == 0) sRed[wave][co * CP + c] = s;
+        for (int j = 0; j < 4; ++j) {
+            float s = dw[co][j];
+#pragma unroll
+            for (int o = 32; o >= Q; o >>= 1) s += __shfl_xor(s, o);        // over the lanes that own this quad
+            if (lane < Q) sRed[wave][co * CP + lane * 4 + j] = s;
         }
         const float s = wave_sum(db[co]);
         if (lane == 0) sRed[wave][MAXCO * CP + co] = s;
@@ -386,13 +417,13 @@ extern "C" int ctu_head_bwd(const float* in, int in_cs, int cin_p, const float* 
     hipStream_t st = (hipStream_t)stream;
     const int nfin = Co * Ci + Co;
     if (cin_p == 8) {
-        head_bwd_kernel<8><<<nb, HB, 0, st>>>(p, g0, g1, gin, gin_cs, ws);
+        head_bwd_q_kernel<8><<<nb, HB, 0, st>>>(p, g0, g1, gin, gin_cs, ws);
         head_bwd_final_kernel<8><<<nfin, HB, 0, st>>>(ws, nb, Ci, Co, imap, dw, db);
     } else if (cin_p == 16) {
-        head_bwd_kernel<16><<<nb, HB, 0, st>>>(p, g0, g1, gin, gin_cs, ws);
+        head_bwd_q_kernel<16><<<nb, HB, 0, st>>>(p, g0, g1, gin, gin_cs, ws);
         head_bwd_final_kernel<16><<<nfin, HB, 0, st>>>(ws, nb, Ci, Co, imap, dw, db);
     } else {
-        head_bwd_kernel<32><<<nb, HB, 0, st>>>(p, g0, g1, gin, gin_cs, ws);
+        head_bwd_q_kernel<32><<<nb, HB, 0, st>>>(p, g0, g1, gin, gin_cs, ws);
         head_bwd_final_kernel<32><<<nfin, HB, 0, st>>>(ws, nb, Ci, Co, imap, dw, db);
     }
     CTU_CHECK_LAUNCH("head_bwd");
