@@ -102,9 +102,21 @@ def cpu_baseline(size, steps=5):
         log(f"cpu baseline step {i}: {dt:.2f} s on {cores} threads")
         if i > 0:
             best = min(best, dt)
+    # "Dice vs CPU ref" (BASELINE metric): hard segmentation argmax(out, 1) of the HIP path against the
+    # oracle's on identical weights and input (train-mode forward, the measured path), plus the raw-output error
+    with torch.no_grad():
+        ref = O.forward(spec, {k: v.clone() for k, v in sd.items()}, x, training=True, update_stats=False)
+        net.load_state_dict(sd)
+        got = net.cuda().train()(x.cuda()).cpu()
+    a, b = got.argmax(1) == 1, ref.argmax(1) == 1
+    tot = int(a.sum()) + int(b.sum())
+    dice = 2.0 * int((a & b).sum()) / tot if tot else 1.0
+    rel = float((got - ref).abs().max() / ref.abs().max())
+    log(f"dice vs cpu ref {dice:.6f}, max rel output error {rel:.2e}")
     return {"value": size ** 3 / best, "unit": "voxels/s", "cores": cores, "kind": "port",
             "sample": f"{steps} fwd+bwd steps (best, after 1 warm-up) of the same {size}^3 batch-1 UNet() train step, "
-                      f"oracle = torch.nn.functional graph on ATen-CPU fp32, no checkpoint recompute, {best:.2f} s/step"}
+                      f"oracle = torch.nn.functional graph on ATen-CPU fp32, no checkpoint recompute, {best:.2f} s/step",
+            "dice_vs_cpu_ref": dice, "max_rel_output_err": rel}
 
 
 def main():

@@ -70,6 +70,10 @@ SIGNATURES = {
     "ctu_loss_fwd": (I, [P, P, I, L, F, F, I, P, P, P]),
     "ctu_loss_bwd": (I, [P, P, I, L, F, F, I, P, P, P, I, P]),
     "ctu_skip_add": (I, [P, I, P, P, I, P, I, P, P, I, P, I, I, L, P]),
+    "ctu_hard_segm": (I, [P, I, I, L, P, P]),
+    "ctu_one_hot": (I, [P, I, I, L, P, P]),
+    "ctu_hard_dice_ws_doubles": (Z, [I]),
+    "ctu_hard_dice_counts": (I, [P, P, I, I, L, P, P, P]),
     "ctu_channel_sum_num_blocks": (I, [L]),
     "ctu_channel_sum": (I, [P, I, I, L, P, P, I, P]),
     "ctu_adam_amsgrad": (I, [P, P, I, P, D, D, D, D, D, I, P]),

@@ -510,3 +510,46 @@ def channel_sum(x: CL, c: int) -> torch.Tensor:
     _lib.check(lib.ctu_channel_sum(x.ptr, x.cs, x.cp, x.nvox, part.data_ptr(), out.data_ptr(), c, _stream()),
                "channel_sum")
     return out
+
+
+# ---------------------------------------------------------------------------- inference tail / sample schema
+def _ncv(t: torch.Tensor):
+    """(N, C, V) of a contiguous fp32 NCDHW (5-D) or CDHW (4-D) CUDA map."""
+    if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous() or t.dim() not in (4, 5):
+        raise RuntimeError("ctunet_amd: expected a contiguous float32 CUDA map [N,C,D,H,W] or [C,D,H,W]")
+    n = t.shape[0] if t.dim() == 5 else 1
+    c = t.shape[1] if t.dim() == 5 else t.shape[0]
+    return n, c, t.numel() // (n * c)
+
+
+def hard_segm(prob: torch.Tensor) -> torch.Tensor:
+    """argmax over the class dimension as float32 ([N,D,H,W] or [D,H,W]); first maximum wins."""
+    n, c, v = _ncv(prob)
+    out = torch.empty(prob.shape[:1] + prob.shape[2:] if prob.dim() == 5 else prob.shape[1:], dtype=torch.float32,
+                      device=prob.device)
+    _lib.check(_lib.load().ctu_hard_segm(prob.data_ptr(), n, c, v, out.data_ptr(), _stream()), "hard_segm")
+    return out
+
+
+def one_hot(label: torch.Tensor, num_classes: int) -> torch.Tensor:
+    """one_hot(label.long(), C).movedim(-1, 1).float() for a float32 CUDA label volume [N,D,H,W]."""
+    if label.dtype != torch.float32 or not label.is_cuda or not label.is_contiguous() or label.dim() != 4:
+        raise RuntimeError("ctunet_amd: expected a contiguous float32 CUDA label volume [N,D,H,W]")
+    n = label.shape[0]
+    out = torch.empty((n, num_classes) + tuple(label.shape[1:]), dtype=torch.float32, device=label.device)
+    _lib.check(_lib.load().ctu_one_hot(label.data_ptr(), n, num_classes, label.numel() // n, out.data_ptr(), _stream()),
+               "one_hot")
+    return out
+
+
+def hard_dice_counts(pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """float64 [N, C, 3]: per item and class {|hard & target|, |hard|, |target|}, hard = one_hot(argmax(pred, 1))."""
+    n, c, v = _ncv(pred)
+    if target.shape != pred.shape or _ncv(target) != (n, c, v):
+        raise RuntimeError("ctunet_amd: prediction and one-hot target must have the same shape")
+    lib = _lib.load()
+    ws = torch.empty(lib.ctu_hard_dice_ws_doubles(n), dtype=torch.float64, device=pred.device)
+    counts = torch.empty((n, c, 3), dtype=torch.float64, device=pred.device)
+    _lib.check(lib.ctu_hard_dice_counts(pred.data_ptr(), target.data_ptr(), n, c, v, counts.data_ptr(), ws.data_ptr(),
+                                        _stream()), "hard_dice_counts")
+    return counts

@@ -43,9 +43,10 @@ def load_params(cfg_file, default_dict=None):
 
 
 def hard_segm_from_tensor(prob_map, keep_dims=False):
-    """argmax over the class dimension as float (utilities.py:103-124)."""
+    """argmax over the class dimension as float (utilities.py:103-124), one pass on the GPU."""
+    from . import ops
     dim = 1 if prob_map.dim() == 5 else 0
-    seg = torch.argmax(prob_map, dim=dim).type(torch.float)
+    seg = ops.hard_segm(prob_map.detach().float().contiguous())
     return seg.unsqueeze(dim) if keep_dims else seg
 
 
@@ -56,9 +57,9 @@ def dice_coeff(pred, target):
     include_background=False)`` (utilities.py:53-59).  monai is an unpinned third-party package that
     is not available here, so this follows its published definition 2|A.B| / (|A| + |B|);
     empty-vs-empty is defined as 1.0 (monai returns NaN).  PARITY UNPINNED.
+    The three counts come from one pass over the maps (``ctu_hard_dice_counts``, exact integers).
     """
-    c = pred.shape[1]
-    hard = torch.nn.functional.one_hot(torch.argmax(pred, 1), c).movedim(-1, 1).to(target.dtype)
-    a, b = hard[:, 1:].flatten(2), target[:, 1:].flatten(2)
-    inter, tot = (a * b).sum(2), a.sum(2) + b.sum(2)
-    return torch.where(tot > 0, 2 * inter / tot.clamp_min(1), torch.ones_like(tot)).mean()
+    from . import ops
+    cnt = ops.hard_dice_counts(pred.detach().float().contiguous(), target.detach().float().contiguous())[:, 1:]
+    inter, tot = cnt[..., 0], cnt[..., 1] + cnt[..., 2]
+    return torch.where(tot > 0, 2 * inter / tot.clamp_min(1), torch.ones_like(tot)).mean().float()

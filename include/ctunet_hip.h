@@ -262,6 +262,20 @@ int ctu_loss_bwd(const float* pred, const float* target, int N, int64_t V, float
 int ctu_skip_add(const float* a, int a_cs, const float* a_scale, const float* a_shift, int a_relu,
                  const float* b, int b_cs, const float* b_scale, const float* b_shift, int b_relu,
                  float* out, int out_cs, int cp, int64_t nvox, void* stream);
+/* -------------------------------------------------- inference tail / sample schema ---- */
+/* hard_segm_from_tensor (/root/reference/ctunet/utilities.py:103-124): seg[n,v] = (float)argmax_c prob[n,c,v] over an
+ * NCDHW map; the first maximum wins (torch.argmax). */
+int ctu_hard_segm(const float* prob, int N, int C, int64_t nvox_per_item, float* seg, void* stream);
+/* one_hot(label.long(), C).movedim(-1, 1).float() of the reference datasets (ctunet/pytorch/datasets.py:107-110,
+ * 212-217): label [N,V] float -> out [N,C,V].  Labels outside [0,C) give an all-zero voxel (torch raises). */
+int ctu_one_hot(const float* label, int N, int C, int64_t nvox_per_item, float* out, void* stream);
+/* dice_coeff (ctunet/utilities.py:53-59 = monai compute_meandice on one_hot(argmax(pred,1))): counts[n][c] =
+ * { sum hard_c*target_c, sum hard_c, sum target_c } in double (exact integers for one-hot targets), two-stage
+ * fixed-order reduction.  C <= 8.  The Dice ratio itself (and the empty-vs-empty convention) is the caller's. */
+size_t ctu_hard_dice_ws_doubles(int N);
+int ctu_hard_dice_counts(const float* pred, const float* target, int N, int C, int64_t nvox_per_item,
+                         double* counts, double* ws, void* stream);
+
 /* Per-channel sum over voxels of a channels-last tensor: out[c] = sum_v x[v,c] (bias grads). */
 int ctu_channel_sum_num_blocks(int64_t nvox);
 int ctu_channel_sum(const float* x, int cs, int cp, int64_t nvox, float* partials,

@@ -140,11 +140,11 @@ def test_ini_parser_type_prefixes(tmp_path):
     assert got == {"keep": 1, "n": 3, "x": 0.5, "flag": True, "name": "abc", "plain": "7", "resume_model": ""}
 
 
-def test_hard_segmentation_and_dice_metric():
+def test_inference_tail_has_no_cpu_fallback():
+    """hard_segm_from_tensor / dice_coeff run as HIP kernels; CPU tensors are refused, not silently computed."""
     from ctunet_amd.utilities import dice_coeff, hard_segm_from_tensor
     p = torch.rand(2, 2, 4, 4, 4, generator=torch.Generator().manual_seed(0))
-    seg = hard_segm_from_tensor(p)
-    assert seg.shape == (2, 4, 4, 4) and seg.dtype == torch.float32
-    assert hard_segm_from_tensor(p, keep_dims=True).shape == (2, 1, 4, 4, 4)
-    t = torch.nn.functional.one_hot(p.argmax(1), 2).movedim(-1, 1).float()
-    assert abs(dice_coeff(p, t).item() - 1.0) < 1e-6
+    with pytest.raises(RuntimeError):
+        hard_segm_from_tensor(p)
+    with pytest.raises(RuntimeError):
+        dice_coeff(p, p)

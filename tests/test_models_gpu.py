@@ -317,3 +317,31 @@ def test_cpu_input_raises_and_bad_shapes():
     net.train()
     with pytest.raises(ValueError):
         net(torch.zeros(1, 1, 16, 16, 16).cuda())     # 1 value per channel in the centre block, as torch raises
+
+
+def test_synthetic_dataset_schema_and_one_step():
+    """the synthetic patch source yields the reference datasets' sample schema
+    (datasets.py:89-112,195-235) and drives one UNetSP + FlapRecWithShapePriorDoubleOut step through a DataLoader."""
+    _, M, L, PH = _mods()
+    from ctunet_amd.datasets import SyntheticFlapDataset
+    ds = SyntheticFlapDataset(4, size=32, seed=7, double_out=True, append_atlas=True)
+    s0, s0b, s1 = ds[0], ds[0], ds[1]
+    assert set(s0) == {"image", "target", "filepath"}
+    assert s0["image"].shape == (2, 32, 32, 32) and s0["image"].dtype == torch.float32 and s0["image"].is_contiguous()
+    full, flap = s0["target"]
+    for t in (full, flap):
+        assert t.shape == (2, 32, 32, 32) and t.dtype == torch.float32
+        assert torch.equal(t.sum(0), torch.ones_like(t[0]))                       # one-hot
+    assert torch.equal(full[1], s0["image"][0] + flap[1])                        # full_skull = image + flap
+    assert flap[1].sum() > 0 and (s0["image"][0] * flap[1]).sum() == 0          # the flap is cut out of the image
+    assert torch.equal(s0["image"], s0b["image"]) and not torch.equal(s0["image"], s1["image"])
+    single = SyntheticFlapDataset(2, size=32, double_out=False, append_atlas=False)[1]
+    assert single["image"].shape == (1, 32, 32, 32) and single["target"].shape == (2, 32, 32, 32)
+    batch = next(iter(torch.utils.data.DataLoader(ds, batch_size=2)))
+    assert isinstance(batch["target"], list) and batch["image"].shape == (2, 2, 32, 32, 32)   # Model.py:344-349
+    net = M.UNetSP().cuda().train()
+    h = Holder(1.0, 1.0)
+    out = net(batch["image"])
+    PH.FlapRecWithShapePriorDoubleOut.comp_losses_metrics(h, out, batch["target"], 0, 1)
+    h.pt_loss.backward()
+    assert torch.isfinite(h.pt_loss) and all(p.grad is None or torch.isfinite(p.grad).all() for p in net.parameters())

@@ -424,3 +424,41 @@ def test_skip_add(shape):
     assert torch.allclose(from_cl(out, c), ref, rtol=1e-6, atol=1e-6)
     ops.skip_add(ops.CL(wide, 0, cp), None, ops.CL(wide, cp, cp))          # slice copy, bit exact
     assert torch.equal(wide[..., cp:], wide[..., :cp])
+
+
+# ---------------------------------------------------------------------------- inference tail / sample schema (8 f4, f1)
+@pytest.mark.parametrize("shape", [(2, 2, 4, 6, 10), (1, 3, 8, 8, 8), (3, 4, 5, 3, 7)])
+def test_hard_segm_one_hot_dice_counts_bit_exact(shape):
+    """Index / counting work: bit exact against torch.argmax / one_hot / integer counts, including exact ties (the
+    first maximum wins) -- utilities.py:103-124, datasets.py:107-110; hard Dice = the oracle's restatement of
+    monai's compute_meandice (parity unpinned)."""
+    from oracle import unet_oracle as O
+    ops = _ops()
+    n, c, d, h, w = shape
+    p = torch.rand(shape, generator=g(11))
+    p[:, :, 0, 0, :] = 0.25                                   # ties across all classes
+    p[:, 1:, 1, 0, :] = p[:, :1, 1, 0, :]                     # tie with class 0
+    seg = ops.hard_segm(p.cuda())
+    assert seg.dtype == torch.float32 and torch.equal(seg.cpu(), p.argmax(1).float())
+    assert torch.equal(ops.hard_segm(p[0].contiguous().cuda()).cpu(), p[0].argmax(0).float())
+    lab = torch.randint(0, c, (n, d, h, w), generator=g(12)).float()
+    oh = ops.one_hot(lab.cuda(), c)
+    assert torch.equal(oh.cpu(), F.one_hot(lab.long(), c).movedim(-1, 1).float())
+    cnt = ops.hard_dice_counts(p.cuda(), oh).cpu()
+    hard = F.one_hot(p.argmax(1), c).movedim(-1, 1).double()
+    ref = torch.stack([(hard * oh.cpu().double()).flatten(2).sum(2), hard.flatten(2).sum(2), oh.cpu().double().flatten(2).sum(2)], -1)
+    assert torch.equal(cnt, ref)
+    from ctunet_amd.utilities import dice_coeff, hard_segm_from_tensor
+    assert hard_segm_from_tensor(p.cuda(), keep_dims=True).shape == (n, 1, d, h, w)
+    assert abs(dice_coeff(p.cuda(), oh).item() - O.hard_dice(p, oh.cpu())) < 1e-6
+    assert abs(dice_coeff(p.cuda(), hard.float().cuda()).item() - 1.0) < 1e-7
+
+
+def test_hard_dice_counts_full_size():
+    """128^3: counts are exact integers and add up (size-independent properties: sum_c |hard_c| = V = sum_c |target_c|)."""
+    ops = _ops()
+    p = torch.rand(1, 2, 128, 128, 128, generator=g(13)).cuda()
+    t = ops.one_hot((torch.rand(1, 128, 128, 128, generator=g(14)) < 0.3).float().cuda(), 2)
+    cnt = ops.hard_dice_counts(p, t)
+    assert torch.equal(cnt, cnt.round()) and cnt[0, :, 1].sum().item() == 128 ** 3 and cnt[0, :, 2].sum().item() == 128 ** 3
+    assert cnt[0, 1, 0].item() == float(((p[0, 1] > p[0, 0]) & (t[0, 1] > 0.5)).sum().item())
