@@ -345,3 +345,45 @@ def test_synthetic_dataset_schema_and_one_step():
     PH.FlapRecWithShapePriorDoubleOut.comp_losses_metrics(h, out, batch["target"], 0, 1)
     h.pt_loss.backward()
     assert torch.isfinite(h.pt_loss) and all(p.grad is None or torch.isfinite(p.grad).all() for p in net.parameters())
+
+
+@pytest.mark.parametrize("shape,kw", [((2, 1, 16, 32, 48), dict(n_blocks=2, i_size=8)),
+                                      ((1, 2, 48, 16, 32), dict(n_blocks=3, i_size=4, input_channels=2, out_channels=3)),
+                                      ((1, 1, 32, 32, 80), dict(n_blocks=2, i_size=8, cat=False))])
+def test_non_cubic_volumes_against_fp64_oracle(shape, kw):
+    """Non-cubic, batched patches (border boxes on every face, ragged box counts along w, the wide-tile kernels at
+    W = 48 / 80): train-mode output, loss, dx and every parameter gradient vs the oracle in fp64, judged next to
+    ATen-CPU fp32 like the cubic case above."""
+    A, M, L, PH = _mods()
+    torch.manual_seed(3)
+    net = A.UNet(use_checkpoint=False, **kw)
+    sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+    spec = O.NetSpec(in_ch=kw.get("input_channels", 1), out_ch=kw.get("out_channels", 2), n_blocks=kw["n_blocks"],
+                     i_size=kw["i_size"], cat=kw.get("cat", True))
+    x = torch.randn(shape, generator=gen(77))
+    oc = spec.out_ch
+    tg = torch.nn.functional.one_hot(torch.randint(0, oc, (shape[0],) + shape[2:], generator=gen(78)), oc).movedim(-1, 1).float()
+
+    def loss(o, t):
+        return ((o - t) ** 2).mean()
+
+    def run(dtype):
+        sd = {k: (v.to(dtype) if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
+        return O.grads(spec, sd, x.to(dtype), lambda o: loss(o, tg.to(dtype)), training=True)
+    o64, l64, g64, dx64 = run(torch.float64)
+    _, _, g32, dx32 = run(torch.float32)
+    net = net.cuda().train()
+    xi = x.cuda().requires_grad_(True)
+    out = net(xi)
+    assert rel_err(out, o64.float()) < 1e-4
+    lg = loss(out, tg.cuda())
+    lg.backward()
+    assert abs(lg.item() - l64.item()) < 1e-5
+
+    def err(a, b):
+        return (a.detach().cpu().double() - b).abs().max().item()
+    checks = [("dx", xi.grad, dx32, dx64)] + [(n_, p.grad, g32[n_], g64[n_]) for n_, p in net.named_parameters()
+                                              if g64[n_] is not None]
+    for n_, got, c32, r64 in checks:
+        scale = r64.abs().max().item()
+        assert err(got, r64) <= max(5 * err(c32, r64), 2e-3 * scale) + 1e-7, (n_, err(got, r64), err(c32, r64), scale)
