@@ -1,0 +1,487 @@
+// Fused ConvTranspose3d(C, C, k=2, s=2, bias) -> Conv3d(C, C_out, k=3, p=1, no bias) forward for gfx950: the first two
+// layers of every decoder block (ctunet/pytorch/models.py:37-38) as ONE kernel on the coarse grid.
+//
+// Algebra (checked to 1e-13 in fp64 in scripts/experiments/fused_upblock_proto.py): for an output parity
+// p in {0,1}^3 the pair is a 2x2x2 convolution of the COARSE input,
+//     y[2i+p] = sum_{d in D(p)} x[i+d] . W_eff[p][d]  +  b_eff[border class of 2i+p],
+//     W_eff[p][d][ci,co] = sum_{(t,a) in S(p,d)} sum_cm WT[ci,cm,a] W3[co,cm,t]
+// (per axis: p=0: d=-1 <- (t=-1,a=1), d=0 <- (t=0,a=0),(t=1,a=1);  p=1: d=0 <- (t=-1,a=0),(t=0,a=1), d=+1 <- (t=1,a=0)),
+// so a parity's taps are the 2x2x2 sub-cube of the 3x3x3 coarse halo that starts at p.  8 taps instead of 27 plus the
+// transposed conv (4096 instead of 15872 FLOP per fine voxel for 32 -> 32 -> 8), and the fine-grid intermediate is never
+// written.  The conv zero-pads the TRANSPOSED-CONV OUTPUT, so at the volume faces only the bias term changes:
+// b_eff[class][co] = sum_{t inside} sum_cm bT[cm] W3[co,cm,t], 27 classes (per axis: interior / first / last fine voxel).
+//
+// Kernel: the persistent implicit GEMM of conv3d.hip (rows = output channels, columns = 16 coarse voxels along w, K =
+// 8-channel chunks x taps; 4x4x16 coarse boxes, haloed box of one chunk in LDS at 12 floats per voxel, lazy-BatchNorm
+// transform applied while staging, next (box, chunk) prefetched into registers under the MFMAs).  One staged box feeds
+// all the block's parities: accumulators acc[parity][row][tile], PB * NTP = 8 tile-parities per block.  The epilogue
+// scatters to the fine grid (float4 per lane), adds the border-class bias and carries the BatchNorm partial sums.
+#include "common.h"
+
+namespace {
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+struct UpP {
+    const float* in;
+    const float* in_scale;
+    const float* in_shift;
+    const float* wp;          // [chunk][parity 8][tap 8][ntp][128]
+    const float* beff;        // [27][nout_p]
+    float* out;               // fine grid [N, 2D, 2H, 2W, out_cs]
+    float* stats;             // [gridDim.y * gridDim.x][2][nout_p]
+    int in_cs, rin_p, in_relu, out_cs, nout_p;
+    int N, D, H, W;           // COARSE dims
+    int tiles_d, tiles_h, tiles_w;
+};
+
+template <int PB, int NTP>
+__global__ __launch_bounds__(256, 2) void upconv_fused_fwd_kernel(UpP p, int ntiles, int tiles_per_block) {
+    static_assert(PB * NTP == 8 && (PB == 8 || PB == 4 || PB == 2), "tile-parities per block");
+    constexpr int MT = 4, TD = 4, TH = 4, TW = 16;
+    constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2, HV = HD * HH * HW;
+    constexpr int NTHR = 256;
+    constexpr int NTPT = NTP;                            // a block covers ALL 16-wide channel tiles of its PB parities
+    constexpr int WFL = PB * 8 * NTP * 128;              // weight floats of one (chunk, block)
+    constexpr int AITEMS = HV * 2, AITER = (AITEMS + NTHR - 1) / NTHR;
+    constexpr int WITER = (WFL / 4 + NTHR - 1) / NTHR;
+    constexpr int VS2 = 6;                               // 12 floats per voxel: conflict-free ds_read_b64
+    static_assert(WFL / 4 % NTHR == 0, "weight staging covers the stage exactly");
+
+    __shared__ __attribute__((aligned(16))) v2f sA2[HV * VS2];
+    __shared__ __attribute__((aligned(16))) v2f sW2[WFL / 2];
+    typedef const volatile __attribute__((address_space(3))) v2f* lds_v2f_ptr;
+    __shared__ float sRed[4 * NTP * 16 * 2];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, kq = lane >> 4;
+    const int by = blockIdx.y;                           // parity group: parities by*PB .. by*PB + PB-1
+    const int nchunk = p.rin_p >> 3;
+    const int half = tid & 1;
+    const bool has_xf = p.in_scale != nullptr;
+    const int pd0 = ((by * PB) >> 2) & 1, ph0 = ((by * PB) >> 1) & 1;      // run-time high parity bits (0 when PB == 8)
+
+    // this wave owns coarse plane td = wave, its 4 M-tiles are the rows th = 0..3; base of row 0, tap (0,0,0) of the
+    // block's first parity
+    lds_v2f_ptr vA = (lds_v2f_ptr)sA2 + (((wave + pd0) * HH + ph0) * HW + m) * VS2 + kq;
+    lds_v2f_ptr vW = (lds_v2f_ptr)sW2 + (kq * 16 + m);
+
+    unsigned hoff[AITER];
+    constexpr int FPW = 5, NFW = (AITER + FPW - 1) / FPW;
+    unsigned fw[NFW];
+#pragma unroll
+    for (int q = 0; q < NFW; ++q) fw[q] = 0;
+#pragma unroll
+    for (int it = 0; it < AITER; ++it) {
+        const int i = tid + it * NTHR;
+        const int v = (i < AITEMS) ? (i >> 1) : 0;
+        const int pw = v % HW, t2 = v / HW, ph = t2 % HH, pd = t2 / HH;
+        hoff[it] = (unsigned)(((pd * p.H + ph) * p.W + pw) * p.in_cs + half * 4) * 4u;
+        const unsigned face = (pd == 0 ? 1u : 0u) | (pd == HD - 1 ? 2u : 0u) | (ph == 0 ? 4u : 0u) | (ph == HH - 1 ? 8u : 0u) |
+                              (pw == 0 ? 16u : 0u) | (pw == HW - 1 ? 32u : 0u);
+        fw[it / FPW] |= face << (6 * (it % FPW));
+    }
+    const unsigned safe_off = (unsigned)(((p.H + 1) * p.W + 1) * p.in_cs + half * 4) * 4u;
+
+    f32x4 acc[PB][MT][NTP];
+    float s1[NTP][4], s2[NTP][4];
+#pragma unroll
+    for (int nt = 0; nt < NTP; ++nt) {
+#pragma unroll
+        for (int pi = 0; pi < PB; ++pi)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[pi][mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s1[nt][r] = 0.f; s2[nt][r] = 0.f; }
+    }
+
+    int tile = blockIdx.x * tiles_per_block;
+    const int tile_end = min(ntiles, tile + tiles_per_block);
+    int c = 0;
+    float4 va[AITER], vw[WITER];
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned vmask = 0;
+
+    struct Box { int tx, ty, tz, n; };
+    Box box;
+    {
+        int t = tile;
+        box.tx = t % p.tiles_w; t /= p.tiles_w;
+        box.ty = t % p.tiles_h; t /= p.tiles_h;
+        box.tz = t % p.tiles_d; box.n = t / p.tiles_d;
+    }
+    auto box_next = [&](Box b) {
+        if (++b.tx == p.tiles_w) { b.tx = 0; if (++b.ty == p.tiles_h) { b.ty = 0; if (++b.tz == p.tiles_d) { b.tz = 0; ++b.n; } } }
+        return b;
+    };
+    bool a_interior = false;
+    auto load_a = [&](Box b, int cc) {
+        const int d0 = b.tz * TD, h0 = b.ty * TH, w0 = b.tx * TW;
+        if (has_xf) {
+            sc = *reinterpret_cast<const float4*>(p.in_scale + cc * 8 + half * 4);
+            sh = *reinterpret_cast<const float4*>(p.in_shift + cc * 8 + half * 4);
+        }
+        const long long org = (((long long)b.n * p.D + d0) * p.H + h0) * p.W + w0 - ((long long)p.H * p.W + p.W + 1);
+        const char* base = reinterpret_cast<const char*>(p.in + org * p.in_cs + cc * 8);
+        a_interior = d0 >= 1 && h0 >= 1 && w0 >= 1 && d0 + TD < p.D && h0 + TH < p.H && w0 + TW < p.W;
+        if (a_interior) {
+#pragma unroll
+            for (int it = 0; it < AITER; ++it) {
+                if ((it + 1) * NTHR <= AITEMS || tid + it * NTHR < AITEMS)
+                    va[it] = *reinterpret_cast<const float4*>(base + hoff[it]);
+                else
+                    va[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            return;
+        }
+        vmask = 0;
+        if (d0 + TD <= p.D && h0 + TH <= p.H && w0 + TW <= p.W) {          // full border box: branch-free
+            const unsigned bface = (d0 == 0 ? 1u : 0u) | (d0 + TD == p.D ? 2u : 0u) | (h0 == 0 ? 4u : 0u) |
+                                   (h0 + TH == p.H ? 8u : 0u) | (w0 == 0 ? 16u : 0u) | (w0 + TW == p.W ? 32u : 0u);
+#pragma unroll
+            for (int it = 0; it < AITER; ++it) {
+                const bool ok = (fw[it / FPW] & (bface << (6 * (it % FPW)))) == 0u;
+                va[it] = *reinterpret_cast<const float4*>(base + (ok ? hoff[it] : safe_off));
+                vmask |= ok ? (1u << it) : 0u;
+            }
+            return;
+        }
+#pragma unroll
+        for (int it = 0; it < AITER; ++it) {                               // ragged box: per-item bounds
+            const int i = tid + it * NTHR, v = i >> 1;
+            const int pw = v % HW, t2 = v / HW, ph = t2 % HH, pd = t2 / HH;
+            const int gd = d0 + pd - 1, gh = h0 + ph - 1, gw = w0 + pw - 1;
+            const bool ok = i < AITEMS && (unsigned)gd < (unsigned)p.D && (unsigned)gh < (unsigned)p.H && (unsigned)gw < (unsigned)p.W;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) {
+                val = *reinterpret_cast<const float4*>(base + hoff[it]);
+                vmask |= 1u << it;
+            }
+            va[it] = val;
+        }
+    };
+    auto load_w = [&](int cc) {
+        const char* wsrc = reinterpret_cast<const char*>(p.wp + ((size_t)cc * 8 + (size_t)by * PB) * 8 * NTPT * 128);
+#pragma unroll
+        for (int it = 0; it < WITER; ++it) vw[it] = *reinterpret_cast<const float4*>(wsrc + (unsigned)(tid + it * NTHR) * 16u);
+    };
+    if (tile >= tile_end) return;
+    load_a(box, 0);
+    load_w(0);
+
+    while (true) {
+        __syncthreads();
+        {
+            auto put = [&](int it, float4 val) {
+                const int i = tid + it * NTHR;
+                if ((it + 1) * NTHR <= AITEMS || i < AITEMS) *reinterpret_cast<float4*>(&sA2[(i >> 1) * VS2 + half * 2]) = val;
+            };
+            if (a_interior) {
+#pragma unroll
+                for (int it = 0; it < AITER; ++it) put(it, has_xf ? xform4(va[it], sc, sh, p.in_relu) : va[it]);
+            } else {
+#pragma unroll
+                for (int it = 0; it < AITER; ++it) {
+                    const float4 t = has_xf ? xform4(va[it], sc, sh, p.in_relu) : va[it];
+                    const bool ok = (vmask >> it) & 1u;
+                    put(it, make_float4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f));
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < WITER; ++it) *reinterpret_cast<float4*>(&sW2[(tid + it * NTHR) * 2]) = vw[it];
+        }
+        __syncthreads();
+        int ntile = tile, nc = c + 1;
+        Box nbox = box;
+        if (nc == nchunk) { nc = 0; ntile = tile + 1; nbox = box_next(box); }
+        const bool has_next = ntile < tile_end;
+        if (has_next) {
+            load_a(nbox, nc);
+            load_w(nc);
+        }
+        // ---- MFMAs: flat sequence of PB * 4 groups (parity pi, dz, dx); a group's 5 input rows feed the 2 dy taps of the
+        // 4 M-tiles: 5 + 2*NTP fragment reads for 16*NTP MFMAs, read one group ahead
+        {
+            constexpr int NG = PB * 4;
+            v2f ar[2][5], br[2][2][NTP];
+            auto load_group = [&](int g, v2f (&aa)[5], v2f (&bb)[2][NTP]) {
+                const int pi = g >> 2, dz = (g >> 1) & 1, dx = g & 1;
+                const int pid = (PB == 8) ? (pi >> 2) : 0, pih = (PB >= 4) ? ((pi >> 1) & 1) : 0, piw = pi & 1;
+#pragma unroll
+                for (int r = 0; r < 5; ++r) aa[r] = vA[(((pid + dz) * HH + r + pih) * HW + piw + dx) * VS2];
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int nt = 0; nt < NTP; ++nt) bb[dy][nt] = vW[((pi * 8 + (dz * 2 + dy) * 2 + dx) * NTP + nt) * 64];
+            };
+            load_group(0, ar[0], br[0]);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if (g + 1 < NG) load_group(g + 1, ar[(g + 1) & 1], br[(g + 1) & 1]);
+                const int pi = g >> 2;
+                v2f (&aa)[5] = ar[g & 1];
+                v2f (&bb)[2][NTP] = br[g & 1];
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy) {
+#pragma unroll
+                    for (int nt = 0; nt < NTP; ++nt)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+                            acc[pi][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bb[dy][nt].x, aa[mt + dy].x, acc[pi][mt][nt], 0, 0, 0);
+#pragma unroll
+                    for (int nt = 0; nt < NTP; ++nt)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+                            acc[pi][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bb[dy][nt].y, aa[mt + dy].y, acc[pi][mt][nt], 0, 0, 0);
+                }
+            }
+        }
+        if (c == nchunk - 1) {
+            // ---- epilogue of this coarse box: scatter its 8 * 256 fine voxels, border-class bias, BN partial sums
+            const int d0 = box.tz * TD, h0 = box.ty * TH, w0 = box.tx * TW;
+            const int Df = 2 * p.D, Hf = 2 * p.H, Wf = 2 * p.W;
+            const int cd = d0 + wave, cw = w0 + m;
+            const bool touches = d0 == 0 || h0 == 0 || w0 == 0 || d0 + TD >= p.D || h0 + TH >= p.H || w0 + TW >= p.W;   // uniform
+#pragma unroll
+            for (int nt = 0; nt < NTP; ++nt) {
+                const int co = nt * 16 + kq * 4;
+                const bool cok = co < p.nout_p;
+                float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (cok) b0 = *reinterpret_cast<const float4*>(p.beff + co);             // class 0: interior
+#pragma unroll
+                for (int pi = 0; pi < PB; ++pi) {
+                    const int pd = pd0 + ((PB == 8) ? (pi >> 2) : 0), ph = ph0 + ((PB >= 4) ? ((pi >> 1) & 1) : 0), pw = pi & 1;
+                    const int fz = 2 * cd + pd, fx = 2 * cw + pw;
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const int ch = h0 + mt, fy = 2 * ch + ph;
+                        if (cok && cd < p.D && ch < p.H && cw < p.W) {
+                            float4 bv = b0;
+                            if (touches) {
+                                const int cz = fz == 0 ? 1 : (fz == Df - 1 ? 2 : 0), cy = fy == 0 ? 1 : (fy == Hf - 1 ? 2 : 0),
+                                          cx = fx == 0 ? 1 : (fx == Wf - 1 ? 2 : 0);
+                                bv = *reinterpret_cast<const float4*>(p.beff + (size_t)((cz * 3 + cy) * 3 + cx) * p.nout_p + co);
+                            }
+                            float4 o;
+                            o.x = acc[pi][mt][nt][0] + bv.x; o.y = acc[pi][mt][nt][1] + bv.y;
+                            o.z = acc[pi][mt][nt][2] + bv.z; o.w = acc[pi][mt][nt][3] + bv.w;
+                            const size_t fv = (((size_t)box.n * Df + fz) * Hf + fy) * Wf + fx;
+                            *reinterpret_cast<float4*>(p.out + fv * p.out_cs + co) = o;
+                            s1[nt][0] += o.x; s1[nt][1] += o.y; s1[nt][2] += o.z; s1[nt][3] += o.w;
+                            s2[nt][0] += o.x * o.x; s2[nt][1] += o.y * o.y; s2[nt][2] += o.z * o.z; s2[nt][3] += o.w * o.w;
+                        }
+                        acc[pi][mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+            }
+        }
+        if (!has_next) break;
+        tile = ntile; c = nc; box = nbox;
+    }
+    // ---- one BatchNorm partial row per block: reduce over the 16 voxel lanes and the 4 waves
+    if (p.stats) {
+        __syncthreads();
+#pragma unroll
+        for (int nt = 0; nt < NTP; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float a1 = s1[nt][r], a2 = s2[nt][r];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { a1 += __shfl_xor(a1, o); a2 += __shfl_xor(a2, o); }
+                if (m == 0) {
+                    sRed[(wave * NTP * 16 + nt * 16 + kq * 4 + r) * 2 + 0] = a1;
+                    sRed[(wave * NTP * 16 + nt * 16 + kq * 4 + r) * 2 + 1] = a2;
+                }
+            }
+        __syncthreads();
+        float* row = p.stats + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * p.nout_p;
+        for (int ch = tid; ch < p.nout_p; ch += NTHR) {
+            float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                a1 += sRed[(w * NTP * 16 + ch) * 2 + 0];
+                a2 += sRed[(w * NTP * 16 + ch) * 2 + 1];
+            }
+            row[ch] = a1;
+            row[p.nout_p + ch] = a2;
+        }
+    }
+}
+
+// ---- composite weights in fragment order: wp[chunk][parity][tap8 = (dz*2+dy)*2+dx][ntp][kq][n][j]
+// per axis: the (t, a) pairs behind (parity bit, tap bit): t = conv tap index 0..2, a = transposed-conv tap 0..1
+__device__ __forceinline__ int axis_pairs(int pbit, int jbit, int (&t)[2], int (&a)[2]) {
+    if (pbit == 0) {
+        if (jbit == 0) { t[0] = 0; a[0] = 1; return 1; }
+        t[0] = 1; a[0] = 0; t[1] = 2; a[1] = 1; return 2;
+    }
+    if (jbit == 0) { t[0] = 0; a[0] = 0; t[1] = 1; a[1] = 1; return 2; }
+    t[0] = 2; a[0] = 0; return 1;
+}
+
+// Packing runs once per optimizer step.  Step 1: transposes so that step 2 reads coalesced --
+//   w3t[t 27][cm C][co nout_p] (zero beyond Co),  wtt[a 8][ci C][cm C].
+__global__ void upconv_transpose_kernel(const float* __restrict__ wt, const float* __restrict__ w3, float* __restrict__ wtt,
+                                        float* __restrict__ w3t, int C, int Co, int nout_p) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n3 = 27 * C * nout_p, nt = 8 * C * C;
+    if (idx < n3) {
+        const int co = idx % nout_p, cm = (idx / nout_p) % C, t = idx / (nout_p * C);
+        w3t[idx] = co < Co ? w3[((size_t)co * C + cm) * 27 + t] : 0.f;
+    } else if (idx < n3 + nt) {
+        const int k = idx - n3;
+        const int cm = k % C, ci = (k / C) % C, a = k / (C * C);
+        wtt[k] = wt[((size_t)ci * C + cm) * 8 + a];
+    }
+}
+
+// Step 2: 8 lanes per (chunk, parity, tap, padded input channel, output channel): the W_eff entry = sum over its <= 8
+// (conv tap, transposed-conv tap) pairs of a C-long dot product; each lane takes every 8th cm, a 3-step shuffle
+// reduction combines them and lane 0 writes the value straight to its fragment position
+__global__ void upconv_pack_kernel(const float* __restrict__ wtt, const float* __restrict__ w3t, float* __restrict__ wp,
+                                   int C, int nout_p, const int32_t* __restrict__ cinv, int nchunk, int ntpt) {
+    const int gidx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int sub = gidx & 7, idx = gidx >> 3;
+    const int ncol = ntpt * 16;
+    if (idx >= nchunk * 8 * 8 * 8 * ncol) return;       // (whole 8-lane groups leave together)
+    int r = idx;
+    const int co = r % ncol; r /= ncol;
+    const int r8 = r & 7; r >>= 3;                       // channel inside the chunk (= kq*2 + j)
+    const int tap = r & 7; r >>= 3;
+    const int par = r & 7; r >>= 3;
+    const int c = r;
+    const int rp = c * 8 + r8;
+    const int ci = cinv ? cinv[rp] : (rp < C ? rp : -1);
+    float v = 0.f;
+    if (ci >= 0 && co < nout_p) {
+        int tz[2], az[2], ty[2], ay[2], tx[2], ax[2];
+        const int nz = axis_pairs((par >> 2) & 1, (tap >> 2) & 1, tz, az);
+        const int ny = axis_pairs((par >> 1) & 1, (tap >> 1) & 1, ty, ay);
+        const int nx = axis_pairs(par & 1, tap & 1, tx, ax);
+        for (int iz = 0; iz < nz; ++iz)
+            for (int iy = 0; iy < ny; ++iy)
+                for (int ix = 0; ix < nx; ++ix) {
+                    const float* a = wtt + ((size_t)((az[iz] * 2 + ay[iy]) * 2 + ax[ix]) * C + ci) * C;
+                    const float* b = w3t + (size_t)((tz[iz] * 3 + ty[iy]) * 3 + tx[ix]) * C * nout_p + co;
+                    float s = 0.f;
+#pragma unroll 4
+                    for (int cm = sub; cm < C; cm += 8) s = fmaf(a[cm], b[(size_t)cm * nout_p], s);
+                    v += s;
+                }
+    }
+    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+    if (sub == 0) {
+        const int nt = co >> 4, n = co & 15, kq = r8 >> 1, j = r8 & 1;
+        wp[((((size_t)c * 8 + par) * 8 + tap) * ntpt + nt) * 128 + kq * 32 + n * 2 + j] = v;
+    }
+}
+
+// b_eff[class 27][nout_p]: class = (cz*3+cy)*3+cx, per axis 0 interior, 1 first fine voxel (t=0 outside), 2 last (t=2 outside).
+// One block: S[t][co] = sum_cm bT[cm] w3t[t][cm][co] into LDS (coalesced over co), then the 27 class sums of valid taps.
+__global__ __launch_bounds__(1024) void upconv_beff_kernel(const float* __restrict__ bt, const float* __restrict__ w3t,
+                                                           float* __restrict__ beff, int C, int nout_p) {
+    __shared__ float S[27 * 64];
+    for (int i = threadIdx.x; i < 27 * nout_p; i += blockDim.x) {
+        const int co = i % nout_p, t = i / nout_p;
+        const float* b = w3t + (size_t)t * C * nout_p + co;
+        float s = 0.f;
+#pragma unroll 4
+        for (int cm = 0; cm < C; ++cm) s = fmaf(bt[cm], b[(size_t)cm * nout_p], s);
+        S[i] = s;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 27 * nout_p; i += blockDim.x) {
+        const int co = i % nout_p, cls = i / nout_p;
+        const int cz = cls / 9, cy = (cls / 3) % 3, cx = cls % 3;
+        float v = 0.f;
+        for (int t = 0; t < 27; ++t) {
+            const int tz = t / 9, ty = (t / 3) % 3, tx = t % 3;
+            if ((cz == 1 && tz == 0) || (cz == 2 && tz == 2) || (cy == 1 && ty == 0) || (cy == 2 && ty == 2) ||
+                (cx == 1 && tx == 0) || (cx == 2 && tx == 2))
+                continue;
+            v += S[t * nout_p + co];
+        }
+        beff[i] = v;
+    }
+}
+
+static void up_grid(int ntiles, int ny, int* gx, int* tpb) {
+    int g = 512 / ny;                                   // 2 resident blocks per CU
+    if (g < 1) g = 1;
+    if (g > ntiles) g = ntiles;
+    *tpb = ceil_div(ntiles, g);
+    *gx = ceil_div(ntiles, *tpb);
+}
+
+static int up_ny(int nout_p) { return nout_p <= 16 ? 1 : (nout_p <= 32 ? 2 : 4); }
+
+}  // namespace
+
+// =================================================================== C ABI
+extern "C" int ctu_upconv_fused_supported(int k, int D, int H, int W, int cin_p, int nout_p) {
+    // coarse volume at least one 16-wide box, 8..64 padded output channels; the volume must be a multiple of the
+    // 4x4x16 box only for speed, not for correctness
+    return k == 3 && W >= 16 && D >= 1 && H >= 1 && cin_p % 8 == 0 && cin_p >= 8 && nout_p % 8 == 0 && nout_p >= 8 && nout_p <= 64;
+}
+
+extern "C" size_t ctu_upconv_fused_packed_floats(int cin_p, int nout_p) {
+    return (size_t)(cin_p / 8) * 8 * 8 * ceil_div(nout_p, 16) * 128;
+}
+
+extern "C" int ctu_upconv_fused_num_blocks(int N, int D, int H, int W, int nout_p) {
+    int gx, tpb;
+    const int ny = up_ny(nout_p);
+    up_grid(N * ceil_div(D, 4) * ceil_div(H, 4) * ceil_div(W, 16), ny, &gx, &tpb);
+    return gx * ny;
+}
+
+extern "C" size_t ctu_upconv_fused_pack_ws_floats(int C, int nout_p) { return (size_t)27 * C * nout_p + (size_t)8 * C * C; }
+
+extern "C" int ctu_upconv_fused_pack(const float* wt, const float* bt, const float* w3, int C, int Co, const int32_t* cinv,
+                                     int cin_p, int nout_p, float* wp, float* beff, float* ws, void* stream) {
+    CTU_REQUIRE(wt && bt && w3 && wp && beff && ws, "upconv_fused_pack: null pointer");
+    CTU_REQUIRE(C > 0 && Co > 0 && Co <= nout_p && cin_p % 8 == 0 && nout_p % 8 == 0 && (cinv || C <= cin_p),
+                "upconv_fused_pack: C=%d Co=%d cin_p=%d nout_p=%d", C, Co, cin_p, nout_p);
+    hipStream_t st = (hipStream_t)stream;
+    const int ntpt = ceil_div(nout_p, 16);
+    float* w3t = ws;
+    float* wtt = ws + (size_t)27 * C * nout_p;
+    const int ntr = 27 * C * nout_p + 8 * C * C;
+    upconv_transpose_kernel<<<ceil_div(ntr, 256), 256, 0, st>>>(wt, w3, wtt, w3t, C, Co, nout_p);
+    CTU_CHECK_LAUNCH("upconv_fused_transpose");
+    const int total = (cin_p / 8) * 8 * 8 * 8 * ntpt * 16 * 8;           // 8 lanes per packed element
+    upconv_pack_kernel<<<ceil_div(total, 256), 256, 0, st>>>(wtt, w3t, wp, C, nout_p, cinv, cin_p / 8, ntpt);
+    CTU_CHECK_LAUNCH("upconv_fused_pack");
+    upconv_beff_kernel<<<1, 1024, 0, st>>>(bt, w3t, beff, C, nout_p);
+    CTU_CHECK_LAUNCH("upconv_fused_beff");
+    return CTU_OK;
+}
+
+extern "C" int ctu_upconv_fused_fwd(const float* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
+                                    int in_relu, const float* wp, const float* beff, float* out, int out_cs, int nout_p,
+                                    float* stats, int N, int D, int H, int W, void* stream) {
+    CTU_REQUIRE(in && wp && beff && out, "upconv_fused_fwd: null pointer");
+    CTU_REQUIRE(ctu_upconv_fused_supported(3, D, H, W, cin_p, nout_p), "upconv_fused_fwd: unsupported geometry (W=%d cin_p=%d nout_p=%d)",
+                W, cin_p, nout_p);
+    CTU_REQUIRE(in_cs >= cin_p && in_cs % 4 == 0 && out_cs >= nout_p && out_cs % 4 == 0, "upconv_fused_fwd: bad stride");
+    CTU_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "upconv_fused_fwd: scale/shift must come together");
+    CTU_REQUIRE(((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)wp & 15) == 0 && ((uintptr_t)beff & 15) == 0,
+                "upconv_fused_fwd: 16-byte alignment");
+    CTU_REQUIRE((int64_t)N * D * H * W * 8 < (int64_t)1 << 31 && (int64_t)(2 * H * W + 2 * W + 2) * in_cs * 4 < (int64_t)1 << 31,
+                "upconv_fused_fwd: volume too large for 32-bit offsets");
+    UpP p;
+    p.in = in; p.in_scale = in_scale; p.in_shift = in_shift; p.wp = wp; p.beff = beff; p.out = out; p.stats = stats;
+    p.in_cs = in_cs; p.rin_p = cin_p; p.in_relu = in_relu; p.out_cs = out_cs; p.nout_p = nout_p;
+    p.N = N; p.D = D; p.H = H; p.W = W;
+    p.tiles_d = ceil_div(D, 4); p.tiles_h = ceil_div(H, 4); p.tiles_w = ceil_div(W, 16);
+    const int ntiles = N * p.tiles_d * p.tiles_h * p.tiles_w;
+    const int ny = up_ny(nout_p);
+    int gx, tpb;
+    up_grid(ntiles, ny, &gx, &tpb);
+    hipStream_t st = (hipStream_t)stream;
+    if (ny == 1) upconv_fused_fwd_kernel<8, 1><<<dim3(gx, 1), 256, 0, st>>>(p, ntiles, tpb);
+    else if (ny == 2) upconv_fused_fwd_kernel<4, 2><<<dim3(gx, 2), 256, 0, st>>>(p, ntiles, tpb);
+    else upconv_fused_fwd_kernel<2, 4><<<dim3(gx, 4), 256, 0, st>>>(p, ntiles, tpb);
+    CTU_CHECK_LAUNCH("upconv_fused_fwd");
+    return CTU_OK;
+}

@@ -70,6 +70,12 @@ SIGNATURES = {
     "ctu_loss_fwd": (I, [P, P, I, L, F, F, I, P, P, P]),
     "ctu_loss_bwd": (I, [P, P, I, L, F, F, I, P, P, P, I, P]),
     "ctu_skip_add": (I, [P, I, P, P, I, P, I, P, P, I, P, I, I, L, P]),
+    "ctu_upconv_fused_supported": (I, [I, I, I, I, I, I]),
+    "ctu_upconv_fused_packed_floats": (Z, [I, I]),
+    "ctu_upconv_fused_num_blocks": (I, [I, I, I, I, I]),
+    "ctu_upconv_fused_pack_ws_floats": (Z, [I, I]),
+    "ctu_upconv_fused_pack": (I, [P, P, P, I, I, P, I, I, P, P, P, P]),
+    "ctu_upconv_fused_fwd": (I, [P, I, I, P, P, I, P, P, P, I, I, P, I, I, I, I, P]),
     "ctu_hard_segm": (I, [P, I, I, L, P, P]),
     "ctu_one_hot": (I, [P, I, I, L, P, P]),
     "ctu_hard_dice_ws_doubles": (Z, [I]),

@@ -18,6 +18,7 @@ Data flow (DESIGN.md has the picture):
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Tuple
 
@@ -27,6 +28,8 @@ from . import ops
 from .ops import CL, pad8
 
 BN_EPS = 1e-5
+# decoder ConvTranspose3d -> Conv3d pairs run as one coarse-grid kernel (CTUNET_FUSE_UP=0: the two separate kernels)
+FUSE_UP = os.environ.get("CTUNET_FUSE_UP", "1") != "0"
 BN_MOMENTUM = 0.1
 
 
@@ -64,6 +67,7 @@ class UNetEngine:
         self.plan = plan
         self._pack_cache: Dict[Tuple, Tuple[int, torch.Tensor]] = {}
         self._replay_stats = False
+        self._up_cache: Dict[str, Tuple] = {}
         self._imaps: Dict[Tuple, torch.Tensor] = {}
 
     # ------------------------------------------------------------------ small helpers
@@ -146,6 +150,49 @@ class UNetEngine:
             rec.first = None
             rec.x, rec.y, rec.vec, rec.stats, rec.nblk = x, out.raw(), vec4, stats, nblk
             rec.conv, rec.bn, rec.cin, rec.cout, rec.imap, rec.bias = conv, bn, cin, cout, imap, bias is not None
+        return y, rec
+
+    def _fuse_up(self, x: CL, nout_p: int) -> bool:
+        """Run ConvTranspose3d -> Conv3d of a decoder block as one coarse-grid kernel (ops.upconv_fused_fwd)?
+        Levels whose first conv has at most 16 (padded) output channels: they hold the FLOPs and have enough boxes."""
+        return (self.plan.k == 3 and not self.plan.conv_bias and nout_p <= 16 and FUSE_UP
+                and ops.upconv_fused_supported(x.dims, 3, x.cp, nout_p))
+
+    def _upconv_bn(self, P, x: CL, prefix: str, ct: int, cout: int, cinv, out: CL, vec4: torch.Tensor, training: bool,
+                   n_upd: int, save: bool) -> Tuple[CL, Optional[_ConvRec]]:
+        """{prefix}.0 (ConvTranspose3d) + {prefix}.1 (Conv3d) fused, then {prefix}.2 (BatchNorm) as in _conv_bn.
+        The record's input (the transposed conv's output) is NOT materialised: backward recomputes it (rec.x None)."""
+        conv, bn = f"{prefix}.1", f"{prefix}.2"
+        wt, bt, w3 = P[f"{prefix}.0.weight"], P[f"{prefix}.0.bias"], P[conv + ".weight"]
+        ver = tuple((t._version, t.data_ptr()) for t in (wt, bt, w3))
+        hit = self._up_cache.get(prefix)
+        if hit is None or hit[0] != ver or hit[3] != (x.cp, out.cp) or torch.cuda.is_current_stream_capturing():
+            into = (hit[1], hit[2], hit[4]) if hit is not None and hit[3] == (x.cp, out.cp) else None
+            wp, beff, pws = ops.upconv_fused_pack(wt, bt, w3, cinv, x.cp, out.cp, into)
+            self._up_cache[prefix] = (ver, wp, beff, (x.cp, out.cp), pws)
+        else:
+            wp, beff = hit[1], hit[2]
+        nvox = 8 * x.nvox
+        if training:
+            nblk = ops.upconv_fused_num_blocks(x.dims, out.cp)
+            stats = torch.empty((nblk, 2, out.cp), dtype=torch.float32, device=x.buf.device)
+            ops.upconv_fused_fwd(x, wp, beff, out, stats, (ct, cout))
+            ops.bn_finalize_into(stats, nblk, cout, out.cp, nvox, P[bn + ".weight"], P[bn + ".bias"],
+                                 P[bn + ".running_mean"], P[bn + ".running_var"], BN_MOMENTUM, BN_EPS, n_upd, vec4)
+            if n_upd:
+                self._nbt.append(P[bn + ".num_batches_tracked"])
+        else:
+            stats, nblk = None, 0
+            ops.upconv_fused_fwd(x, wp, beff, out, None, (ct, cout))
+            ops.bn_eval_affine_into(P[bn + ".weight"], P[bn + ".bias"], P[bn + ".running_mean"],
+                                    P[bn + ".running_var"], BN_EPS, cout, out.cp, vec4)
+        y = out.with_xf(vec4[0], vec4[1], True)
+        rec = None
+        if save:
+            rec = _ConvRec()
+            rec.first = None
+            rec.x, rec.y, rec.vec, rec.stats, rec.nblk = None, out.raw(), vec4, stats, nblk
+            rec.conv, rec.bn, rec.cin, rec.cout, rec.imap, rec.bias = conv, bn, ct, cout, None, False
         return y, rec
 
     def _first_conv_bn(self, P, x: torch.Tensor, conv: str, bn: str, cin: int, cout: int, out: CL, vec4: torch.Tensor,
@@ -262,14 +309,19 @@ class UNetEngine:
             imap_t, cinv_t = self._maps(cur_segs, cur.cp, dev)
             wt = P[f"{blk.prefix}.0.weight"]
             wpt = self._packed(f"{blk.prefix}.0", wt, "convt", cinv_t, cur.cp, ctp, 0)
-            up = CL(torch.empty((n, dd, hh, ww, ctp), dtype=torch.float32, device=dev), 0, ctp)
-            ops.convt_fwd(cur, wpt, P[f"{blk.prefix}.0.bias"].detach(), up)
             dec_in.append(cur)
-            ups.append(up)
             t1 = CL(torch.empty((n, dd, hh, ww, cp), dtype=torch.float32, device=dev), 0, cp)
             v1 = torch.empty((4, cp), dtype=torch.float32, device=dev)
-            a1, recs[(blk.prefix, 1)] = self._conv_bn(P, up, f"{blk.prefix}.1", f"{blk.prefix}.2", ct, blk.cout, None, t1,
-                                                      v1, training, n_upd, save)
+            if self._fuse_up(cur, cp):
+                ups.append(None)                      # never materialised in forward; backward recomputes it
+                a1, recs[(blk.prefix, 1)] = self._upconv_bn(P, cur, blk.prefix, ct, blk.cout, cinv_t, t1, v1, training,
+                                                            n_upd, save)
+            else:
+                up = CL(torch.empty((n, dd, hh, ww, ctp), dtype=torch.float32, device=dev), 0, ctp)
+                ops.convt_fwd(cur, wpt, P[f"{blk.prefix}.0.bias"].detach(), up)
+                ups.append(up)
+                a1, recs[(blk.prefix, 1)] = self._conv_bn(P, up, f"{blk.prefix}.1", f"{blk.prefix}.2", ct, blk.cout, None,
+                                                          t1, v1, training, n_upd, save)
             a2, recs[(blk.prefix, 2)] = self._conv_bn(P, a1, f"{blk.prefix}.4", f"{blk.prefix}.5", blk.cout, blk.cout, None,
                                                       CL(cat[i], 0, cp), xf[i][:, :cp], training, n_upd, save)
             if plan.skip == "cat":               # free concat: both producers wrote channel slices of cat[i]
@@ -344,10 +396,10 @@ class UNetEngine:
                 ws_n = max(ws_n, ops.conv_first_wgrad_ws(r.y.dims, r.cin))
                 part_n = max(part_n, ops.bn_bwd_partials_floats(r.y.nvox, r.y.cp))
                 continue
-            ws_n = max(ws_n, ops.conv3d_wgrad_ws(r.x.dims, k, r.x.cp, r.y.cp))
+            ws_n = max(ws_n, ops.conv3d_wgrad_ws(r.y.dims, k, r.x.cp if r.x is not None else pad8(r.cin), r.y.cp))
             part_n = max(part_n, ops.bn_bwd_partials_floats(r.y.nvox, r.y.cp))
-        for x_in, up in zip(ctx["dec_in"], ctx["ups"]):
-            ws_n = max(ws_n, ops.convt_wgrad_ws(x_in.dims, x_in.cp, up.cp))
+        for x_in, blk in zip(ctx["dec_in"], plan.dec):
+            ws_n = max(ws_n, ops.convt_wgrad_ws(x_in.dims, x_in.cp, pad8(blk.cin)))
         ws = torch.empty(ws_n, dtype=torch.float32, device=dev)
         part = torch.empty(part_n, dtype=torch.float32, device=dev)
 
@@ -391,9 +443,6 @@ class UNetEngine:
             g_u2 = CL(gcat[i], 0, cp)
             g_u1 = CL(torch.empty_like(r1.y.buf), 0, cp)
             self._conv_bn_bwd(P, r2, g_u2, g_u1, grads, ws, part)
-            up = ctx["ups"][j]
-            g_up = CL(torch.empty_like(up.buf), 0, up.cp)
-            self._conv_bn_bwd(P, r1, g_u1, g_up, grads, ws, part)
             x_in = ctx["dec_in"][j]
             ct = blk.cin
             if j > 0 and plan.skip == "cat":
@@ -402,6 +451,18 @@ class UNetEngine:
                 segs = ((ct, 0),)
             imap_t, cinv_t = self._maps(segs, x_in.cp, dev)
             wt = P[f"{blk.prefix}.0.weight"]
+            up = ctx["ups"][j]
+            if up is None:
+                # the forward ran ConvTranspose3d -> Conv3d fused and never wrote the transposed conv's output;
+                # the (unfused) backward of the two layers needs it as the conv's input: recompute it here
+                ctp = pad8(ct)
+                nn_, dd_, hh_, ww_ = r1.y.dims
+                up = CL(torch.empty((nn_, dd_, hh_, ww_, ctp), dtype=torch.float32, device=dev), 0, ctp)
+                ops.convt_fwd(x_in, self._packed(f"{blk.prefix}.0", wt, "convt", cinv_t, x_in.cp, ctp, 0),
+                              P[f"{blk.prefix}.0.bias"].detach(), up)
+                r1.x = up
+            g_up = CL(torch.empty_like(up.buf), 0, up.cp)
+            self._conv_bn_bwd(P, r1, g_u1, g_up, grads, ws, part)
             dwt, dbt = ops.convt_wgrad(x_in, g_up, ct, ct, imap_t, ws)
             grads[f"{blk.prefix}.0.weight"], grads[f"{blk.prefix}.0.bias"] = dwt, dbt
             wpd = self._packed(f"{blk.prefix}.0", wt, "convt", cinv_t, g_up.cp, x_in.cp, 1)

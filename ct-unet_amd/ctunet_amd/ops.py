@@ -512,6 +512,54 @@ def channel_sum(x: CL, c: int) -> torch.Tensor:
     return out
 
 
+# ---------------------------------------------------------------------------- fused up-convolution (decoder)
+def upconv_fused_supported(dims, k: int, cin_p: int, nout_p: int) -> bool:
+    n, d, h, w = dims
+    return bool(_lib.load().ctu_upconv_fused_supported(k, d, h, w, cin_p, nout_p))
+
+
+def upconv_fused_pack(wt: torch.Tensor, bt: torch.Tensor, w3: torch.Tensor, cinv, cin_p: int, nout_p: int,
+                      into=None):
+    """Composite weights (fragment order) and the 27 border-class biases of ConvTranspose3d(C,C,2,2) -> Conv3d(C,Co,3).
+    into = (wp, beff): re-pack in place (stable pointers for graph replay)."""
+    lib = _lib.load()
+    c, co = wt.shape[0], w3.shape[0]
+    assert wt.shape == (c, c, 2, 2, 2) and w3.shape == (co, c, 3, 3, 3) and bt.shape == (c,)
+    if into is not None:
+        wp, beff, ws = into
+    else:
+        wp = torch.empty(lib.ctu_upconv_fused_packed_floats(cin_p, nout_p), dtype=torch.float32, device=wt.device)
+        beff = torch.empty((27, nout_p), dtype=torch.float32, device=wt.device)
+        ws = torch.empty(lib.ctu_upconv_fused_pack_ws_floats(c, nout_p), dtype=torch.float32, device=wt.device)
+    _lib.check(lib.ctu_upconv_fused_pack(wt.detach().contiguous().data_ptr(), bt.detach().contiguous().data_ptr(),
+                                         w3.detach().contiguous().data_ptr(), c, co, _ptr(cinv), cin_p, nout_p, wp.data_ptr(),
+                                         beff.data_ptr(), ws.data_ptr(), _stream()), "upconv_fused_pack")
+    return wp, beff, ws
+
+
+def upconv_fused_num_blocks(dims, nout_p: int) -> int:
+    n, d, h, w = dims
+    return _lib.load().ctu_upconv_fused_num_blocks(n, d, h, w, nout_p)
+
+
+def upconv_fused_fwd(x: CL, wp: torch.Tensor, beff: torch.Tensor, out: CL, stats: Optional[torch.Tensor],
+                     algo_ch: Optional[Tuple[int, int]] = None) -> None:
+    """out (fine grid, raw) = conv3(convT(act(x))) in one kernel; x is the COARSE input."""
+    n, d, h, w = x.dims
+    assert out.dims == (n, 2 * d, 2 * h, 2 * w)
+    lib = _lib.load()
+    t0 = TIMER.begin() if TIMER is not None else None
+    _lib.check(lib.ctu_upconv_fused_fwd(x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), wp.data_ptr(),
+                                        beff.data_ptr(), out.ptr, out.cs, out.cp, _ptr(stats), n, d, h, w, _stream()),
+               "upconv_fused_fwd")
+    if t0 is not None:
+        ci, co = algo_ch if algo_ch is not None else (x.cp, out.cp)
+        vox = n * d * h * w
+        # algorithmic work of the two layers it replaces: convT 2*ci*ci*8 per coarse voxel + conv 2*27*ci*co per fine voxel
+        TIMER.end(f"upconv_fused_fwd_kernel<{out.cp}>", vox * (16.0 * ci * ci + 8 * 54.0 * ci * co), 4.0 * vox * (ci + 8 * co),
+                  t0, (w, x.cp, out.cp))
+
+
 # ---------------------------------------------------------------------------- inference tail / sample schema
 def _ncv(t: torch.Tensor):
     """(N, C, V) of a contiguous fp32 NCDHW (5-D) or CDHW (4-D) CUDA map."""

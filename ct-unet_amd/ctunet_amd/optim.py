@@ -62,6 +62,9 @@ class Adam(torch.optim.Optimizer):
                                             float(b2), float(group["eps"]), float(group["weight_decay"]),
                                             int(bool(group["decoupled_weight_decay"])),
                                             torch.cuda.current_stream().cuda_stream), "adam_amsgrad")
+            # the kernel wrote the parameters through raw pointers: tell autograd / every (version-keyed) cache of
+            # derived data -- the engine's MFMA-ordered weight copies -- that they changed
+            torch.autograd.graph.increment_version(live)
         return loss
 
 

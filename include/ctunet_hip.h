@@ -262,6 +262,27 @@ int ctu_loss_bwd(const float* pred, const float* target, int N, int64_t V, float
 int ctu_skip_add(const float* a, int a_cs, const float* a_scale, const float* a_shift, int a_relu,
                  const float* b, int b_cs, const float* b_scale, const float* b_shift, int b_relu,
                  float* out, int out_cs, int cp, int64_t nvox, void* stream);
+/* ------------------------------------------- fused up-convolution (decoder) ---- */
+/* ConvTranspose3d(C, C, 2, 2, bias) followed by Conv3d(C, Co, 3, padding 1, no bias) -- the first two layers of
+ * every decoder block (/root/reference/ctunet/pytorch/models.py:37-38) -- as ONE convolution on the coarse grid:
+ * per output parity a 2x2x2 convolution with composite weights W_eff = WT o W3 and a bias that only differs on the
+ * volume faces (27 border classes).  Same result as the two layers up to fp32 summation order; 8 taps instead of
+ * 27 + the transposed conv, and the fine-grid intermediate is never materialised.
+ *   ctu_upconv_fused_pack: wt [C][C][2][2][2], bt [C], w3 [Co][C][3][3][3] (torch layouts) -> wp (packed_floats)
+ *     and beff [27][nout_p]; cinv maps padded input positions to logical channels (concat layout), NULL = identity;
+ *     ws = pack_ws_floats scratch (transposed copies of the two weight tensors).
+ *   ctu_upconv_fused_fwd: in = COARSE activations [N,D,H,W,in_cs] with the lazy BatchNorm transform, out = RAW
+ *     fine-grid output [N,2D,2H,2W,out_cs]; stats = num_blocks rows of [2][nout_p] partial sums for ctu_bn_finalize. */
+int ctu_upconv_fused_supported(int k, int D, int H, int W, int cin_p, int nout_p);
+size_t ctu_upconv_fused_packed_floats(int cin_p, int nout_p);
+int ctu_upconv_fused_num_blocks(int N, int D, int H, int W, int nout_p);
+size_t ctu_upconv_fused_pack_ws_floats(int C, int nout_p);
+int ctu_upconv_fused_pack(const float* wt, const float* bt, const float* w3, int C, int Co, const int32_t* cinv,
+                          int cin_p, int nout_p, float* wp, float* beff, float* ws, void* stream);
+int ctu_upconv_fused_fwd(const float* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
+                         int in_relu, const float* wp, const float* beff, float* out, int out_cs, int nout_p,
+                         float* stats, int N, int D, int H, int W, void* stream);
+
 /* -------------------------------------------------- inference tail / sample schema ---- */
 /* hard_segm_from_tensor (/root/reference/ctunet/utilities.py:103-124): seg[n,v] = (float)argmax_c prob[n,c,v] over an
  * NCDHW map; the first maximum wins (torch.argmax). */

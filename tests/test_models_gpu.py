@@ -387,3 +387,30 @@ def test_non_cubic_volumes_against_fp64_oracle(shape, kw):
     for n_, got, c32, r64 in checks:
         scale = r64.abs().max().item()
         assert err(got, r64) <= max(5 * err(c32, r64), 2e-3 * scale) + 1e-7, (n_, err(got, r64), err(c32, r64), scale)
+
+
+def test_fused_adam_training_trajectory_matches_torch_adam():
+    """Regression: the fused optimizer writes parameters through raw pointers and must bump their version counters,
+    otherwise the engine keeps convolving with stale MFMA-ordered weight copies.  Four eager steps with
+    ctunet_amd.optim.Adam must follow torch.optim.Adam(amsgrad=True) (Model.py:514-520)."""
+    A, M, L, PH = _mods()
+    from ctunet_amd import optim as O2
+    x = torch.randn(1, 1, 32, 32, 32, generator=gen(1)).cuda()
+    t = onehot_target((1, 2, 32, 32, 32), 2, 0.3).cuda()
+
+    def run(fused):
+        torch.manual_seed(0)
+        net = A.UNet(n_blocks=2, use_checkpoint=False).cuda().train()
+        opt = O2.Adam(net.parameters(), lr=1e-2) if fused else torch.optim.Adam(net.parameters(), lr=1e-2, amsgrad=True)
+        out = []
+        for _ in range(4):
+            ce, dc = L.fused_ce_dice(net(x), t, 1.0, 1.0, False)
+            (ce + dc).backward()
+            opt.step()
+            for p in net.parameters():
+                p.grad = None
+            out.append((ce + dc).item())
+        return out
+    a, b = run(True), run(False)
+    assert a[0] == b[0] and a[3] < a[0]
+    assert all(abs(u - v) < 2e-5 for u, v in zip(a, b)), (a, b)

@@ -462,3 +462,60 @@ def test_hard_dice_counts_full_size():
     cnt = ops.hard_dice_counts(p, t)
     assert torch.equal(cnt, cnt.round()) and cnt[0, :, 1].sum().item() == 128 ** 3 and cnt[0, :, 2].sum().item() == 128 ** 3
     assert cnt[0, 1, 0].item() == float(((p[0, 1] > p[0, 0]) & (t[0, 1] > 0.5)).sum().item())
+
+
+# ---------------------------------------------------------------------------- fused up-convolution
+@pytest.mark.parametrize("c,co,dims,segs", [
+    (8, 8, (1, 4, 4, 16), None),                      # single chunk, one box, every voxel on a face
+    (16, 8, (2, 8, 4, 32), None),                     # batch, two boxes along w
+    (24, 16, (1, 4, 8, 16), ((12, 0), (12, 16))),     # concat input layout (two slices of a 32-wide buffer)
+    (32, 8, (1, 6, 5, 20), None),                     # ragged: boxes hang over the volume on every axis
+    (16, 32, (1, 4, 4, 16), None),                    # 2 channel tiles, 2 parity groups
+    (8, 64, (1, 4, 4, 16), None),                     # 4 channel tiles, 4 parity groups
+])
+def test_upconv_fused_fwd(c, co, dims, segs):
+    """ConvTranspose3d(C,C,2,2,bias) -> Conv3d(C,Co,3,p=1) (models.py:37-38) as one coarse-grid kernel vs the two torch
+    ops in fp32 (reference = F.conv3d(F.conv_transpose3d(relu(bn(x))))), incl. the border-class bias at every face
+    and the BatchNorm partial sums.  Tolerance 1e-4 of the output scale: the composite weights re-associate the sums."""
+    ops = _ops()
+    n, d, h, w = dims
+    cop = ops.pad8(co)
+    x = torch.randn(n, c, d, h, w, generator=g(21))
+    wt = torch.randn(c, c, 2, 2, 2, generator=g(22)) * 0.2
+    bt = torch.randn(c, generator=g(23))
+    w3 = torch.randn(co, c, 3, 3, 3, generator=g(24)) * 0.1
+    if segs is None:
+        cp = ops.pad8(c)
+        xc = to_cl(x)
+        cinv = None
+        sc, sh = xf_vectors(c, cp, 25)
+        scl, shl = sc[:c], sh[:c]
+    else:                                             # logical channels live at padded positions (free-concat layout)
+        cp = 32
+        buf = torch.zeros(n, d, h, w, cp)
+        cinv_l = [-1] * cp
+        lo = 0
+        for cnt, start in segs:
+            buf[..., start:start + cnt] = x[:, lo:lo + cnt].permute(0, 2, 3, 4, 1)
+            for q in range(cnt):
+                cinv_l[start + q] = lo + q
+            lo += cnt
+        xc = ops.CL(buf.cuda(), 0, cp)
+        cinv = torch.tensor(cinv_l, dtype=torch.int32, device="cuda")
+        sc, sh = xf_vectors(cp, cp, 25)
+        pos = [i for i, v in enumerate(cinv_l) if v >= 0]
+        scl, shl = sc[pos], sh[pos]
+    xa = F.relu(x * scl.view(1, -1, 1, 1, 1) + shl.view(1, -1, 1, 1, 1))
+    ref = F.conv3d(F.conv_transpose3d(xa, wt, bt, stride=2), w3, padding=1)
+    wp, beff, _ = ops.upconv_fused_pack(wt.cuda(), bt.cuda(), w3.cuda(), cinv, cp, cop)
+    out = ops.CL(torch.full((n, 2 * d, 2 * h, 2 * w, cop), float("nan"), device="cuda"), 0, cop)
+    nb = ops.upconv_fused_num_blocks(dims, cop)
+    stats = torch.zeros(nb, 2, cop, device="cuda")
+    ops.upconv_fused_fwd(xc.with_xf(sc.cuda(), sh.cuda(), True), wp, beff, out, stats)
+    got = from_cl(out, co)
+    assert (got - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+    if cop > co:
+        assert torch.equal(out.buf[..., co:].cpu(), torch.zeros(n, 2 * d, 2 * h, 2 * w, cop - co))
+    s = stats.sum(0).cpu()
+    assert torch.allclose(s[0, :co], ref.sum((0, 2, 3, 4)), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(s[1, :co], (ref * ref).sum((0, 2, 3, 4)), rtol=1e-4, atol=1e-2)
