@@ -815,15 +815,19 @@ inline int wgrad_gx(int ntiles, int pairs_z) {
 //   SM = 1, SN = 2 (C -> 8): t0 = 0 keeps s'=0 (kw 0); t0 = 1 gives kw 1,2 -> 18
 //   SM = 2, SN = 1 (8 -> C): t0 = 0 gives kw 0,1; t0 = 1 keeps s=1 (kw 2)  -> 18
 // Persistent blocks walk contiguous voxel boxes with register prefetch of the next box.
-template <int SM, int SN>
+// UP: the weight gradient of the FUSED decoder up-convolution (upconv_fused.hip): in = COARSE activations, g = the
+// fine-grid gradient read at one output parity (blockIdx.y carries the parity), the 8 taps of that parity's 2x2x2
+// sub-cube of the coarse halo -> dW_eff[parity][tap][ci][co] slabs.
+template <int SM, int SN, bool UP = false>
 __global__ __launch_bounds__(256, CTU_K3S_OCC) void conv3d_wgrad_k3s_kernel(WgP p, int tiles_per_block) {
+    static_assert(!UP || (SM == 1 && SN == 1), "the fused up-convolution uses the full 16 x 16 channel tile");
     // box: 4 x 4 x 16 voxels; 4 x 4 x 8 for the full 16 x 16 channel tile, whose 27 accumulators leave fewer staging registers
     constexpr int TD = 4, TH = 4, TW = (SM == 2 && SN == 2) ? 16 : 8, HD = 6, HH = 6, HW = TW + 2, HV = HD * HH * HW;
     constexpr int KPR = TW / 4, NKS = TH * KPR;       // K-steps (4 voxels) per row / per plane
     constexpr int CM = 16 / SM, CN = 16 / SN;        // channels per block on the input / output side
     constexpr int GW = TW + (SN - 1), GV = TD * TH * GW;
     constexpr int QN = (SM == 2 && SN == 2) ? 1 : ((SM == 1 && SN == 1) ? 3 : 2);     // w positions per (kd, kh) row
-    constexpr int NMF = 9 * QN;
+    constexpr int NMF = UP ? 8 : 9 * QN;
     constexpr int AQ = CM / 4, GQ = CN / 4;
     constexpr int AITEMS = HV * AQ, AITER = (AITEMS + 255) / 256;
     constexpr int GITEMS = GV * GQ, GITER = (GITEMS + 255) / 256;
@@ -838,7 +842,10 @@ __global__ __launch_bounds__(256, CTU_K3S_OCC) void conv3d_wgrad_k3s_kernel(WgP 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, kq = lane >> 4;
-    const int cig = blockIdx.y % p.n_ci_t, cog = blockIdx.y / p.n_ci_t;
+    const int cig = blockIdx.y % p.n_ci_t, cog = UP ? (blockIdx.y / p.n_ci_t) % p.n_co_t : blockIdx.y / p.n_ci_t;
+    const int par = UP ? blockIdx.y / (p.n_ci_t * p.n_co_t) : 0;          // output parity (pz, py, px) = bits 2, 1, 0
+    const int pz = (par >> 2) & 1, py = (par >> 1) & 1, px = par & 1;
+    const int gH = UP ? 2 * p.H : p.H, gW = UP ? 2 * p.W : p.W, gs = UP ? 2 : 1;      // gradient grid: row strides, voxel step
     const int ci0 = cig * CM, co0 = cog * CN;
     const bool has_xf = p.in_scale != nullptr;
 
@@ -880,14 +887,16 @@ __global__ __launch_bounds__(256, CTU_K3S_OCC) void conv3d_wgrad_k3s_kernel(WgP 
     for (int it = 0; it < GITER; ++it) {
         const int e = tid + it * 256, v = (e < GITEMS) ? e / GQ : 0;
         const int tw = v % GW, th = (v / GW) % TH, td = v / (GW * TH);
-        goff[it] = (unsigned)(((td * p.H + th) * p.W + tw) * p.g_cs + co0 + gq * 4) * 4u;
+        goff[it] = (unsigned)(((gs * td * gH + gs * th) * gW + gs * tw) * p.g_cs + co0 + gq * 4) * 4u;
         if (SN == 2 && tw == 0) gw0 |= 1u << it;
     }
     // a full box's only out-of-volume items sit on halo faces that coincide with volume faces: a load from the box
     // origin (always inside) stands in for them and the LDS write zeroes them
-    const unsigned safe_a = (unsigned)(((p.H + 1) * p.W + 1) * p.in_cs + ci0 + aq * 4) * 4u;
-    const unsigned safe_g = (unsigned)((SN - 1) * p.g_cs + co0 + gq * 4) * 4u;
-    const bool ch_full = ci0 + CM <= p.cin_p && co0 + CN <= p.cout_p;       // uniform
+    // (UP: channel quads beyond the tensors -- 8 padded output channels in a 16-wide tile -- are masked per thread
+    //  instead of sending the whole block down the ragged path)
+    const unsigned safe_a = (unsigned)(((p.H + 1) * p.W + 1) * p.in_cs + ci0 + ((UP && !a_ok) ? 0 : aq * 4)) * 4u;
+    const unsigned safe_g = (unsigned)((SN - 1) * p.g_cs + co0 + ((UP && !g_ok) ? 0 : gq * 4)) * 4u;
+    const bool ch_full = UP || (ci0 + CM <= p.cin_p && co0 + CN <= p.cout_p);       // uniform
 
     // box coordinates advance incrementally (no div/mod per box)
     struct Box { int tx, ty, tz, n; };
@@ -915,7 +924,12 @@ __global__ __launch_bounds__(256, CTU_K3S_OCC) void conv3d_wgrad_k3s_kernel(WgP 
         const int d0 = b.tz * TD, h0 = b.ty * TH, w0 = b.tx * TW;
         const long long org = (((long long)b.n * p.D + d0) * p.H + h0) * p.W + w0;
         pf_abase = reinterpret_cast<const char*>(p.in + (org - ((long long)p.H * p.W + p.W + 1)) * p.in_cs);
-        pf_gbase = reinterpret_cast<const char*>(p.g + (org - (SN - 1)) * p.g_cs);
+        if (UP) {
+            const long long gorg = (((long long)b.n * 2 * p.D + 2 * d0 + pz) * gH + 2 * h0 + py) * gW + 2 * w0 + px;
+            pf_gbase = reinterpret_cast<const char*>(p.g + gorg * p.g_cs);
+        } else {
+            pf_gbase = reinterpret_cast<const char*>(p.g + (org - (SN - 1)) * p.g_cs);
+        }
         pf_bface = (d0 == 0 ? 1u : 0u) | (d0 + TD == p.D ? 2u : 0u) | (h0 == 0 ? 4u : 0u) | (h0 + TH == p.H ? 8u : 0u) |
                    (w0 == 0 ? 16u : 0u) | (w0 + TW == p.W ? 32u : 0u);
         amask = 0; gmask = 0;
@@ -924,12 +938,12 @@ __global__ __launch_bounds__(256, CTU_K3S_OCC) void conv3d_wgrad_k3s_kernel(WgP 
     // a full box's only out-of-volume items sit on halo faces that coincide with volume faces: they fetch the box
     // origin instead (no branch) and are zeroed when written to LDS
     auto fetch_a = [&](int it) {
-        const bool ok = (fw[it / FPW] & (pf_bface << (6 * (it % FPW)))) == 0u;
+        const bool ok = (fw[it / FPW] & (pf_bface << (6 * (it % FPW)))) == 0u && (!UP || a_ok);
         va[it] = *reinterpret_cast<const float4*>(pf_abase + (ok ? aoff[it] : safe_a));
         amask |= ok ? (1u << it) : 0u;
     };
     auto fetch_g = [&](int it) {
-        const bool ok = !((pf_bface & 16u) && ((gw0 >> it) & 1u));
+        const bool ok = !((pf_bface & 16u) && ((gw0 >> it) & 1u)) && (!UP || g_ok);
         vg[it] = *reinterpret_cast<const float4*>(pf_gbase + (ok ? goff[it] : safe_g));
         gmask |= ok ? (1u << it) : 0u;
     };
@@ -966,7 +980,7 @@ __global__ __launch_bounds__(256, CTU_K3S_OCC) void conv3d_wgrad_k3s_kernel(WgP 
 
     // fragment reads: one ds_read_b32 each at a compile-time offset from two per-lane bases, issued one K-step ahead
     typedef const volatile __attribute__((address_space(3))) float* lds_f_ptr;
-    lds_f_ptr vA = (lds_f_ptr)sA + ((wave * HH * HW + kq) * CM + i);
+    lds_f_ptr vA = (lds_f_ptr)sA + (((wave + pz) * HH + py) * HW + kq + px) * CM + i;      // (+ the parity's sub-cube origin)
     lds_f_ptr vG = (lds_f_ptr)sG + ((wave * TH * GW + kq + (SN - 1)) * CN + boff);
 
     // one staged item -> LDS stage st: transform (identity scale/shift without BatchNorm), zero what lies outside
@@ -1000,7 +1014,7 @@ __global__ __launch_bounds__(256, CTU_K3S_OCC) void conv3d_wgrad_k3s_kernel(WgP 
         auto a_read = [&](int j) -> float {
             const int ks = j / NMF, t = j % NMF;
             const int th = ks / KPR, tw4 = (ks % KPR) * 4;
-            const int r = t / QN, q = t % QN, kd = r / 3, kh = r % 3;
+            const int r = UP ? (t >> 1) : t / QN, q = UP ? (t & 1) : t % QN, kd = UP ? (r >> 1) : r / 3, kh = UP ? (r & 1) : r % 3;
             return cA[((kd * HH + th + kh) * HW + tw4 + q) * CM];
         };
         auto b_read = [&](int ks) -> float { return cG[((ks / KPR) * GW + (ks % KPR) * 4) * CN]; };
@@ -1169,6 +1183,39 @@ static int launch_wgrad_k3s(WgP p, float* dw, int Co, int Ci, const int32_t* cin
         p.ws, dw, Co, Ci, cinv, p.cin_p, p.n_ci_t, g.gx);
     CTU_CHECK_LAUNCH("conv3d_wgrad_k3s_reduce");
     return CTU_OK;
+}
+
+// dW_eff[parity 8][tap 8][cin_p][nout_p] from the slabs of the UP kernel (fixed-order parallel reduction)
+__global__ __launch_bounds__(1024) void upconv_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dweff,
+                                                                  int cin_p, int nout_p, int n_ci_g, int n_co_g, int gx) {
+    __shared__ float red[RPARTS][64];
+    const int e = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int el = blockIdx.x * 64 + e;                  // element of the [8][16][16] slab
+    const int yb = blockIdx.y;                           // (parity * n_co_g + cog) * n_ci_g + cig
+    float s = 0.f;
+    const float* src = ws + (size_t)yb * gx * (8 * 256) + el;
+    for (int k = part; k < gx; k += RPARTS) s += src[(size_t)k * (8 * 256)];
+    red[part][e] = s;
+    __syncthreads();
+    if (part != 0) return;
+    const float tot = red_total(red, e);
+    const int t = el >> 8, i = (el >> 4) & 15, j = el & 15;
+    const int cig = yb % n_ci_g, cog = (yb / n_ci_g) % n_co_g, par = yb / (n_ci_g * n_co_g);
+    const int rp = cig * 16 + i, co = cog * 16 + j;
+    if (rp < cin_p && co < nout_p) dweff[((size_t)(par * 8 + t) * cin_p + rp) * nout_p + co] = tot;
+}
+
+struct UpWgGeom { int ntiles, n_ci_g, n_co_g, pairs, gx, tpb; };
+static UpWgGeom upwg_geom(int N, int D, int H, int W, int cin_p, int nout_p) {
+    UpWgGeom g;
+    g.ntiles = N * ceil_div(D, 4) * ceil_div(H, 4) * ceil_div(W, 8);
+    g.n_ci_g = ceil_div(cin_p, 16);
+    g.n_co_g = ceil_div(nout_p, 16);
+    g.pairs = 8 * g.n_ci_g * g.n_co_g;
+    g.gx = wgrad_gx(g.ntiles, g.pairs);
+    g.tpb = ceil_div(g.ntiles, g.gx);
+    g.gx = ceil_div(g.ntiles, g.tpb);
+    return g;
 }
 
 }  // namespace
@@ -1437,5 +1484,36 @@ extern "C" int ctu_conv3d_wgrad(const float* in, int in_cs, int cin_p, const flo
                       : launch_wgrad<5, 1>(p, dw, Co, Ci, cinv, gz, gx, st);
     if (rc != CTU_OK) return rc;
     if (dbias) return ctu_channel_sum(gout, g_cs, cout_p, (int64_t)N * D * H * W, ws, dbias, Co, stream);
+    return CTU_OK;
+}
+
+// ---- fused decoder up-convolution: weight gradient w.r.t. the composite weights (see upconv_fused.hip)
+extern "C" size_t ctu_upconv_fused_wgrad_ws_floats(int N, int D, int H, int W, int cin_p, int nout_p) {
+    const UpWgGeom g = upwg_geom(N, D, H, W, cin_p, nout_p);
+    return (size_t)g.pairs * g.gx * 8 * 256;
+}
+
+extern "C" int ctu_upconv_fused_wgrad(const float* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
+                                      int in_relu, const float* gout, int g_cs, int nout_p, float* dweff, float* ws,
+                                      int N, int D, int H, int W, void* stream) {
+    CTU_REQUIRE(in && gout && dweff && ws, "upconv_fused_wgrad: null pointer");
+    CTU_REQUIRE(cin_p % 8 == 0 && nout_p % 8 == 0 && cin_p > 0 && nout_p > 0 && nout_p <= 64, "upconv_fused_wgrad: padded channels");
+    CTU_REQUIRE(in_cs >= cin_p && in_cs % 4 == 0 && g_cs >= nout_p && g_cs % 4 == 0, "upconv_fused_wgrad: bad stride");
+    CTU_REQUIRE(((uintptr_t)in & 15) == 0 && ((uintptr_t)gout & 15) == 0, "upconv_fused_wgrad: 16-byte alignment");
+    CTU_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "upconv_fused_wgrad: scale/shift must come together");
+    CTU_REQUIRE((int64_t)(2 * H * W + 2 * W + 2) * in_cs * 4 < (int64_t)1 << 31 && (int64_t)(8 * 2 * H + 8) * 2 * W * g_cs * 4 < (int64_t)1 << 31,
+                "upconv_fused_wgrad: volume too large for 32-bit offsets");
+    hipStream_t st = (hipStream_t)stream;
+    const UpWgGeom g = upwg_geom(N, D, H, W, cin_p, nout_p);
+    WgP p;
+    p.in = in; p.in_scale = in_scale; p.in_shift = in_shift; p.g = gout; p.ws = ws;
+    p.in_cs = in_cs; p.cin_p = cin_p; p.in_relu = in_relu; p.g_cs = g_cs; p.cout_p = nout_p;
+    p.N = N; p.D = D; p.H = H; p.W = W;
+    p.tiles_d = ceil_div(D, 4); p.tiles_h = ceil_div(H, 4); p.tiles_w = ceil_div(W, 8);
+    p.ntiles = g.ntiles; p.n_ci_t = g.n_ci_g; p.n_co_t = g.n_co_g;
+    conv3d_wgrad_k3s_kernel<1, 1, true><<<dim3(g.gx, g.pairs), 256, 0, st>>>(p, g.tpb);
+    CTU_CHECK_LAUNCH("upconv_fused_wgrad");
+    upconv_wgrad_reduce_kernel<<<dim3(8 * 256 / 64, g.pairs), 64 * RPARTS, 0, st>>>(ws, dweff, cin_p, nout_p, g.n_ci_g, g.n_co_g, g.gx);
+    CTU_CHECK_LAUNCH("upconv_fused_wgrad_reduce");
     return CTU_OK;
 }

@@ -405,6 +405,126 @@ __global__ __launch_bounds__(1024) void upconv_beff_kernel(const float* __restri
     }
 }
 
+// ------------------------------------------------------------------ backward w.r.t. the three parameter tensors
+// dW_eff[parity][tap][ci][co] (conv3d.hip, conv3d_wgrad_k3s_kernel<1,1,true>) and the fine-grid gradient dy are
+// projected onto the reference's parameters (the composite is bilinear in WT and W3):
+//   dWT[ci,cm,a] = sum_t sum_co dW_eff[pd(t,a)][ci][co] W3[co,cm,t]
+//   dW3[co,cm,t] = sum_a sum_ci dW_eff[pd(t,a)][ci][co] WT[ci,cm,a]  +  V[t][co] bT[cm]
+//   dbT[cm]      = sum_t sum_co V[t][co] W3[co,cm,t]
+// V[t][co] = sum of dy over the fine voxels whose conv tap t lies inside the volume (per axis: t=0 excludes the first
+// plane, t=2 the last) -- built from 27 box sums T[sel] (each axis: all / first plane / last plane).
+constexpr int FS_SPLIT = 64;
+
+__global__ __launch_bounds__(256) void upconv_face_sums_kernel(const float* __restrict__ dy, int cs, int cp, int N, int Df, int Hf,
+                                                               int Wf, float* __restrict__ tpart) {
+    const int sel = blockIdx.x;                                   // (sz*3 + sy)*3 + sx, 0 all / 1 first / 2 last
+    const int sz = sel / 9, sy = (sel / 3) % 3, sx = sel % 3;
+    const int nz = sz ? 1 : Df, ny = sy ? 1 : Hf, nx = sx ? 1 : Wf;
+    const int z0 = sz == 2 ? Df - 1 : 0, y0 = sy == 2 ? Hf - 1 : 0, x0 = sx == 2 ? Wf - 1 : 0;
+    const int nq = cp >> 2;
+    const int qd = threadIdx.x % nq;                              // 256 % nq == 0 for cp in {8, 16, 32, 64}
+    const int64_t nvox = (int64_t)N * nz * ny * nx;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t v = (int64_t)blockIdx.y * (256 / nq) + threadIdx.x / nq; v < nvox; v += (int64_t)FS_SPLIT * (256 / nq)) {
+        int64_t r = v;
+        const int x = x0 + (int)(r % nx); r /= nx;
+        const int y = y0 + (int)(r % ny); r /= ny;
+        const int z = z0 + (int)(r % nz);
+        const int n = (int)(r / nz);
+        const float4 g = *reinterpret_cast<const float4*>(dy + ((((size_t)n * Df + z) * Hf + y) * Wf + x) * cs + qd * 4);
+        acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
+    }
+    __shared__ float4 red[256];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o >= nq; o >>= 1) {                         // threads with equal quad are nq apart
+        if (threadIdx.x < o) {
+            float4 b = red[threadIdx.x + o];
+            float4& a = red[threadIdx.x];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < nq)
+        *reinterpret_cast<float4*>(tpart + ((size_t)sel * FS_SPLIT + blockIdx.y) * cp + threadIdx.x * 4) = red[threadIdx.x];
+}
+
+__global__ void upconv_v_kernel(const float* __restrict__ tpart, int cp, float* __restrict__ V) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 27 * cp) return;
+    const int co = idx % cp, t = idx / cp;
+    const int tz = t / 9, ty = (t / 3) % 3, tx = t % 3;
+    // per axis: tap 0 -> all - first, tap 1 -> all, tap 2 -> all - last
+    float v = 0.f;
+    for (int iz = 0; iz < (tz == 1 ? 1 : 2); ++iz)
+        for (int iy = 0; iy < (ty == 1 ? 1 : 2); ++iy)
+            for (int ix = 0; ix < (tx == 1 ? 1 : 2); ++ix) {
+                const int sz = iz == 0 ? 0 : (tz == 0 ? 1 : 2), sy = iy == 0 ? 0 : (ty == 0 ? 1 : 2), sx = ix == 0 ? 0 : (tx == 0 ? 1 : 2);
+                const float sign = ((iz + iy + ix) & 1) ? -1.f : 1.f;
+                const float* src = tpart + (size_t)((sz * 3 + sy) * 3 + sx) * FS_SPLIT * cp + co;
+                float s = 0.f;
+                for (int b = 0; b < FS_SPLIT; ++b) s += src[(size_t)b * cp];          // fixed order
+                v += sign * s;
+            }
+    V[idx] = v;
+}
+
+// (conv tap t in 0..2, transposed-conv tap a in 0..1) of one axis -> (parity bit, sub-cube tap bit) of its W_eff entry
+__device__ __forceinline__ void axis_pd(int t, int a, int& pbit, int& jbit) {
+    if (a == 1) { pbit = (t == 1) ? 1 : 0; jbit = (t == 2) ? 1 : 0; }        // (0,1)->(0,0) (1,1)->(1,0) (2,1)->(0,1)
+    else { pbit = (t == 1) ? 0 : 1; jbit = (t == 0) ? 0 : 1; }               // (0,0)->(1,0) (1,0)->(0,1) (2,0)->(1,1)
+}
+__device__ __forceinline__ int weff_index(int t, int a) {                    // (parity*8 + tap) of the 3-D pair (t, a)
+    int pz, jz, py, jy, px, jx;
+    axis_pd(t / 9, (a >> 2) & 1, pz, jz);
+    axis_pd((t / 3) % 3, (a >> 1) & 1, py, jy);
+    axis_pd(t % 3, a & 1, px, jx);
+    return ((pz * 4 + py * 2 + px) * 8) + (jz * 4 + jy * 2 + jx);
+}
+
+// 8 lanes per output element; grid covers dWT (C*C*8), then dW3 (Co*C*27), then dbT (C)
+__global__ void upconv_project_kernel(const float* __restrict__ dweff, const float* __restrict__ V, const float* __restrict__ wtt,
+                                      const float* __restrict__ w3t, const float* __restrict__ bt,
+                                      const int32_t* __restrict__ imap, int C, int Co, int cin_p, int nout_p,
+                                      float* __restrict__ dwt, float* __restrict__ dw3, float* __restrict__ dbt) {
+    const int gidx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int sub = gidx & 7;
+    int idx = gidx >> 3;
+    const int n1 = C * C * 8, n2 = Co * C * 27, n3 = C;
+    if (idx >= n1 + n2 + n3) return;
+    float v = 0.f;
+    float* dst;
+    if (idx < n1) {                                               // dWT[ci][cm][a]
+        const int a = idx & 7, cm = (idx >> 3) % C, ci = idx / (8 * C);
+        const int pos = imap ? imap[ci] : ci;
+        for (int t = sub; t < 27; t += 8) {
+            const float* g = dweff + ((size_t)weff_index(t, a) * cin_p + pos) * nout_p;
+            const float* w = w3t + ((size_t)t * C + cm) * nout_p;
+            for (int co = 0; co < Co; ++co) v = fmaf(g[co], w[co], v);
+        }
+        dst = dwt + idx;
+    } else if (idx < n1 + n2) {                                   // dW3[co][cm][t]
+        const int k = idx - n1;
+        const int t = k % 27, cm = (k / 27) % C, co = k / (27 * C);
+        for (int a = 0; a < 8; ++a) {
+            const float* g = dweff + (size_t)weff_index(t, a) * cin_p * nout_p + co;
+            const float* w = wtt + (size_t)a * C * C + cm;
+            for (int ci = sub; ci < C; ci += 8) v = fmaf(g[(size_t)(imap ? imap[ci] : ci) * nout_p], w[(size_t)ci * C], v);
+        }
+        if (sub == 0) v = fmaf(V[t * nout_p + co], bt[cm], v);
+        dst = dw3 + k;
+    } else {                                                      // dbT[cm]
+        const int cm = idx - n1 - n2;
+        for (int t = sub; t < 27; t += 8) {
+            const float* w = w3t + ((size_t)t * C + cm) * nout_p;
+            for (int co = 0; co < Co; ++co) v = fmaf(V[t * nout_p + co], w[co], v);
+        }
+        dst = dbt + cm;
+    }
+    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+    if (sub == 0) *dst = v;
+}
+
 static void up_grid(int ntiles, int ny, int* gx, int* tpb) {
     int g = 512 / ny;                                   // 2 resident blocks per CU
     if (g < 1) g = 1;
@@ -483,5 +603,31 @@ extern "C" int ctu_upconv_fused_fwd(const float* in, int in_cs, int cin_p, const
     else if (ny == 2) upconv_fused_fwd_kernel<4, 2><<<dim3(gx, 2), 256, 0, st>>>(p, ntiles, tpb);
     else upconv_fused_fwd_kernel<2, 4><<<dim3(gx, 4), 256, 0, st>>>(p, ntiles, tpb);
     CTU_CHECK_LAUNCH("upconv_fused_fwd");
+    return CTU_OK;
+}
+
+extern "C" size_t ctu_upconv_fused_project_ws_floats(int nout_p) { return (size_t)27 * FS_SPLIT * nout_p + (size_t)27 * nout_p; }
+
+// dweff: [8][8][cin_p][nout_p] from ctu_upconv_fused_wgrad; gout: fine-grid gradient w.r.t. the fused op's RAW output
+// [N,2D,2H,2W,g_cs]; pack_ws: the scratch ctu_upconv_fused_pack filled this step (transposed weights); imap: logical input
+// channel -> padded position (NULL = identity).  Outputs in torch layouts: dwt [C][C][2][2][2], dbt [C], dw3 [Co][C][3][3][3].
+extern "C" int ctu_upconv_fused_project(const float* dweff, const float* gout, int g_cs, int nout_p, int N, int D, int H, int W,
+                                        const float* bt, const float* pack_ws, const int32_t* imap, int C, int Co, int cin_p,
+                                        float* dwt, float* dbt, float* dw3, float* ws, void* stream) {
+    CTU_REQUIRE(dweff && gout && bt && pack_ws && dwt && dbt && dw3 && ws, "upconv_fused_project: null pointer");
+    CTU_REQUIRE(nout_p == 8 || nout_p == 16 || nout_p == 32 || nout_p == 64, "upconv_fused_project: nout_p=%d", nout_p);
+    CTU_REQUIRE(C > 0 && Co > 0 && Co <= nout_p && g_cs >= nout_p && g_cs % 4 == 0, "upconv_fused_project: bad channels");
+    hipStream_t st = (hipStream_t)stream;
+    float* tpart = ws;
+    float* V = ws + (size_t)27 * FS_SPLIT * nout_p;
+    upconv_face_sums_kernel<<<dim3(27, FS_SPLIT), 256, 0, st>>>(gout, g_cs, nout_p, N, 2 * D, 2 * H, 2 * W, tpart);
+    CTU_CHECK_LAUNCH("upconv_face_sums");
+    upconv_v_kernel<<<ceil_div(27 * nout_p, 256), 256, 0, st>>>(tpart, nout_p, V);
+    CTU_CHECK_LAUNCH("upconv_v");
+    const float* w3t = pack_ws;
+    const float* wtt = pack_ws + (size_t)27 * C * nout_p;
+    const int total = (C * C * 8 + Co * C * 27 + C) * 8;
+    upconv_project_kernel<<<ceil_div(total, 256), 256, 0, st>>>(dweff, V, wtt, w3t, bt, imap, C, Co, cin_p, nout_p, dwt, dw3, dbt);
+    CTU_CHECK_LAUNCH("upconv_project");
     return CTU_OK;
 }

@@ -360,10 +360,11 @@ class UNetEngine:
         if rec.first is not None:                  # direct C_in <= 2 kernels; gin is a request flag here
             grads[rec.conv + ".weight"] = ops.conv_first_wgrad(rec.first, ga, rec.cout, ws)
             return ops.conv_first_bwd_data(ga, P[rec.conv + ".weight"].detach(), rec.cin) if gin is not None else None
-        dw, dbias = ops.conv3d_wgrad(rec.x, ga, rec.cout, rec.cin, k, rec.imap, ws, rec.bias)
-        grads[rec.conv + ".weight"] = dw
-        if rec.bias:
-            grads[rec.conv + ".bias"] = dbias
+        if rec.x is not None:                      # (None: fused up-convolution, its weight gradients come from the caller)
+            dw, dbias = ops.conv3d_wgrad(rec.x, ga, rec.cout, rec.cin, k, rec.imap, ws, rec.bias)
+            grads[rec.conv + ".weight"] = dw
+            if rec.bias:
+                grads[rec.conv + ".bias"] = dbias
         if gin is not None:
             lay = ops.conv_layout(k, gin.cp, ga.dims[3])
             wpd = self._packed(rec.conv, P[rec.conv + ".weight"], "conv", rec.imap, ga.cp, gin.cp, 1, lay)
@@ -452,18 +453,17 @@ class UNetEngine:
             imap_t, cinv_t = self._maps(segs, x_in.cp, dev)
             wt = P[f"{blk.prefix}.0.weight"]
             up = ctx["ups"][j]
+            ctp = pad8(ct)
+            g_up = CL(torch.empty(r1.y.dims + (ctp,), dtype=torch.float32, device=dev), 0, ctp)
+            self._conv_bn_bwd(P, r1, g_u1, g_up, grads, ws, part)      # BN backward, (conv wgrad,) conv data gradient
             if up is None:
-                # the forward ran ConvTranspose3d -> Conv3d fused and never wrote the transposed conv's output;
-                # the (unfused) backward of the two layers needs it as the conv's input: recompute it here
-                ctp = pad8(ct)
-                nn_, dd_, hh_, ww_ = r1.y.dims
-                up = CL(torch.empty((nn_, dd_, hh_, ww_, ctp), dtype=torch.float32, device=dev), 0, ctp)
-                ops.convt_fwd(x_in, self._packed(f"{blk.prefix}.0", wt, "convt", cinv_t, x_in.cp, ctp, 0),
-                              P[f"{blk.prefix}.0.bias"].detach(), up)
-                r1.x = up
-            g_up = CL(torch.empty_like(up.buf), 0, up.cp)
-            self._conv_bn_bwd(P, r1, g_u1, g_up, grads, ws, part)
-            dwt, dbt = ops.convt_wgrad(x_in, g_up, ct, ct, imap_t, ws)
+                # ConvTranspose3d -> Conv3d ran fused (the transposed conv's output was never written): the gradients of
+                # BOTH layers' parameters come from the composite-weight gradient of the coarse input and g_u1
+                dwt, dbt, dw3 = ops.upconv_fused_wgrad(x_in, g_u1, ct, blk.cout, P[f"{blk.prefix}.0.bias"],
+                                                       self._up_cache[blk.prefix][4], imap_t)
+                grads[f"{blk.prefix}.1.weight"] = dw3
+            else:
+                dwt, dbt = ops.convt_wgrad(x_in, g_up, ct, ct, imap_t, ws)
             grads[f"{blk.prefix}.0.weight"], grads[f"{blk.prefix}.0.bias"] = dwt, dbt
             wpd = self._packed(f"{blk.prefix}.0", wt, "convt", cinv_t, g_up.cp, x_in.cp, 1)
             if j > 0:

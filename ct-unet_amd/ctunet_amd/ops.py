@@ -560,6 +560,33 @@ def upconv_fused_fwd(x: CL, wp: torch.Tensor, beff: torch.Tensor, out: CL, stats
                   t0, (w, x.cp, out.cp))
 
 
+def upconv_fused_wgrad(x: CL, g: CL, c: int, co: int, bt: torch.Tensor, pack_ws: torch.Tensor, imap):
+    """(dWT [C,C,2,2,2], dbT [C], dW3 [Co,C,3,3,3]) of the fused ConvTranspose3d -> Conv3d pair: x = COARSE input of the
+    transposed conv, g = fine-grid gradient w.r.t. the conv's raw output, pack_ws = scratch of this step's
+    upconv_fused_pack (transposed weights)."""
+    n, d, h, w = x.dims
+    assert g.dims == (n, 2 * d, 2 * h, 2 * w)
+    lib = _lib.load()
+    dev = x.buf.device
+    dweff = torch.empty((8, 8, x.cp, g.cp), dtype=torch.float32, device=dev)
+    ws = torch.empty(lib.ctu_upconv_fused_wgrad_ws_floats(n, d, h, w, x.cp, g.cp), dtype=torch.float32, device=dev)
+    t0 = TIMER.begin() if TIMER is not None else None
+    _lib.check(lib.ctu_upconv_fused_wgrad(x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), g.ptr, g.cs, g.cp,
+                                          dweff.data_ptr(), ws.data_ptr(), n, d, h, w, _stream()), "upconv_fused_wgrad")
+    if t0 is not None:
+        vox = n * d * h * w
+        TIMER.end(f"upconv_fused_wgrad_kernel<{g.cp}> (+slab reduce)", vox * (16.0 * c * c + 8 * 54.0 * c * co),
+                  4.0 * vox * (c + 8 * co), t0, (w, x.cp, g.cp))
+    dwt = torch.empty((c, c, 2, 2, 2), dtype=torch.float32, device=dev)
+    dbt = torch.empty(c, dtype=torch.float32, device=dev)
+    dw3 = torch.empty((co, c, 3, 3, 3), dtype=torch.float32, device=dev)
+    ws2 = torch.empty(lib.ctu_upconv_fused_project_ws_floats(g.cp), dtype=torch.float32, device=dev)
+    _lib.check(lib.ctu_upconv_fused_project(dweff.data_ptr(), g.ptr, g.cs, g.cp, n, d, h, w, bt.detach().data_ptr(),
+                                            pack_ws.data_ptr(), _ptr(imap), c, co, x.cp, dwt.data_ptr(), dbt.data_ptr(),
+                                            dw3.data_ptr(), ws2.data_ptr(), _stream()), "upconv_fused_project")
+    return dwt, dbt, dw3
+
+
 # ---------------------------------------------------------------------------- inference tail / sample schema
 def _ncv(t: torch.Tensor):
     """(N, C, V) of a contiguous fp32 NCDHW (5-D) or CDHW (4-D) CUDA map."""

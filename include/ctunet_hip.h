@@ -283,6 +283,20 @@ int ctu_upconv_fused_fwd(const float* in, int in_cs, int cin_p, const float* in_
                          int in_relu, const float* wp, const float* beff, float* out, int out_cs, int nout_p,
                          float* stats, int N, int D, int H, int W, void* stream);
 
+/* Backward of the fused up-convolution w.r.t. the three parameter tensors (the data gradient still takes the two
+ * unfused kernels).  ctu_upconv_fused_wgrad: dweff [8 parities][8 taps][cin_p][nout_p] = sum_i x[i+d]^T dy[2i+p]
+ * (in = COARSE activations with the lazy transform, gout = fine-grid gradient of the fused op's raw output).
+ * ctu_upconv_fused_project: dWT, dbT, dW3 (torch layouts) from dweff and the border-aware sums of gout; pack_ws is
+ * the scratch ctu_upconv_fused_pack filled in this step's forward, imap maps logical input channels to padded positions. */
+size_t ctu_upconv_fused_wgrad_ws_floats(int N, int D, int H, int W, int cin_p, int nout_p);
+int ctu_upconv_fused_wgrad(const float* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
+                           int in_relu, const float* gout, int g_cs, int nout_p, float* dweff, float* ws,
+                           int N, int D, int H, int W, void* stream);
+size_t ctu_upconv_fused_project_ws_floats(int nout_p);
+int ctu_upconv_fused_project(const float* dweff, const float* gout, int g_cs, int nout_p, int N, int D, int H, int W,
+                             const float* bt, const float* pack_ws, const int32_t* imap, int C, int Co, int cin_p,
+                             float* dwt, float* dbt, float* dw3, float* ws, void* stream);
+
 /* -------------------------------------------------- inference tail / sample schema ---- */
 /* hard_segm_from_tensor (/root/reference/ctunet/utilities.py:103-124): seg[n,v] = (float)argmax_c prob[n,c,v] over an
  * NCDHW map; the first maximum wins (torch.argmax). */

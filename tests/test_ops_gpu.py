@@ -519,3 +519,55 @@ def test_upconv_fused_fwd(c, co, dims, segs):
     s = stats.sum(0).cpu()
     assert torch.allclose(s[0, :co], ref.sum((0, 2, 3, 4)), rtol=1e-4, atol=1e-2)
     assert torch.allclose(s[1, :co], (ref * ref).sum((0, 2, 3, 4)), rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.parametrize("c,co,dims,segs", [
+    (8, 8, (1, 4, 4, 16), None),
+    (16, 8, (2, 8, 4, 32), None),
+    (24, 16, (1, 4, 8, 16), ((12, 0), (12, 16))),
+    (32, 8, (1, 6, 5, 20), None),
+    (16, 32, (1, 4, 4, 16), None),
+])
+def test_upconv_fused_wgrad(c, co, dims, segs):
+    """dWT, dbT, dW3 of ConvTranspose3d -> Conv3d through the composite-weight gradient and its projection, against
+    torch autograd of the two unfused ops in fp64 (tolerance 2e-4 of each tensor's scale; fp32 sums over up to 2e4
+    voxels).  Border planes matter for dbT / dW3 (zero padding of the transposed-conv output)."""
+    ops = _ops()
+    n, d, h, w = dims
+    cop = ops.pad8(co)
+    x = torch.randn(n, c, d, h, w, generator=g(31))
+    wt = (torch.randn(c, c, 2, 2, 2, generator=g(32)) * 0.2)
+    bt = torch.randn(c, generator=g(33))
+    w3 = (torch.randn(co, c, 3, 3, 3, generator=g(34)) * 0.1)
+    dy = torch.randn(n, co, 2 * d, 2 * h, 2 * w, generator=g(35))
+    if segs is None:
+        cp = ops.pad8(c)
+        xc = to_cl(x)
+        cinv = imap = None
+        sc, sh = xf_vectors(c, cp, 36)
+        scl, shl = sc[:c], sh[:c]
+    else:
+        cp = 32
+        buf = torch.zeros(n, d, h, w, cp)
+        cinv_l, imap_l, lo = [-1] * cp, [], 0
+        for cnt, start in segs:
+            buf[..., start:start + cnt] = x[:, lo:lo + cnt].permute(0, 2, 3, 4, 1)
+            for q in range(cnt):
+                cinv_l[start + q] = lo + q
+                imap_l.append(start + q)
+            lo += cnt
+        xc = ops.CL(buf.cuda(), 0, cp)
+        cinv = torch.tensor(cinv_l, dtype=torch.int32, device="cuda")
+        imap = torch.tensor(imap_l, dtype=torch.int32, device="cuda")
+        sc, sh = xf_vectors(cp, cp, 36)
+        scl, shl = sc[imap_l], sh[imap_l]
+    xa = F.relu(x * scl.view(1, -1, 1, 1, 1) + shl.view(1, -1, 1, 1, 1)).double()
+    wt64, bt64, w364 = (t.double().requires_grad_(True) for t in (wt, bt, w3))
+    ref = F.conv3d(F.conv_transpose3d(xa, wt64, bt64, stride=2), w364, padding=1)
+    ref.backward(dy.double())
+    _, _, pws = ops.upconv_fused_pack(wt.cuda(), bt.cuda(), w3.cuda(), cinv, cp, cop)
+    gcl = to_cl(dy)
+    dwt, dbt, dw3 = ops.upconv_fused_wgrad(xc.with_xf(sc.cuda(), sh.cuda(), True), gcl, c, co, bt.cuda(), pws, imap)
+    for name, got, want in (("dWT", dwt, wt64.grad), ("dbT", dbt, bt64.grad), ("dW3", dw3, w364.grad)):
+        err = (got.cpu().double() - want).abs().max().item()
+        assert err <= 2e-4 * want.abs().max().item(), (name, err, want.abs().max().item())
