@@ -308,6 +308,262 @@ __global__ __launch_bounds__(256, 2) void upconv_fused_fwd_kernel(UpP p, int nti
     }
 }
 
+// ------------------------------------------------------------------ fused data gradient
+// dX[i][ci] = sum_p sum_{d in D(p)} sum_co dy[2(i-d)+p][co] W_eff[p][d][ci][co]: the adjoint of the parity convolutions,
+// again on the COARSE grid.  The fine-grid gradient is read as a strided space-to-depth view: a "chunk" is 8 channels
+// of ONE output parity (fine voxel 2j + p of coarse voxel j), so the 6x6x18 coarse halo box of a chunk is staged exactly
+// like an input chunk of the forward kernel, only with doubled voxel strides and a parity offset.  A chunk of parity p
+// contributes through the 2x2x2 sub-cube of the halo that starts at 1 - p (coarse input j = i - d), with the taps of
+// W_eff mirrored (tap bit = 1 - sub-cube bit).  rows = input channels ci (NT 16-wide tiles per block), K = chunks x 8 taps.
+struct UpDP {
+    const float* g;           // fine grid [N, 2D, 2H, 2W, g_cs], raw-output gradient of the fused op
+    const float* wp;          // [chunk = parity*QC + q][tap 8][n16][128]
+    float* out;               // coarse [N, D, H, W, out_cs]
+    int g_cs, nout_p, out_cs, cin_p;
+    int N, D, H, W;           // COARSE dims
+    int tiles_d, tiles_h, tiles_w, n16;
+};
+
+template <int NT>
+__global__ __launch_bounds__(256, 2) void upconv_fused_bwd_data_kernel(UpDP p, int ntiles, int tiles_per_block) {
+    constexpr int MT = 4, TD = 4, TH = 4, TW = 16;
+    constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2, HV = HD * HH * HW;
+    constexpr int NTHR = 256;
+    constexpr int WFL = 8 * NT * 128;
+    constexpr int AITEMS = HV * 2, AITER = (AITEMS + NTHR - 1) / NTHR;
+    constexpr int WITER = (WFL / 4 + NTHR - 1) / NTHR;
+    constexpr int VS2 = 6;
+    static_assert(WFL / 4 % NTHR == 0, "weight staging covers the stage exactly");
+
+    __shared__ __attribute__((aligned(16))) v2f sA2[HV * VS2];
+    __shared__ __attribute__((aligned(16))) v2f sW2[WFL / 2];
+    typedef const volatile __attribute__((address_space(3))) v2f* lds_v2f_ptr;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, kq = lane >> 4;
+    const int by = blockIdx.y;
+    const int qc = p.nout_p >> 3;                        // 8-channel chunks per parity
+    const int nchunk = 8 * qc;
+    const int half = tid & 1;
+    const int Hf = 2 * p.H, Wf = 2 * p.W;
+
+    lds_v2f_ptr vA0 = (lds_v2f_ptr)sA2 + ((wave * HH) * HW + m) * VS2 + kq;
+    lds_v2f_ptr vW = (lds_v2f_ptr)sW2 + (kq * 16 + m);
+
+    unsigned hoff[AITER];
+    constexpr int FPW = 5, NFW = (AITER + FPW - 1) / FPW;
+    unsigned fw[NFW];
+#pragma unroll
+    for (int q = 0; q < NFW; ++q) fw[q] = 0;
+#pragma unroll
+    for (int it = 0; it < AITER; ++it) {
+        const int i = tid + it * NTHR;
+        const int v = (i < AITEMS) ? (i >> 1) : 0;
+        const int pw = v % HW, t2 = v / HW, ph = t2 % HH, pd = t2 / HH;
+        hoff[it] = (unsigned)(((2 * pd * Hf + 2 * ph) * Wf + 2 * pw) * p.g_cs + half * 4) * 4u;      // fine strides
+        const unsigned face = (pd == 0 ? 1u : 0u) | (pd == HD - 1 ? 2u : 0u) | (ph == 0 ? 4u : 0u) | (ph == HH - 1 ? 8u : 0u) |
+                              (pw == 0 ? 16u : 0u) | (pw == HW - 1 ? 32u : 0u);
+        fw[it / FPW] |= face << (6 * (it % FPW));
+    }
+    const unsigned safe_off = (unsigned)(((2 * Hf + 2) * Wf + 2) * p.g_cs + half * 4) * 4u;          // the box origin
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int tile = blockIdx.x * tiles_per_block;
+    const int tile_end = min(ntiles, tile + tiles_per_block);
+    if (tile >= tile_end) return;
+    int c = 0;
+    float4 va[AITER], vw[WITER];
+    unsigned vmask = 0;
+
+    struct Box { int tx, ty, tz, n; };
+    Box box;
+    {
+        int t = tile;
+        box.tx = t % p.tiles_w; t /= p.tiles_w;
+        box.ty = t % p.tiles_h; t /= p.tiles_h;
+        box.tz = t % p.tiles_d; box.n = t / p.tiles_d;
+    }
+    auto box_next = [&](Box b) {
+        if (++b.tx == p.tiles_w) { b.tx = 0; if (++b.ty == p.tiles_h) { b.ty = 0; if (++b.tz == p.tiles_d) { b.tz = 0; ++b.n; } } }
+        return b;
+    };
+    bool a_interior = false;
+    auto load_a = [&](Box b, int cc) {
+        const int d0 = b.tz * TD, h0 = b.ty * TH, w0 = b.tx * TW;
+        const int par = cc / qc, q = cc % qc;
+        const int pz = (par >> 2) & 1, py = (par >> 1) & 1, px = par & 1;
+        // fine voxel of the coarse halo origin (d0-1, h0-1, w0-1) at parity p (may lie outside: only valid items are read)
+        const long long org = (((long long)b.n * 2 * p.D + 2 * (d0 - 1) + pz) * Hf + 2 * (h0 - 1) + py) * Wf + 2 * (w0 - 1) + px;
+        const char* base = reinterpret_cast<const char*>(p.g + org * p.g_cs + q * 8);
+        a_interior = d0 >= 1 && h0 >= 1 && w0 >= 1 && d0 + TD < p.D && h0 + TH < p.H && w0 + TW < p.W;
+        if (a_interior) {
+#pragma unroll
+            for (int it = 0; it < AITER; ++it) {
+                if ((it + 1) * NTHR <= AITEMS || tid + it * NTHR < AITEMS)
+                    va[it] = *reinterpret_cast<const float4*>(base + hoff[it]);
+                else
+                    va[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            return;
+        }
+        vmask = 0;
+        if (d0 + TD <= p.D && h0 + TH <= p.H && w0 + TW <= p.W) {
+            const unsigned bface = (d0 == 0 ? 1u : 0u) | (d0 + TD == p.D ? 2u : 0u) | (h0 == 0 ? 4u : 0u) |
+                                   (h0 + TH == p.H ? 8u : 0u) | (w0 == 0 ? 16u : 0u) | (w0 + TW == p.W ? 32u : 0u);
+#pragma unroll
+            for (int it = 0; it < AITER; ++it) {
+                const bool ok = (fw[it / FPW] & (bface << (6 * (it % FPW)))) == 0u;
+                va[it] = *reinterpret_cast<const float4*>(base + (ok ? hoff[it] : safe_off));
+                vmask |= ok ? (1u << it) : 0u;
+            }
+            return;
+        }
+#pragma unroll
+        for (int it = 0; it < AITER; ++it) {
+            const int i = tid + it * NTHR, v = i >> 1;
+            const int pw = v % HW, t2 = v / HW, ph = t2 % HH, pd = t2 / HH;
+            const int gd = d0 + pd - 1, gh = h0 + ph - 1, gw = w0 + pw - 1;
+            const bool ok = i < AITEMS && (unsigned)gd < (unsigned)p.D && (unsigned)gh < (unsigned)p.H && (unsigned)gw < (unsigned)p.W;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) {
+                val = *reinterpret_cast<const float4*>(base + hoff[it]);
+                vmask |= 1u << it;
+            }
+            va[it] = val;
+        }
+    };
+    const bool w_full = (by + 1) * NT <= p.n16;
+    auto load_w = [&](int cc) {
+        const float* wsrc = p.wp + ((size_t)cc * 8 * p.n16 + (size_t)by * NT) * 128;
+#pragma unroll
+        for (int it = 0; it < WITER; ++it) {
+            const int i = (tid + it * NTHR) * 4;
+            const int ts = i / (NT * 128), r = i % (NT * 128);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (w_full || by * NT * 128 + r < p.n16 * 128)
+                v = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(wsrc) + (unsigned)(ts * p.n16 * 128 + r) * 4u);
+            vw[it] = v;
+        }
+    };
+    load_a(box, 0);
+    load_w(0);
+
+    while (true) {
+        __syncthreads();
+        {
+            auto put = [&](int it, float4 val) {
+                const int i = tid + it * NTHR;
+                if ((it + 1) * NTHR <= AITEMS || i < AITEMS) *reinterpret_cast<float4*>(&sA2[(i >> 1) * VS2 + half * 2]) = val;
+            };
+            if (a_interior) {
+#pragma unroll
+                for (int it = 0; it < AITER; ++it) put(it, va[it]);
+            } else {
+#pragma unroll
+                for (int it = 0; it < AITER; ++it) {
+                    const bool ok = (vmask >> it) & 1u;
+                    put(it, make_float4(ok ? va[it].x : 0.f, ok ? va[it].y : 0.f, ok ? va[it].z : 0.f, ok ? va[it].w : 0.f));
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < WITER; ++it) *reinterpret_cast<float4*>(&sW2[(tid + it * NTHR) * 2]) = vw[it];
+        }
+        __syncthreads();
+        // this chunk's parity -> origin of its 2x2x2 sub-cube in the halo: 1 - p per axis
+        const int par = c / qc;
+        lds_v2f_ptr vA = vA0 + (((1 - ((par >> 2) & 1)) * HH + (1 - ((par >> 1) & 1))) * HW + (1 - (par & 1))) * VS2;
+        int ntile = tile, nc = c + 1;
+        Box nbox = box;
+        if (nc == nchunk) { nc = 0; ntile = tile + 1; nbox = box_next(box); }
+        const bool has_next = ntile < tile_end;
+        if (has_next) {
+            load_a(nbox, nc);
+            load_w(nc);
+        }
+        {
+            v2f ar[2][5], br[2][2][NT];
+            auto load_group = [&](int g, v2f (&aa)[5], v2f (&bb)[2][NT]) {
+                const int ez = (g >> 1) & 1, ex = g & 1;
+#pragma unroll
+                for (int r = 0; r < 5; ++r) aa[r] = vA[((ez * HH + r) * HW + ex) * VS2];
+#pragma unroll
+                for (int ey = 0; ey < 2; ++ey)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) bb[ey][nt] = vW[(((ez * 2 + ey) * 2 + ex) * NT + nt) * 64];
+            };
+            load_group(0, ar[0], br[0]);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (g + 1 < 4) load_group(g + 1, ar[(g + 1) & 1], br[(g + 1) & 1]);
+                v2f (&aa)[5] = ar[g & 1];
+                v2f (&bb)[2][NT] = br[g & 1];
+#pragma unroll
+                for (int ey = 0; ey < 2; ++ey) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bb[ey][nt].x, aa[mt + ey].x, acc[mt][nt], 0, 0, 0);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bb[ey][nt].y, aa[mt + ey].y, acc[mt][nt], 0, 0, 0);
+                }
+            }
+        }
+        if (c == nchunk - 1) {
+            const int d0 = box.tz * TD, h0 = box.ty * TH, w0 = box.tx * TW;
+            const int gw = w0 + m;
+            float* obase = p.out + ((((size_t)box.n * p.D + d0 + wave) * p.H + h0) * p.W + gw) * p.out_cs;
+            const int orow = p.W * p.out_cs;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int co = (by * NT + nt) * 16 + kq * 4;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    if (co < p.cin_p && d0 + wave < p.D && h0 + mt < p.H && gw < p.W) {
+                        float4 o;
+                        o.x = acc[mt][nt][0]; o.y = acc[mt][nt][1]; o.z = acc[mt][nt][2]; o.w = acc[mt][nt][3];
+                        *reinterpret_cast<float4*>(obase + mt * orow + co) = o;
+                    }
+                    acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        }
+        if (!has_next) break;
+        tile = ntile; c = nc; box = nbox;
+    }
+}
+
+// data-gradient weights gathered from the forward packing: wpd[(p*qc + q)][e][n16][kq][n][j] = W_eff[p][tap = e ^ 7][pos][co],
+// pos = n16*16 + n (padded input-channel position), co = q*8 + kq*2 + j
+__global__ void upconv_pack_bwd_kernel(const float* __restrict__ wp, float* __restrict__ wpd, int cin_p, int nout_p) {
+    const int n16 = (cin_p + 15) >> 4, qc = nout_p >> 3, ntpt = (nout_p + 15) >> 4;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 8 * qc * 8 * n16 * 128) return;
+    int r = idx;
+    const int j = r & 1; r >>= 1;
+    const int n = r & 15; r >>= 4;
+    const int kq = r & 3; r >>= 2;
+    const int nt = r % n16; r /= n16;
+    const int e = r & 7; r >>= 3;
+    const int q = r % qc;
+    const int par = r / qc;
+    const int pos = nt * 16 + n, co = q * 8 + kq * 2 + j;
+    float v = 0.f;
+    if (pos < cin_p) {
+        const int cf = pos >> 3, kqf = (pos & 7) >> 1, jf = pos & 1;
+        v = wp[((((size_t)cf * 8 + par) * 8 + (e ^ 7)) * ntpt + (co >> 4)) * 128 + kqf * 32 + (co & 15) * 2 + jf];
+    }
+    wpd[idx] = v;
+}
+
 // ---- composite weights in fragment order: wp[chunk][parity][tap8 = (dz*2+dy)*2+dx][ntp][kq][n][j]
 // per axis: the (t, a) pairs behind (parity bit, tap bit): t = conv tap index 0..2, a = transposed-conv tap 0..1
 __device__ __forceinline__ int axis_pairs(int pbit, int jbit, int (&t)[2], int (&a)[2]) {
@@ -629,5 +885,43 @@ extern "C" int ctu_upconv_fused_project(const float* dweff, const float* gout, i
     const int total = (C * C * 8 + Co * C * 27 + C) * 8;
     upconv_project_kernel<<<ceil_div(total, 256), 256, 0, st>>>(dweff, V, wtt, w3t, bt, imap, C, Co, cin_p, nout_p, dwt, dw3, dbt);
     CTU_CHECK_LAUNCH("upconv_project");
+    return CTU_OK;
+}
+
+// ---- fused data gradient: gin (coarse) from the fine-grid gradient of the fused op's raw output
+extern "C" size_t ctu_upconv_fused_bwd_packed_floats(int cin_p, int nout_p) {
+    return (size_t)8 * (nout_p / 8) * 8 * ceil_div(cin_p, 16) * 128;
+}
+
+extern "C" int ctu_upconv_fused_pack_bwd(const float* wp, int cin_p, int nout_p, float* wpd, void* stream) {
+    CTU_REQUIRE(wp && wpd && cin_p % 8 == 0 && nout_p % 8 == 0, "upconv_fused_pack_bwd: bad argument");
+    const int total = (int)ctu_upconv_fused_bwd_packed_floats(cin_p, nout_p);
+    upconv_pack_bwd_kernel<<<ceil_div(total, 256), 256, 0, (hipStream_t)stream>>>(wp, wpd, cin_p, nout_p);
+    CTU_CHECK_LAUNCH("upconv_fused_pack_bwd");
+    return CTU_OK;
+}
+
+extern "C" int ctu_upconv_fused_bwd_data(const float* gout, int g_cs, int nout_p, const float* wpd, float* gin, int gin_cs,
+                                         int cin_p, int N, int D, int H, int W, void* stream) {
+    CTU_REQUIRE(gout && wpd && gin, "upconv_fused_bwd_data: null pointer");
+    CTU_REQUIRE(ctu_upconv_fused_supported(3, D, H, W, cin_p, nout_p), "upconv_fused_bwd_data: unsupported geometry");
+    CTU_REQUIRE(g_cs >= nout_p && g_cs % 4 == 0 && gin_cs >= cin_p && gin_cs % 4 == 0, "upconv_fused_bwd_data: bad stride");
+    CTU_REQUIRE(((uintptr_t)gout & 15) == 0 && ((uintptr_t)gin & 15) == 0 && ((uintptr_t)wpd & 15) == 0, "upconv_fused_bwd_data: alignment");
+    CTU_REQUIRE((int64_t)(12 * 2 * H + 12) * 2 * W * g_cs * 4 + 64 < (int64_t)1 << 31, "upconv_fused_bwd_data: volume too large for 32-bit offsets");
+    UpDP p;
+    p.g = gout; p.wp = wpd; p.out = gin; p.g_cs = g_cs; p.nout_p = nout_p; p.out_cs = gin_cs; p.cin_p = cin_p;
+    p.N = N; p.D = D; p.H = H; p.W = W;
+    p.tiles_d = ceil_div(D, 4); p.tiles_h = ceil_div(H, 4); p.tiles_w = ceil_div(W, 16);
+    p.n16 = ceil_div(cin_p, 16);
+    const int ntiles = N * p.tiles_d * p.tiles_h * p.tiles_w;
+    const int NT = p.n16 >= 4 ? 4 : (p.n16 >= 2 ? 2 : 1);
+    const int ny = ceil_div(p.n16, NT);
+    int gx, tpb;
+    up_grid(ntiles, ny, &gx, &tpb);
+    hipStream_t st = (hipStream_t)stream;
+    if (NT == 4) upconv_fused_bwd_data_kernel<4><<<dim3(gx, ny), 256, 0, st>>>(p, ntiles, tpb);
+    else if (NT == 2) upconv_fused_bwd_data_kernel<2><<<dim3(gx, ny), 256, 0, st>>>(p, ntiles, tpb);
+    else upconv_fused_bwd_data_kernel<1><<<dim3(gx, ny), 256, 0, st>>>(p, ntiles, tpb);
+    CTU_CHECK_LAUNCH("upconv_fused_bwd_data");
     return CTU_OK;
 }

@@ -80,6 +80,9 @@ SIGNATURES = {
     "ctu_upconv_fused_wgrad": (I, [P, I, I, P, P, I, P, I, I, P, P, I, I, I, I, P]),
     "ctu_upconv_fused_project_ws_floats": (Z, [I]),
     "ctu_upconv_fused_project": (I, [P, P, I, I, I, I, I, I, P, P, P, I, I, I, P, P, P, P, P]),
+    "ctu_upconv_fused_bwd_packed_floats": (Z, [I, I]),
+    "ctu_upconv_fused_pack_bwd": (I, [P, I, I, P, P]),
+    "ctu_upconv_fused_bwd_data": (I, [P, I, I, P, P, I, I, I, I, I, I, P]),
     "ctu_hard_segm": (I, [P, I, I, L, P, P]),
     "ctu_one_hot": (I, [P, I, I, L, P, P]),
     "ctu_hard_dice_ws_doubles": (Z, [I]),

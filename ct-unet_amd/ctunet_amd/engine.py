@@ -167,9 +167,10 @@ class UNetEngine:
         ver = tuple((t._version, t.data_ptr()) for t in (wt, bt, w3))
         hit = self._up_cache.get(prefix)
         if hit is None or hit[0] != ver or hit[3] != (x.cp, out.cp) or torch.cuda.is_current_stream_capturing():
-            into = (hit[1], hit[2], hit[4]) if hit is not None and hit[3] == (x.cp, out.cp) else None
-            wp, beff, pws = ops.upconv_fused_pack(wt, bt, w3, cinv, x.cp, out.cp, into)
-            self._up_cache[prefix] = (ver, wp, beff, (x.cp, out.cp), pws)
+            same = hit is not None and hit[3] == (x.cp, out.cp)
+            wp, beff, pws = ops.upconv_fused_pack(wt, bt, w3, cinv, x.cp, out.cp, (hit[1], hit[2], hit[4]) if same else None)
+            wpd = ops.upconv_fused_pack_bwd(wp, x.cp, out.cp, hit[5] if same else None)      # same weights, data-gradient order
+            self._up_cache[prefix] = (ver, wp, beff, (x.cp, out.cp), pws, wpd)
         else:
             wp, beff = hit[1], hit[2]
         nvox = 8 * x.nvox
@@ -308,7 +309,6 @@ class UNetEngine:
             ctp = pad8(ct)
             imap_t, cinv_t = self._maps(cur_segs, cur.cp, dev)
             wt = P[f"{blk.prefix}.0.weight"]
-            wpt = self._packed(f"{blk.prefix}.0", wt, "convt", cinv_t, cur.cp, ctp, 0)
             dec_in.append(cur)
             t1 = CL(torch.empty((n, dd, hh, ww, cp), dtype=torch.float32, device=dev), 0, cp)
             v1 = torch.empty((4, cp), dtype=torch.float32, device=dev)
@@ -318,6 +318,7 @@ class UNetEngine:
                                                             n_upd, save)
             else:
                 up = CL(torch.empty((n, dd, hh, ww, ctp), dtype=torch.float32, device=dev), 0, ctp)
+                wpt = self._packed(f"{blk.prefix}.0", wt, "convt", cinv_t, cur.cp, ctp, 0)
                 ops.convt_fwd(cur, wpt, P[f"{blk.prefix}.0.bias"].detach(), up)
                 ups.append(up)
                 a1, recs[(blk.prefix, 1)] = self._conv_bn(P, up, f"{blk.prefix}.1", f"{blk.prefix}.2", ct, blk.cout, None,
@@ -453,25 +454,28 @@ class UNetEngine:
             imap_t, cinv_t = self._maps(segs, x_in.cp, dev)
             wt = P[f"{blk.prefix}.0.weight"]
             up = ctx["ups"][j]
-            ctp = pad8(ct)
-            g_up = CL(torch.empty(r1.y.dims + (ctp,), dtype=torch.float32, device=dev), 0, ctp)
-            self._conv_bn_bwd(P, r1, g_u1, g_up, grads, ws, part)      # BN backward, (conv wgrad,) conv data gradient
-            if up is None:
-                # ConvTranspose3d -> Conv3d ran fused (the transposed conv's output was never written): the gradients of
-                # BOTH layers' parameters come from the composite-weight gradient of the coarse input and g_u1
-                dwt, dbt, dw3 = ops.upconv_fused_wgrad(x_in, g_u1, ct, blk.cout, P[f"{blk.prefix}.0.bias"],
-                                                       self._up_cache[blk.prefix][4], imap_t)
-                grads[f"{blk.prefix}.1.weight"] = dw3
-            else:
-                dwt, dbt = ops.convt_wgrad(x_in, g_up, ct, ct, imap_t, ws)
-            grads[f"{blk.prefix}.0.weight"], grads[f"{blk.prefix}.0.bias"] = dwt, dbt
-            wpd = self._packed(f"{blk.prefix}.0", wt, "convt", cinv_t, g_up.cp, x_in.cp, 1)
             if j > 0:
                 gin = g_skip_target(i + 1)
             else:
                 gin = CL(torch.empty_like(x_in.buf), 0, x_in.cp)
                 g_deep = gin
-            ops.convt_bwd_data(g_up, wpd, gin)
+            if up is None:
+                # ConvTranspose3d -> Conv3d ran fused (the transposed conv's output never existed): BatchNorm backward,
+                # then the gradients of BOTH layers' parameters from the composite-weight gradient of (coarse input, g_u1)
+                # and the data gradient straight back to the coarse grid
+                self._conv_bn_bwd(P, r1, g_u1, None, grads, ws, part)
+                dwt, dbt, dw3 = ops.upconv_fused_wgrad(x_in, g_u1, ct, blk.cout, P[f"{blk.prefix}.0.bias"],
+                                                       self._up_cache[blk.prefix][4], imap_t)
+                grads[f"{blk.prefix}.1.weight"] = dw3
+                grads[f"{blk.prefix}.0.weight"], grads[f"{blk.prefix}.0.bias"] = dwt, dbt
+                ops.upconv_fused_bwd_data(g_u1, self._up_cache[blk.prefix][5], gin, (ct, blk.cout))
+            else:
+                g_up = CL(torch.empty_like(up.buf), 0, up.cp)
+                self._conv_bn_bwd(P, r1, g_u1, g_up, grads, ws, part)
+                dwt, dbt = ops.convt_wgrad(x_in, g_up, ct, ct, imap_t, ws)
+                grads[f"{blk.prefix}.0.weight"], grads[f"{blk.prefix}.0.bias"] = dwt, dbt
+                wpd = self._packed(f"{blk.prefix}.0", wt, "convt", cinv_t, g_up.cp, x_in.cp, 1)
+                ops.convt_bwd_data(g_up, wpd, gin)
             if j > 0:
                 g_skip_fanout(i + 1)
             emit()

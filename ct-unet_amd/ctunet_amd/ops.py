@@ -587,6 +587,29 @@ def upconv_fused_wgrad(x: CL, g: CL, c: int, co: int, bt: torch.Tensor, pack_ws:
     return dwt, dbt, dw3
 
 
+def upconv_fused_pack_bwd(wp: torch.Tensor, cin_p: int, nout_p: int, into: Optional[torch.Tensor] = None) -> torch.Tensor:
+    lib = _lib.load()
+    wpd = into if into is not None else torch.empty(lib.ctu_upconv_fused_bwd_packed_floats(cin_p, nout_p),
+                                                     dtype=torch.float32, device=wp.device)
+    _lib.check(lib.ctu_upconv_fused_pack_bwd(wp.data_ptr(), cin_p, nout_p, wpd.data_ptr(), _stream()), "upconv_fused_pack_bwd")
+    return wpd
+
+
+def upconv_fused_bwd_data(g: CL, wpd: torch.Tensor, gin: CL, algo_ch: Optional[Tuple[int, int]] = None) -> None:
+    """gin (coarse) <- gradient of the fused ConvTranspose3d -> Conv3d pair w.r.t. its (activated) input."""
+    n, d, h, w = gin.dims
+    assert g.dims == (n, 2 * d, 2 * h, 2 * w)
+    lib = _lib.load()
+    t0 = TIMER.begin() if TIMER is not None else None
+    _lib.check(lib.ctu_upconv_fused_bwd_data(g.ptr, g.cs, g.cp, wpd.data_ptr(), gin.ptr, gin.cs, gin.cp, n, d, h, w, _stream()),
+               "upconv_fused_bwd_data")
+    if t0 is not None:
+        ci, co = algo_ch if algo_ch is not None else (gin.cp, g.cp)
+        vox = n * d * h * w
+        TIMER.end(f"upconv_fused_bwd_data_kernel<{g.cp}>", vox * (16.0 * ci * ci + 8 * 54.0 * ci * co), 4.0 * vox * (ci + 8 * co),
+                  t0, (w, gin.cp, g.cp))
+
+
 # ---------------------------------------------------------------------------- inference tail / sample schema
 def _ncv(t: torch.Tensor):
     """(N, C, V) of a contiguous fp32 NCDHW (5-D) or CDHW (4-D) CUDA map."""

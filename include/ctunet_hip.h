@@ -297,6 +297,14 @@ int ctu_upconv_fused_project(const float* dweff, const float* gout, int g_cs, in
                              const float* bt, const float* pack_ws, const int32_t* imap, int C, int Co, int cin_p,
                              float* dwt, float* dbt, float* dw3, float* ws, void* stream);
 
+/* Data gradient of the fused up-convolution: gin (COARSE, [N,D,H,W,gin_cs], cin_p padded channels in the input's
+ * layout) from gout (fine grid, gradient of the raw output) -- the adjoint parity convolutions, no fine-grid
+ * intermediate.  wpd = ctu_upconv_fused_pack_bwd(wp): the forward packing re-gathered for the transposed product. */
+size_t ctu_upconv_fused_bwd_packed_floats(int cin_p, int nout_p);
+int ctu_upconv_fused_pack_bwd(const float* wp, int cin_p, int nout_p, float* wpd, void* stream);
+int ctu_upconv_fused_bwd_data(const float* gout, int g_cs, int nout_p, const float* wpd, float* gin, int gin_cs,
+                              int cin_p, int N, int D, int H, int W, void* stream);
+
 /* -------------------------------------------------- inference tail / sample schema ---- */
 /* hard_segm_from_tensor (/root/reference/ctunet/utilities.py:103-124): seg[n,v] = (float)argmax_c prob[n,c,v] over an
  * NCDHW map; the first maximum wins (torch.argmax). */

@@ -571,3 +571,46 @@ def test_upconv_fused_wgrad(c, co, dims, segs):
     for name, got, want in (("dWT", dwt, wt64.grad), ("dbT", dbt, bt64.grad), ("dW3", dw3, w364.grad)):
         err = (got.cpu().double() - want).abs().max().item()
         assert err <= 2e-4 * want.abs().max().item(), (name, err, want.abs().max().item())
+
+
+@pytest.mark.parametrize("c,co,dims,segs", [
+    (8, 8, (1, 4, 4, 16), None),
+    (16, 8, (2, 8, 4, 32), None),
+    (24, 16, (1, 4, 8, 16), ((12, 0), (12, 16))),
+    (32, 8, (1, 6, 5, 20), None),
+    (64, 16, (1, 4, 4, 16), None),
+    (16, 32, (1, 4, 4, 16), None),
+])
+def test_upconv_fused_bwd_data(c, co, dims, segs):
+    """Gradient of ConvTranspose3d -> Conv3d w.r.t. the transposed conv's input as one coarse-grid kernel (the adjoint
+    parity convolutions over a strided view of the fine-grid gradient) vs torch autograd of the two ops in fp64;
+    2e-4 of the gradient's scale."""
+    ops = _ops()
+    n, d, h, w = dims
+    cop = ops.pad8(co)
+    wt = (torch.randn(c, c, 2, 2, 2, generator=g(42)) * 0.2)
+    bt = torch.randn(c, generator=g(43))
+    w3 = (torch.randn(co, c, 3, 3, 3, generator=g(44)) * 0.1)
+    dy = torch.randn(n, co, 2 * d, 2 * h, 2 * w, generator=g(45))
+    xa = torch.randn(n, c, d, h, w, generator=g(41)).double().requires_grad_(True)
+    F.conv3d(F.conv_transpose3d(xa, wt.double(), bt.double(), stride=2), w3.double(), padding=1).backward(dy.double())
+    if segs is None:
+        cp, cinv, pos = ops.pad8(c), None, list(range(c))
+    else:
+        cp, cinv_l, pos, lo = 32, [-1] * 32, [], 0
+        for cnt, start in segs:
+            for q in range(cnt):
+                cinv_l[start + q] = lo + q
+                pos.append(start + q)
+            lo += cnt
+        cinv = torch.tensor(cinv_l, dtype=torch.int32, device="cuda")
+    wp, _, _ = ops.upconv_fused_pack(wt.cuda(), bt.cuda(), w3.cuda(), cinv, cp, cop)
+    wpd = ops.upconv_fused_pack_bwd(wp, cp, cop)
+    gin = ops.CL(torch.full((n, d, h, w, cp), float("nan"), device="cuda"), 0, cp)
+    ops.upconv_fused_bwd_data(to_cl(dy), wpd, gin)
+    got = gin.buf.cpu()[..., pos].permute(0, 4, 1, 2, 3).double()
+    err = (got - xa.grad).abs().max().item()
+    assert err <= 2e-4 * xa.grad.abs().max().item(), (err, xa.grad.abs().max().item())
+    rest = [q for q in range(cp) if q not in pos]
+    if rest:
+        assert torch.equal(gin.buf.cpu()[..., rest], torch.zeros(n, d, h, w, len(rest)))      # padding positions get zeros
