@@ -669,11 +669,11 @@ __global__ __launch_bounds__(1024) void upconv_beff_kernel(const float* __restri
 //   dbT[cm]      = sum_t sum_co V[t][co] W3[co,cm,t]
 // V[t][co] = sum of dy over the fine voxels whose conv tap t lies inside the volume (per axis: t=0 excludes the first
 // plane, t=2 the last) -- built from 27 box sums T[sel] (each axis: all / first plane / last plane).
-constexpr int FS_SPLIT = 64;
+constexpr int FS_SPLIT = 16;      // blocks per face / edge / corner selection (the full-volume sum goes through ctu_channel_sum)
 
 __global__ __launch_bounds__(256) void upconv_face_sums_kernel(const float* __restrict__ dy, int cs, int cp, int N, int Df, int Hf,
                                                                int Wf, float* __restrict__ tpart) {
-    const int sel = blockIdx.x;                                   // (sz*3 + sy)*3 + sx, 0 all / 1 first / 2 last
+    const int sel = blockIdx.x + 1;                               // (sz*3 + sy)*3 + sx, 0 all / 1 first / 2 last; sel 0 is not computed here
     const int sz = sel / 9, sy = (sel / 3) % 3, sx = sel % 3;
     const int nz = sz ? 1 : Df, ny = sy ? 1 : Hf, nx = sx ? 1 : Wf;
     const int z0 = sz == 2 ? Df - 1 : 0, y0 = sy == 2 ? Hf - 1 : 0, x0 = sx == 2 ? Wf - 1 : 0;
@@ -705,7 +705,7 @@ __global__ __launch_bounds__(256) void upconv_face_sums_kernel(const float* __re
         *reinterpret_cast<float4*>(tpart + ((size_t)sel * FS_SPLIT + blockIdx.y) * cp + threadIdx.x * 4) = red[threadIdx.x];
 }
 
-__global__ void upconv_v_kernel(const float* __restrict__ tpart, int cp, float* __restrict__ V) {
+__global__ void upconv_v_kernel(const float* __restrict__ tpart, const float* __restrict__ tall, int cp, float* __restrict__ V) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= 27 * cp) return;
     const int co = idx % cp, t = idx / cp;
@@ -717,9 +717,14 @@ __global__ void upconv_v_kernel(const float* __restrict__ tpart, int cp, float* 
             for (int ix = 0; ix < (tx == 1 ? 1 : 2); ++ix) {
                 const int sz = iz == 0 ? 0 : (tz == 0 ? 1 : 2), sy = iy == 0 ? 0 : (ty == 0 ? 1 : 2), sx = ix == 0 ? 0 : (tx == 0 ? 1 : 2);
                 const float sign = ((iz + iy + ix) & 1) ? -1.f : 1.f;
-                const float* src = tpart + (size_t)((sz * 3 + sy) * 3 + sx) * FS_SPLIT * cp + co;
+                const int sel = (sz * 3 + sy) * 3 + sx;
                 float s = 0.f;
-                for (int b = 0; b < FS_SPLIT; ++b) s += src[(size_t)b * cp];          // fixed order
+                if (sel == 0) {
+                    s = tall[co];
+                } else {
+                    const float* src = tpart + (size_t)sel * FS_SPLIT * cp + co;
+                    for (int b = 0; b < FS_SPLIT; ++b) s += src[(size_t)b * cp];      // fixed order
+                }
                 v += sign * s;
             }
     V[idx] = v;
@@ -753,19 +758,30 @@ __global__ void upconv_project_kernel(const float* __restrict__ dweff, const flo
     if (idx < n1) {                                               // dWT[ci][cm][a]
         const int a = idx & 7, cm = (idx >> 3) % C, ci = idx / (8 * C);
         const int pos = imap ? imap[ci] : ci;
-        for (int t = sub; t < 27; t += 8) {
-            const float* g = dweff + ((size_t)weff_index(t, a) * cin_p + pos) * nout_p;
-            const float* w = w3t + ((size_t)t * C + cm) * nout_p;
-            for (int co = 0; co < Co; ++co) v = fmaf(g[co], w[co], v);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                              // t = sub, sub + 8, sub + 16, sub + 24: independent chains
+            const int t = sub + 8 * k;
+            if (t < 27) {
+                const float* g = dweff + ((size_t)weff_index(t, a) * cin_p + pos) * nout_p;
+                const float* w = w3t + ((size_t)t * C + cm) * nout_p;
+                float s = 0.f;
+#pragma unroll 8
+                for (int co = 0; co < Co; ++co) s = fmaf(g[co], w[co], s);
+                v += s;
+            }
         }
         dst = dwt + idx;
     } else if (idx < n1 + n2) {                                   // dW3[co][cm][t]
         const int k = idx - n1;
         const int t = k % 27, cm = (k / 27) % C, co = k / (27 * C);
-        for (int a = 0; a < 8; ++a) {
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {                              // 8 independent chains
             const float* g = dweff + (size_t)weff_index(t, a) * cin_p * nout_p + co;
             const float* w = wtt + (size_t)a * C * C + cm;
-            for (int ci = sub; ci < C; ci += 8) v = fmaf(g[(size_t)(imap ? imap[ci] : ci) * nout_p], w[(size_t)ci * C], v);
+            float s = 0.f;
+#pragma unroll 4
+            for (int ci = sub; ci < C; ci += 8) s = fmaf(g[(size_t)(imap ? imap[ci] : ci) * nout_p], w[(size_t)ci * C], s);
+            v += s;
         }
         if (sub == 0) v = fmaf(V[t * nout_p + co], bt[cm], v);
         dst = dw3 + k;
@@ -862,7 +878,12 @@ extern "C" int ctu_upconv_fused_fwd(const float* in, int in_cs, int cin_p, const
     return CTU_OK;
 }
 
-extern "C" size_t ctu_upconv_fused_project_ws_floats(int nout_p) { return (size_t)27 * FS_SPLIT * nout_p + (size_t)27 * nout_p; }
+extern "C" int ctu_channel_sum_num_blocks(int64_t nvox);
+extern "C" int ctu_channel_sum(const float* x, int cs, int cp, int64_t nvox, float* partials, float* out, int C, void* stream);
+
+extern "C" size_t ctu_upconv_fused_project_ws_floats(int nout_p, int64_t fine_nvox) {
+    return (size_t)27 * FS_SPLIT * nout_p + (size_t)27 * nout_p + nout_p + (size_t)ctu_channel_sum_num_blocks(fine_nvox) * nout_p;
+}
 
 // dweff: [8][8][cin_p][nout_p] from ctu_upconv_fused_wgrad; gout: fine-grid gradient w.r.t. the fused op's RAW output
 // [N,2D,2H,2W,g_cs]; pack_ws: the scratch ctu_upconv_fused_pack filled this step (transposed weights); imap: logical input
@@ -876,9 +897,14 @@ extern "C" int ctu_upconv_fused_project(const float* dweff, const float* gout, i
     hipStream_t st = (hipStream_t)stream;
     float* tpart = ws;
     float* V = ws + (size_t)27 * FS_SPLIT * nout_p;
-    upconv_face_sums_kernel<<<dim3(27, FS_SPLIT), 256, 0, st>>>(gout, g_cs, nout_p, N, 2 * D, 2 * H, 2 * W, tpart);
+    float* tall = V + (size_t)27 * nout_p;
+    float* csp = tall + nout_p;
+    const int64_t fvox = (int64_t)N * 8 * D * H * W;
+    int rc = ctu_channel_sum(gout, g_cs, nout_p, fvox, csp, tall, nout_p, stream);          // full-volume sum per channel
+    if (rc != CTU_OK) return rc;
+    upconv_face_sums_kernel<<<dim3(26, FS_SPLIT), 256, 0, st>>>(gout, g_cs, nout_p, N, 2 * D, 2 * H, 2 * W, tpart);
     CTU_CHECK_LAUNCH("upconv_face_sums");
-    upconv_v_kernel<<<ceil_div(27 * nout_p, 256), 256, 0, st>>>(tpart, nout_p, V);
+    upconv_v_kernel<<<ceil_div(27 * nout_p, 64), 64, 0, st>>>(tpart, tall, nout_p, V);
     CTU_CHECK_LAUNCH("upconv_v");
     const float* w3t = pack_ws;
     const float* wtt = pack_ws + (size_t)27 * C * nout_p;

@@ -78,7 +78,7 @@ SIGNATURES = {
     "ctu_upconv_fused_fwd": (I, [P, I, I, P, P, I, P, P, P, I, I, P, I, I, I, I, P]),
     "ctu_upconv_fused_wgrad_ws_floats": (Z, [I, I, I, I, I, I]),
     "ctu_upconv_fused_wgrad": (I, [P, I, I, P, P, I, P, I, I, P, P, I, I, I, I, P]),
-    "ctu_upconv_fused_project_ws_floats": (Z, [I]),
+    "ctu_upconv_fused_project_ws_floats": (Z, [I, L]),
     "ctu_upconv_fused_project": (I, [P, P, I, I, I, I, I, I, P, P, P, I, I, I, P, P, P, P, P]),
     "ctu_upconv_fused_bwd_packed_floats": (Z, [I, I]),
     "ctu_upconv_fused_pack_bwd": (I, [P, I, I, P, P]),

@@ -580,7 +580,7 @@ def upconv_fused_wgrad(x: CL, g: CL, c: int, co: int, bt: torch.Tensor, pack_ws:
     dwt = torch.empty((c, c, 2, 2, 2), dtype=torch.float32, device=dev)
     dbt = torch.empty(c, dtype=torch.float32, device=dev)
     dw3 = torch.empty((co, c, 3, 3, 3), dtype=torch.float32, device=dev)
-    ws2 = torch.empty(lib.ctu_upconv_fused_project_ws_floats(g.cp), dtype=torch.float32, device=dev)
+    ws2 = torch.empty(lib.ctu_upconv_fused_project_ws_floats(g.cp, g.nvox), dtype=torch.float32, device=dev)
     _lib.check(lib.ctu_upconv_fused_project(dweff.data_ptr(), g.ptr, g.cs, g.cp, n, d, h, w, bt.detach().data_ptr(),
                                             pack_ws.data_ptr(), _ptr(imap), c, co, x.cp, dwt.data_ptr(), dbt.data_ptr(),
                                             dw3.data_ptr(), ws2.data_ptr(), _stream()), "upconv_fused_project")

@@ -292,7 +292,7 @@ size_t ctu_upconv_fused_wgrad_ws_floats(int N, int D, int H, int W, int cin_p, i
 int ctu_upconv_fused_wgrad(const float* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
                            int in_relu, const float* gout, int g_cs, int nout_p, float* dweff, float* ws,
                            int N, int D, int H, int W, void* stream);
-size_t ctu_upconv_fused_project_ws_floats(int nout_p);
+size_t ctu_upconv_fused_project_ws_floats(int nout_p, int64_t fine_nvox);
 int ctu_upconv_fused_project(const float* dweff, const float* gout, int g_cs, int nout_p, int N, int D, int H, int W,
                              const float* bt, const float* pack_ws, const int32_t* imap, int C, int Co, int cin_p,
                              float* dwt, float* dbt, float* dw3, float* ws, void* stream);
