@@ -30,6 +30,7 @@ from .ops import CL, pad8
 BN_EPS = 1e-5
 # decoder ConvTranspose3d -> Conv3d pairs run as one coarse-grid kernel (CTUNET_FUSE_UP=0: the two separate kernels)
 FUSE_UP = os.environ.get("CTUNET_FUSE_UP", "1") != "0"
+FUSE_UP_MAX_CO = int(os.environ.get("CTUNET_FUSE_UP_MAXCO", "16"))     # widest (padded) conv output that takes the fused path
 BN_MOMENTUM = 0.1
 
 
@@ -155,7 +156,7 @@ class UNetEngine:
     def _fuse_up(self, x: CL, nout_p: int) -> bool:
         """Run ConvTranspose3d -> Conv3d of a decoder block as one coarse-grid kernel (ops.upconv_fused_fwd)?
         Levels whose first conv has at most 16 (padded) output channels: they hold the FLOPs and have enough boxes."""
-        return (self.plan.k == 3 and not self.plan.conv_bias and nout_p <= 16 and FUSE_UP
+        return (self.plan.k == 3 and not self.plan.conv_bias and nout_p <= FUSE_UP_MAX_CO and FUSE_UP
                 and ops.upconv_fused_supported(x.dims, 3, x.cp, nout_p))
 
     def _upconv_bn(self, P, x: CL, prefix: str, ct: int, cout: int, cinv, out: CL, vec4: torch.Tensor, training: bool,
