@@ -243,7 +243,10 @@ def main():
                 kernels[tag] = {"launches_per_step": d["launches"] / timer_steps, "avg_ms": round(d["avg_ms"], 4),
                                 "ms_per_step": round(d["total_ms"] / timer_steps, 3),
                                 "achieved_tflops": round(d["flops"] / (d["total_ms"] * 1e-3) / 1e12, 2)}
-            dom = max(summ.items(), key=lambda kv: kv[1]["total_ms"])
+            # dominant kernel for the roofline leg: largest share of the step among the kernels whose algorithmic FLOPs are
+            # the FLOPs they execute (the fused up-convolution symbols are credited with the two layers they replace)
+            plain = {k: v for k, v in summ.items() if not k.startswith("upconv_fused")}
+            dom = max((plain or summ).items(), key=lambda kv: kv[1]["total_ms"])
             ach = dom[1]["flops"] / (dom[1]["total_ms"] * 1e-3) / 1e12
             roofline = {"kernel": dom[0], "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
                         "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
@@ -263,7 +266,11 @@ def main():
                        "patch": args.size, "per_gpu_batch": 1, "parallelism": f"dp{world}", "launch": mode,
                        "whole_step_tflops_algorithmic": round(FLOP_PER_VOXEL_FWD_BWD * value / 1e12, 2),
                        "whole_step_frac_of_mfma_peak": round(FLOP_PER_VOXEL_FWD_BWD * value / world / 1e12 /
-                                                             PEAK_FP32_MFMA_TFLOPS, 4)},
+                                                             PEAK_FP32_MFMA_TFLOPS, 4),
+                       "flop_accounting": "algorithmic = the reference's layers (SURVEY 8d); the fused decoder "
+                                          "up-convolution kernels (upconv_fused_*) execute 3.9x fewer multiply-adds than the "
+                                          "ConvTranspose3d + Conv3d pair they are credited with, so their TFLOP/s can exceed "
+                                          "the MFMA peak; the roofline kernel is chosen among the unfused convolutions"},
             "roofline": roofline, "kernels": kernels,
         }
         if world == 1 and not args.no_cpu_baseline:
