@@ -108,6 +108,9 @@ class UNetEngine:
         return wp
 
     def refresh_packs(self, P: Dict[str, torch.Tensor]) -> None:
+        # under graph capture every copy is re-packed unconditionally: the replayed graph must refresh them after each
+        # optimizer step, whether or not the weights happened to change between the last warm-up step and the capture
+        force = P and next(iter(P.values())).is_cuda and torch.cuda.is_current_stream_capturing()
         jobs = []
         for key, ent in self._pack_cache.items():
             name, kind, mode, rin_p, nout_p, layout = key
@@ -115,7 +118,7 @@ class UNetEngine:
             if w is None or w.device != ent[1].device:
                 continue
             ver = (w._version, w.data_ptr())
-            if ent[0] != ver:
+            if force or ent[0] != ver:
                 jobs.append((kind, w.detach().contiguous(), ent[1], ent[2], rin_p, nout_p, mode, layout))
                 self._pack_cache[key] = (ver, ent[1], ent[2])
         ops.pack_batch(jobs)

@@ -4,10 +4,11 @@ launch-bound inner loops in hipGraphs").
 
 The step is the reference's ``Model.forward_pass`` train branch (ctunet/pytorch/Model.py:343-374) minus its
 host round trips: the per-term ``float(loss)`` syncs become ONE device->host copy after the replay.
-With ``process_group`` set (one process per GPU) the captured graph holds forward + loss + backward only;
-the gradient mean over ranks (one flat RCCL all-reduce, 3.3 MB for UNet()) and the optimizer step are
-launched eagerly after each replay -- no collective is ever captured.  The bucketed, backward-overlapped
-``parallel.GradSync`` path remains the eager alternative.
+With ``distributed`` set (one process per GPU) the step is TWO graphs around one eagerly launched collective:
+graph 1 = forward + loss + backward + flattening of the live gradients into one static buffer; then the gradient
+sum over ranks (one flat RCCL all-reduce, 3.3 MB for UNet()) -- no collective is ever captured --; graph 2 = scale
+by 1/world + the fused optimizer step reading the gradients straight from the flat buffer.  The bucketed,
+backward-overlapped ``parallel.GradSync`` path remains the eager alternative.
 """
 from __future__ import annotations
 
@@ -38,19 +39,30 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
+        if distributed:
+            import torch.distributed as dist
+            self.world = dist.get_world_size(process_group)
         with torch.cuda.stream(side):
             for _ in range(warmup):
                 self._step()
+                if distributed:
+                    self._eager_reduce_step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         with torch.cuda.graph(self.graph):
             self.values = self._step()
         self.keys = self._keys()
         if distributed:
-            import torch.distributed as dist
-            self.world = dist.get_world_size(process_group)
-            self.live = [p for p in model.parameters() if p.grad is not None]     # static .grad tensors of the graph
-            self.sizes = [p.grad.numel() for p in self.live]
+            if warmup == 0:                                   # the optimizer state must exist before graph 2 is captured
+                self.graph.replay()
+                self._eager_reduce_step()
+                torch.cuda.synchronize()
+            # graph 2: the optimizer reads its gradients from views of the static flat buffer graph 1 fills
+            for p, v in zip(self._live, self.flat.split([p.numel() for p in self._live])):
+                p.grad = v.view_as(p)
+            self.graph2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph2):
+                self._scale_and_step()
 
     def _keys(self) -> List[str]:
         k: List[str] = []
@@ -90,16 +102,28 @@ class GraphedTrainStep:
             self.opt.step()
             for p in self.model.parameters():
                 p.grad = None
+        else:
+            # every live gradient into one flat buffer (static once captured); grads are left to the next backward,
+            # which overwrites them (parameters the graph never touches keep .grad None on every rank)
+            self._live = [p for p in self.model.parameters() if p.grad is not None]
+            self.flat = torch.cat([p.grad.reshape(-1) for p in self._live])
+            for p in self._live:
+                p.grad = None
         return torch.stack([t.detach() for t in terms] + [loss.detach()])
 
-    def _reduce_and_step(self) -> None:
-        import torch.distributed as dist
-        grads = [p.grad for p in self.live]
-        flat = torch.cat([g.reshape(-1) for g in grads])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-        flat.mul_(1.0 / self.world)
-        torch._foreach_copy_(grads, [c.view_as(g) for c, g in zip(flat.split(self.sizes), grads)])
+    def _scale_and_step(self) -> None:
+        self.flat.mul_(1.0 / self.world)
         self.opt.step()
+
+    def _eager_reduce_step(self) -> None:
+        """One eagerly launched all-reduce + optimizer step on the flat buffer the last _step() produced."""
+        import torch.distributed as dist
+        for p, v in zip(self._live, self.flat.split([p.numel() for p in self._live])):
+            p.grad = v.view_as(p)
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        self._scale_and_step()
+        for p in self._live:
+            p.grad = None
 
     def __call__(self, x: Optional[torch.Tensor] = None, targets: Optional[Sequence[torch.Tensor]] = None) -> torch.Tensor:
         """Copies the batch into the captured buffers, replays the step, returns the loss terms (device tensor,
@@ -111,5 +135,7 @@ class GraphedTrainStep:
                 dst.copy_(src)
         self.graph.replay()
         if self.distributed:
-            self._reduce_and_step()
+            import torch.distributed as dist
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            self.graph2.replay()
         return self.values

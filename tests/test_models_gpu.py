@@ -414,3 +414,46 @@ def test_fused_adam_training_trajectory_matches_torch_adam():
     a, b = run(True), run(False)
     assert a[0] == b[0] and a[3] < a[0]
     assert all(abs(u - v) < 2e-5 for u, v in zip(a, b)), (a, b)
+
+
+def test_distributed_graphed_step_one_rank_equals_eager():
+    """The N > 1 form of GraphedTrainStep (graph 1: forward + backward + gradient flattening; eager RCCL all-reduce;
+    graph 2: scale + fused Adam reading the flat buffer) on a 1-rank RCCL group follows the eagerly launched steps --
+    including the re-packing of the MFMA-ordered weight copies inside graph 1 after every optimizer step."""
+    import torch.distributed as dist
+    A, M, L, PH = _mods()
+    from ctunet_amd.graph import GraphedTrainStep
+    from ctunet_amd import optim as O2
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1,
+                                device_id=torch.device("cuda", 0))
+    try:
+        x = torch.randn(1, 1, 32, 32, 32, generator=gen(5)).cuda()
+        tg = [onehot_target((1, 2, 32, 32, 32), 12, 0.2).cuda()]
+
+        def make():
+            torch.manual_seed(0)
+            net = A.UNet(n_blocks=2, use_checkpoint=True).cuda().train()
+            return net, O2.Adam(net.parameters(), lr=1e-2, amsgrad=True)
+        net_e, opt_e = make()
+        losses_e = []
+        for _ in range(3 + 3):                  # 3 eager warm-up steps inside GraphedTrainStep, then 3 replays
+            h = Holder(1.0, 1.0)
+            out = net_e(x.clone().requires_grad_(True))
+            PH.ProblemHandler.comp_losses_metrics(h, out, tg[0], 0, 1)
+            h.pt_loss.backward()
+            opt_e.step()
+            for p in net_e.parameters():
+                p.grad = None
+            losses_e.append(h.pt_loss.item())
+        net_g, opt_g = make()
+        gs = GraphedTrainStep(net_g, opt_g, x, tg, 1.0, 1.0, warmup=3, distributed=True)
+        got = [gs(x, tg).tolist()[-1] for _ in range(3)]
+        assert all(abs(a - b) < 2e-5 for a, b in zip(got, losses_e[3:6])), (got, losses_e)
+        assert got[2] < got[0]
+        for (n_, a), (_, b) in zip(net_e.state_dict().items(), net_g.state_dict().items()):
+            if "num_batches_tracked" in n_:
+                continue                                    # (the capture pass itself does not execute)
+            assert torch.allclose(a.float(), b.float(), rtol=2e-3, atol=1e-5), n_
+    finally:
+        dist.destroy_process_group()
