@@ -28,7 +28,7 @@ Workload: `bench.py` default — `UNet()` (1 in, 2 out, i_size 8, 4 blocks), one
 | run | ms/step | voxels/s | note |
 |---|---|---|---|
 | `python bench.py` (defaults: 20 steps, 5 warm-up, HIP graph) | {d['ms_per_step']:.2f} | {d['value'] / 1e6:.1f} M | `r01_bench_default.json` (the JSON line as printed) |
-| same under `python -m torch.distributed.run --nproc-per-node 1 … bench.py --gpus 1` (RCCL communicator, flat all-reduce, eager fused Adam) | {float(sys.argv[1]):.2f} | {float(sys.argv[2]):.1f} M | the N>1 code path on one rank |
+| same under `python -m torch.distributed.run --nproc-per-node 1 … bench.py --gpus 1` (RCCL communicator; graph 1 → flat all-reduce → graph 2 with the fused Adam) | {float(sys.argv[1]):.2f} | {float(sys.argv[2]):.1f} M | the N>1 code path on one rank |
 | CPU oracle (ATen-CPU fp32, {cb['cores']} granted cores of the GPU box, no checkpoint recompute) | {1e3 * 2097152 / cb['value']:.0f} | {cb['value'] / 1e6:.2f} M | `cpu_baseline`, kind "port"; Dice of the HIP path's hard segmentation vs the oracle's on identical weights/input: {cb['dice_vs_cpu_ref']:.7f}, max rel. output error {cb['max_rel_output_err']:.1e} |
 
 Algorithmic work (SURVEY §8d): 271.7 GFLOP per step ⇒ **{271.7 / d['ms_per_step']:.1f} TFLOP/s whole-step = {271.7 / d['ms_per_step'] / 157.3:.2f} of the 157.3 TF
