@@ -457,3 +457,34 @@ def test_distributed_graphed_step_one_rank_equals_eager():
             assert torch.allclose(a.float(), b.float(), rtol=2e-3, atol=1e-5), n_
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("ini", ["examples/UNetSPDO/FlapRecSP2O_128.ini", "examples/UNetSPDO/FlapRecSP2O.ini"])
+def test_example_ini_parameters_drive_the_path(ini):
+    """the parameter dict the reference's own ini parser produces for its example configs (fixture
+    ini_params.json, generated from the reference) resolves model / handler / optimizer here and runs train and
+    validation passes over the synthetic source of the datasets' sample schema."""
+    from ctunet_amd.datasets import SyntheticFlapDataset
+    from ctunet_amd.trainer import StepRunner
+    params = dict(load_json("ini_params.json")[ini])
+    params["device"] = "cuda"
+    params["save_hd_plots"] = False       # the Hausdorff metric (monai) is outside the accelerated path (DESIGN 7)
+    run = StepRunner(params)
+    assert type(run.models["main"]).__name__ == params["model_class"] == "UNetSP"
+    assert type(run.problem_handler).__name__ == "FlapRecWithShapePriorDoubleOut"
+    assert type(run.params["optimizer"]).__name__ == "Adam" and run.params["optimizer"].defaults["amsgrad"]
+    loader = torch.utils.data.DataLoader(SyntheticFlapDataset(3, size=32, seed=3), batch_size=1)
+    run.forward_pass("train", loader)
+    tr = run.epoch_averages()
+    keys = {"epoch_loss"} | ({"ce_sk", "ce_fl"} if params["ce_lambda"] else set()) | \
+        ({"dice_loss_sk", "dice_loss_fl"} if params["dice_lambda"] else set()) | \
+        ({"dice_coef_sk", "dice_coef_fl"} if params.get("save_dice_plots") is True else set())
+    assert set(tr) == keys and all(v == v for v in tr.values())
+    before = {k: v.clone() for k, v in run.models["main"].state_dict().items()}
+    run.forward_pass("validation", loader)
+    va = run.epoch_averages()
+    assert set(va) == keys
+    for k, v in run.models["main"].state_dict().items():
+        assert torch.equal(v, before[k]), k                    # validation updates nothing (eval-mode BatchNorm, no step)
+    with pytest.raises(NameError):
+        StepRunner(dict(params, model_class="NoSuchNet"))
