@@ -488,3 +488,49 @@ def test_example_ini_parameters_drive_the_path(ini):
         assert torch.equal(v, before[k]), k                    # validation updates nothing (eval-mode BatchNorm, no step)
     with pytest.raises(NameError):
         StepRunner(dict(params, model_class="NoSuchNet"))
+
+
+@pytest.mark.parametrize("name,size", [("UNet", 128), ("UNetSP", 192)])
+def test_fused_and_unfused_upconv_paths_agree_at_full_size(name, size):
+    """Size-independent cross-check at BASELINE patch sizes (the oracle would take minutes here): the fused decoder
+    up-convolution (composite weights on the coarse grid, upconv_fused.hip) and the two separate kernels it replaces
+    are different algorithms for the same function -- train-mode outputs (1e-4) and loss (1e-5) must agree to fp32
+    summation-order accuracy; gradients at default init are ill-conditioned (ReLU masks flip on rounding noise, see
+    the module docstring), so they get the same 2e-2-of-scale gate as the fp32-vs-fp32 class checks."""
+    A, M, L, PH = _mods()
+    from ctunet_amd import engine as E
+    in_ch = CLASS_INPUT[name][0]
+    x = torch.randn(1, in_ch, size, size, size, generator=gen(9)).cuda()
+    two = name == "UNetSP"
+    tg = [onehot_target((1, 2, size, size, size), 20 + i, 0.2).cuda() for i in range(2 if two else 1)]
+
+    def run(fuse):
+        old = E.FUSE_UP
+        E.FUSE_UP = fuse
+        try:
+            torch.manual_seed(0)
+            net = getattr(A, name)().cuda().train()
+            xi = x.clone().requires_grad_(True)
+            out = net(xi)
+            h = Holder(1.0, 1.0)
+            if two:
+                PH.FlapRecWithShapePriorDoubleOut.comp_losses_metrics(h, out, tg, 0, 1)
+            else:
+                PH.ProblemHandler.comp_losses_metrics(h, out, tg[0], 0, 1)
+            h.pt_loss.backward()
+            outs = out if isinstance(out, tuple) else (out,)
+            return [o.detach() for o in outs], h.pt_loss.item(), xi.grad, {n_: p.grad for n_, p in net.named_parameters()}
+        finally:
+            E.FUSE_UP = old
+    of, lf, dxf, gf = run(True)
+    ou, lu, dxu, gu = run(False)
+    assert all(torch.isfinite(o).all() for o in of) and lf == lf
+    for a, b in zip(of, ou):
+        assert rel_err(a, b) < 1e-4
+    assert abs(lf - lu) < 1e-5
+    assert (dxf - dxu).abs().max().item() <= 2e-2 * dxu.abs().max().item() + 1e-9
+    for n_, g in gu.items():
+        if g is None:
+            assert gf[n_] is None, n_
+        else:
+            assert (gf[n_] - g).abs().max().item() <= 2e-2 * g.abs().max().item() + 1e-6, n_
