@@ -16,6 +16,7 @@
 // transform applied while staging, next (box, chunk) prefetched into registers under the MFMAs).  One staged box feeds
 // all the block's parities: accumulators acc[parity][row][tile], PB * NTP = 8 tile-parities per block.  The epilogue
 // scatters to the fine grid (float4 per lane), adds the border-class bias and carries the BatchNorm partial sums.
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -35,14 +36,18 @@ struct UpP {
     int tiles_d, tiles_h, tiles_w;
 };
 
-template <int PB, int NTP>
+// PW (8 padded output channels): a 16-wide tile would be half empty, so the w-parity moves into the tile instead --
+// columns = (p_w, c_out), 4 (p_d, p_h) parities per block, 2 x 2 x 3 taps (w offsets 0..2; offset 0 only feeds the
+// p_w = 0 half, offset 2 only the p_w = 1 half, zeros elsewhere): 48 tile-taps instead of 64.
+template <int PB, int NTP, bool PW = false>
 __global__ __launch_bounds__(256, 2) void upconv_fused_fwd_kernel(UpP p, int ntiles, int tiles_per_block) {
-    static_assert(PB * NTP == 8 && (PB == 8 || PB == 4 || PB == 2), "tile-parities per block");
+    static_assert(PW ? (PB == 4 && NTP == 1) : (PB * NTP == 8 && (PB == 8 || PB == 4 || PB == 2)), "tile-parities per block");
+    constexpr int NTW = PW ? 3 : 2, TAPS = 4 * NTW;      // taps along w / per parity
     constexpr int MT = 4, TD = 4, TH = 4, TW = 16;
     constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2, HV = HD * HH * HW;
     constexpr int NTHR = 256;
     constexpr int NTPT = NTP;                            // a block covers ALL 16-wide channel tiles of its PB parities
-    constexpr int WFL = PB * 8 * NTP * 128;              // weight floats of one (chunk, block)
+    constexpr int WFL = PB * TAPS * NTP * 128;           // weight floats of one (chunk, block)
     constexpr int AITEMS = HV * 2, AITER = (AITEMS + NTHR - 1) / NTHR;
     constexpr int WITER = (WFL / 4 + NTHR - 1) / NTHR;
     constexpr int VS2 = 6;                               // 12 floats per voxel: conflict-free ds_read_b64
@@ -59,7 +64,7 @@ __global__ __launch_bounds__(256, 2) void upconv_fused_fwd_kernel(UpP p, int nti
     const int nchunk = p.rin_p >> 3;
     const int half = tid & 1;
     const bool has_xf = p.in_scale != nullptr;
-    const int pd0 = ((by * PB) >> 2) & 1, ph0 = ((by * PB) >> 1) & 1;      // run-time high parity bits (0 when PB == 8)
+    const int pd0 = PW ? 0 : ((by * PB) >> 2) & 1, ph0 = PW ? 0 : ((by * PB) >> 1) & 1;      // run-time high parity bits
 
     // this wave owns coarse plane td = wave, its 4 M-tiles are the rows th = 0..3; base of row 0, tap (0,0,0) of the
     // block's first parity
@@ -98,7 +103,12 @@ __global__ __launch_bounds__(256, 2) void upconv_fused_fwd_kernel(UpP p, int nti
     int tile = blockIdx.x * tiles_per_block;
     const int tile_end = min(ntiles, tile + tiles_per_block);
     int c = 0;
-    float4 va[AITER], vw[WITER];
+    float4 va[AITER];
+    // weight staging values: as float4 the array stays a stack object (scratch; the compiler copies the structs with
+    // memcpy) -- harmless for the 255-VGPR variants, which have no registers to spare, but for PW it would be promoted
+    // to 24 KB of LDS and halve the occupancy, so PW uses the plain vector type (registers)
+    typedef typename std::conditional<PW, f32x4, float4>::type wv_t;
+    wv_t vw[WITER];
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
     unsigned vmask = 0;
 
@@ -161,9 +171,10 @@ __global__ __launch_bounds__(256, 2) void upconv_fused_fwd_kernel(UpP p, int nti
         }
     };
     auto load_w = [&](int cc) {
-        const char* wsrc = reinterpret_cast<const char*>(p.wp + ((size_t)cc * 8 + (size_t)by * PB) * 8 * NTPT * 128);
+        const char* wsrc = reinterpret_cast<const char*>(PW ? p.wp + (size_t)cc * 4 * TAPS * 128
+                                                            : p.wp + ((size_t)cc * 8 + (size_t)by * PB) * 8 * NTPT * 128);
 #pragma unroll
-        for (int it = 0; it < WITER; ++it) vw[it] = *reinterpret_cast<const float4*>(wsrc + (unsigned)(tid + it * NTHR) * 16u);
+        for (int it = 0; it < WITER; ++it) vw[it] = *reinterpret_cast<const wv_t*>(wsrc + (unsigned)(tid + it * NTHR) * 16u);
     };
     if (tile >= tile_end) return;
     load_a(box, 0);
@@ -188,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void upconv_fused_fwd_kernel(UpP p, int nti
                 }
             }
 #pragma unroll
-            for (int it = 0; it < WITER; ++it) *reinterpret_cast<float4*>(&sW2[(tid + it * NTHR) * 2]) = vw[it];
+            for (int it = 0; it < WITER; ++it) *reinterpret_cast<wv_t*>(&sW2[(tid + it * NTHR) * 2]) = vw[it];
         }
         __syncthreads();
         int ntile = tile, nc = c + 1;
@@ -202,23 +213,24 @@ __global__ __launch_bounds__(256, 2) void upconv_fused_fwd_kernel(UpP p, int nti
         // ---- MFMAs: flat sequence of PB * 4 groups (parity pi, dz, dx); a group's 5 input rows feed the 2 dy taps of the
         // 4 M-tiles: 5 + 2*NTP fragment reads for 16*NTP MFMAs, read one group ahead
         {
-            constexpr int NG = PB * 4;
+            constexpr int NG = PB * 2 * NTW;
             v2f ar[2][5], br[2][2][NTP];
             auto load_group = [&](int g, v2f (&aa)[5], v2f (&bb)[2][NTP]) {
-                const int pi = g >> 2, dz = (g >> 1) & 1, dx = g & 1;
-                const int pid = (PB == 8) ? (pi >> 2) : 0, pih = (PB >= 4) ? ((pi >> 1) & 1) : 0, piw = pi & 1;
+                const int pi = g / (2 * NTW), dz = (g / NTW) & 1, dx = g % NTW;
+                const int pid = PW ? (pi >> 1) : ((PB == 8) ? (pi >> 2) : 0), pih = PW ? (pi & 1) : ((PB >= 4) ? ((pi >> 1) & 1) : 0),
+                          piw = PW ? 0 : (pi & 1);
 #pragma unroll
                 for (int r = 0; r < 5; ++r) aa[r] = vA[(((pid + dz) * HH + r + pih) * HW + piw + dx) * VS2];
 #pragma unroll
                 for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
-                    for (int nt = 0; nt < NTP; ++nt) bb[dy][nt] = vW[((pi * 8 + (dz * 2 + dy) * 2 + dx) * NTP + nt) * 64];
+                    for (int nt = 0; nt < NTP; ++nt) bb[dy][nt] = vW[((pi * TAPS + (dz * 2 + dy) * NTW + dx) * NTP + nt) * 64];
             };
             load_group(0, ar[0], br[0]);
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
                 if (g + 1 < NG) load_group(g + 1, ar[(g + 1) & 1], br[(g + 1) & 1]);
-                const int pi = g >> 2;
+                const int pi = g / (2 * NTW);
                 v2f (&aa)[5] = ar[g & 1];
                 v2f (&bb)[2][NTP] = br[g & 1];
 #pragma unroll
@@ -244,13 +256,14 @@ __global__ __launch_bounds__(256, 2) void upconv_fused_fwd_kernel(UpP p, int nti
             const bool touches = d0 == 0 || h0 == 0 || w0 == 0 || d0 + TD >= p.D || h0 + TH >= p.H || w0 + TW >= p.W;   // uniform
 #pragma unroll
             for (int nt = 0; nt < NTP; ++nt) {
-                const int co = nt * 16 + kq * 4;
+                const int co = PW ? (kq & 1) * 4 : nt * 16 + kq * 4;
                 const bool cok = co < p.nout_p;
                 float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (cok) b0 = *reinterpret_cast<const float4*>(p.beff + co);             // class 0: interior
 #pragma unroll
                 for (int pi = 0; pi < PB; ++pi) {
-                    const int pd = pd0 + ((PB == 8) ? (pi >> 2) : 0), ph = ph0 + ((PB >= 4) ? ((pi >> 1) & 1) : 0), pw = pi & 1;
+                    const int pd = PW ? (pi >> 1) : pd0 + ((PB == 8) ? (pi >> 2) : 0), ph = PW ? (pi & 1) : ph0 + ((PB >= 4) ? ((pi >> 1) & 1) : 0),
+                              pw = PW ? (kq >> 1) : (pi & 1);
                     const int fz = 2 * cd + pd, fx = 2 * cw + pw;
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
@@ -288,9 +301,11 @@ __global__ __launch_bounds__(256, 2) void upconv_fused_fwd_kernel(UpP p, int nti
                 float a1 = s1[nt][r], a2 = s2[nt][r];
 #pragma unroll
                 for (int o = 1; o < 16; o <<= 1) { a1 += __shfl_xor(a1, o); a2 += __shfl_xor(a2, o); }
-                if (m == 0) {
-                    sRed[(wave * NTP * 16 + nt * 16 + kq * 4 + r) * 2 + 0] = a1;
-                    sRed[(wave * NTP * 16 + nt * 16 + kq * 4 + r) * 2 + 1] = a2;
+                if (PW) { a1 += __shfl_xor(a1, 32); a2 += __shfl_xor(a2, 32); }      // the two w-parity halves hold the same channels
+                const int ch = PW ? (kq & 1) * 4 + r : nt * 16 + kq * 4 + r;
+                if (m == 0 && (!PW || kq < 2)) {
+                    sRed[(wave * NTP * 16 + ch) * 2 + 0] = a1;
+                    sRed[(wave * NTP * 16 + ch) * 2 + 1] = a2;
                 }
             }
         __syncthreads();
@@ -632,6 +647,24 @@ __global__ void upconv_pack_kernel(const float* __restrict__ wtt, const float* _
     }
 }
 
+// PW forward packing (8 padded output channels) gathered from the standard one:
+// wpw[chunk][par4 = pd*2+ph][tap12 = (dz*2+dy)*3+dxx][kq][n = px*8+co][j] = W_eff[(pd,ph,px)][(dz,dy,dxx-px)] or 0
+__global__ void upconv_pack_pw_kernel(const float* __restrict__ wp, float* __restrict__ wpw, int nchunk) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nchunk * 4 * 12 * 128) return;
+    int r = idx;
+    const int j = r & 1; r >>= 1;
+    const int n = r & 15; r >>= 4;
+    const int kq = r & 3; r >>= 2;
+    const int tap = r % 12; r /= 12;
+    const int par4 = r & 3;
+    const int c = r >> 2;
+    const int px = n >> 3, co = n & 7, dxx = tap % 3, dzy = tap / 3, jx = dxx - px;
+    float v = 0.f;
+    if (jx == 0 || jx == 1) v = wp[((size_t)(c * 8 + par4 * 2 + px) * 8 + dzy * 2 + jx) * 128 + kq * 32 + co * 2 + j];
+    wpw[idx] = v;
+}
+
 // b_eff[class 27][nout_p]: class = (cz*3+cy)*3+cx, per axis 0 interior, 1 first fine voxel (t=0 outside), 2 last (t=2 outside).
 // One block: S[t][co] = sum_cm bT[cm] w3t[t][cm][co] into LDS (coalesced over co), then the 27 class sums of valid taps.
 __global__ __launch_bounds__(1024) void upconv_beff_kernel(const float* __restrict__ bt, const float* __restrict__ w3t,
@@ -816,8 +849,11 @@ extern "C" int ctu_upconv_fused_supported(int k, int D, int H, int W, int cin_p,
     return k == 3 && W >= 16 && D >= 1 && H >= 1 && cin_p % 8 == 0 && cin_p >= 8 && nout_p % 8 == 0 && nout_p >= 8 && nout_p <= 64;
 }
 
+static size_t up_std_packed(int cin_p, int nout_p) { return (size_t)(cin_p / 8) * 8 * 8 * ceil_div(nout_p, 16) * 128; }
+
+// standard packing [chunk][parity 8][tap 8][n16][128]; for 8 padded output channels followed by the PW forward packing
 extern "C" size_t ctu_upconv_fused_packed_floats(int cin_p, int nout_p) {
-    return (size_t)(cin_p / 8) * 8 * 8 * ceil_div(nout_p, 16) * 128;
+    return up_std_packed(cin_p, nout_p) + (nout_p == 8 ? (size_t)(cin_p / 8) * 4 * 12 * 128 : 0);
 }
 
 extern "C" int ctu_upconv_fused_num_blocks(int N, int D, int H, int W, int nout_p) {
@@ -844,6 +880,11 @@ extern "C" int ctu_upconv_fused_pack(const float* wt, const float* bt, const flo
     const int total = (cin_p / 8) * 8 * 8 * 8 * ntpt * 16 * 8;           // 8 lanes per packed element
     upconv_pack_kernel<<<ceil_div(total, 256), 256, 0, st>>>(wtt, w3t, wp, C, nout_p, cinv, cin_p / 8, ntpt);
     CTU_CHECK_LAUNCH("upconv_fused_pack");
+    if (nout_p == 8) {
+        const int tpw = (cin_p / 8) * 4 * 12 * 128;
+        upconv_pack_pw_kernel<<<ceil_div(tpw, 256), 256, 0, st>>>(wp, wp + up_std_packed(cin_p, nout_p), cin_p / 8);
+        CTU_CHECK_LAUNCH("upconv_fused_pack_pw");
+    }
     upconv_beff_kernel<<<1, 1024, 0, st>>>(bt, w3t, beff, C, nout_p);
     CTU_CHECK_LAUNCH("upconv_fused_beff");
     return CTU_OK;
@@ -871,7 +912,10 @@ extern "C" int ctu_upconv_fused_fwd(const float* in, int in_cs, int cin_p, const
     int gx, tpb;
     up_grid(ntiles, ny, &gx, &tpb);
     hipStream_t st = (hipStream_t)stream;
-    if (ny == 1) upconv_fused_fwd_kernel<8, 1><<<dim3(gx, 1), 256, 0, st>>>(p, ntiles, tpb);
+    if (nout_p == 8) {
+        p.wp = wp + up_std_packed(cin_p, nout_p);                 // w-parity-in-tile packing
+        upconv_fused_fwd_kernel<4, 1, true><<<dim3(gx, 1), 256, 0, st>>>(p, ntiles, tpb);
+    } else if (ny == 1) upconv_fused_fwd_kernel<8, 1><<<dim3(gx, 1), 256, 0, st>>>(p, ntiles, tpb);
     else if (ny == 2) upconv_fused_fwd_kernel<4, 2><<<dim3(gx, 2), 256, 0, st>>>(p, ntiles, tpb);
     else upconv_fused_fwd_kernel<2, 4><<<dim3(gx, 4), 256, 0, st>>>(p, ntiles, tpb);
     CTU_CHECK_LAUNCH("upconv_fused_fwd");
