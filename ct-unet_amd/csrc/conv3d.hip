@@ -818,7 +818,9 @@ inline int wgrad_gx(int ntiles, int pairs_z) {
 // UP: the weight gradient of the FUSED decoder up-convolution (upconv_fused.hip): in = COARSE activations, g = the
 // fine-grid gradient read at one output parity (blockIdx.y carries the parity), the 8 taps of that parity's 2x2x2
 // sub-cube of the coarse halo -> dW_eff[parity][tap][ci][co] slabs.
-template <int SM, int SN, bool UP = false>
+// UP = 2 (8 padded output channels, gradient stride 8): the tile's 16 columns are (w-parity, c_out) -- the two fine voxels
+// 2x, 2x+1 are 16 contiguous floats -- one (p_d, p_h) parity per block, 2 x 2 x 3 taps (12 MFMAs per K-step instead of 2 x 8).
+template <int SM, int SN, int UP = 0>
 __global__ __launch_bounds__(256, CTU_K3S_OCC) void conv3d_wgrad_k3s_kernel(WgP p, int tiles_per_block) {
     static_assert(!UP || (SM == 1 && SN == 1), "the fused up-convolution uses the full 16 x 16 channel tile");
     // box: 4 x 4 x 16 voxels; 4 x 4 x 8 for the full 16 x 16 channel tile, whose 27 accumulators leave fewer staging registers
@@ -827,7 +829,7 @@ __global__ __launch_bounds__(256, CTU_K3S_OCC) void conv3d_wgrad_k3s_kernel(WgP 
     constexpr int CM = 16 / SM, CN = 16 / SN;        // channels per block on the input / output side
     constexpr int GW = TW + (SN - 1), GV = TD * TH * GW;
     constexpr int QN = (SM == 2 && SN == 2) ? 1 : ((SM == 1 && SN == 1) ? 3 : 2);     // w positions per (kd, kh) row
-    constexpr int NMF = UP ? 8 : 9 * QN;
+    constexpr int NMF = UP == 2 ? 12 : (UP ? 8 : 9 * QN);
     constexpr int AQ = CM / 4, GQ = CN / 4;
     constexpr int AITEMS = HV * AQ, AITER = (AITEMS + 255) / 256;
     constexpr int GITEMS = GV * GQ, GITER = (GITEMS + 255) / 256;
@@ -844,7 +846,7 @@ __global__ __launch_bounds__(256, CTU_K3S_OCC) void conv3d_wgrad_k3s_kernel(WgP 
     const int i = lane & 15, kq = lane >> 4;
     const int cig = blockIdx.y % p.n_ci_t, cog = UP ? (blockIdx.y / p.n_ci_t) % p.n_co_t : blockIdx.y / p.n_ci_t;
     const int par = UP ? blockIdx.y / (p.n_ci_t * p.n_co_t) : 0;          // output parity (pz, py, px) = bits 2, 1, 0
-    const int pz = (par >> 2) & 1, py = (par >> 1) & 1, px = par & 1;
+    const int pz = UP == 2 ? (par >> 1) & 1 : (par >> 2) & 1, py = UP == 2 ? par & 1 : (par >> 1) & 1, px = UP == 2 ? 0 : par & 1;
     const int gH = UP ? 2 * p.H : p.H, gW = UP ? 2 * p.W : p.W, gs = UP ? 2 : 1;      // gradient grid: row strides, voxel step
     const int ci0 = cig * CM, co0 = cog * CN;
     const bool has_xf = p.in_scale != nullptr;
@@ -1014,7 +1016,8 @@ __global__ __launch_bounds__(256, CTU_K3S_OCC) void conv3d_wgrad_k3s_kernel(WgP 
         auto a_read = [&](int j) -> float {
             const int ks = j / NMF, t = j % NMF;
             const int th = ks / KPR, tw4 = (ks % KPR) * 4;
-            const int r = UP ? (t >> 1) : t / QN, q = UP ? (t & 1) : t % QN, kd = UP ? (r >> 1) : r / 3, kh = UP ? (r & 1) : r % 3;
+            const int r = UP == 2 ? t / 3 : (UP ? (t >> 1) : t / QN), q = UP == 2 ? t % 3 : (UP ? (t & 1) : t % QN),
+                      kd = UP ? (r >> 1) : r / 3, kh = UP ? (r & 1) : r % 3;
             return cA[((kd * HH + th + kh) * HW + tw4 + q) * CM];
         };
         auto b_read = [&](int ks) -> float { return cG[((ks / KPR) * GW + (ks % KPR) * 4) * CN]; };
@@ -1205,9 +1208,39 @@ __global__ __launch_bounds__(1024) void upconv_wgrad_reduce_kernel(const float* 
     if (rp < cin_p && co < nout_p) dweff[((size_t)(par * 8 + t) * cin_p + rp) * nout_p + co] = tot;
 }
 
-struct UpWgGeom { int ntiles, n_ci_g, n_co_g, pairs, gx, tpb; };
-static UpWgGeom upwg_geom(int N, int D, int H, int W, int cin_p, int nout_p) {
+// UP = 2 slabs [12 taps = (dz*2+dy)*3+dxx][16 ci][16 = (px, co)] -> dW_eff[(pz,py,px)][(dz,dy,dxx-px)][cin_p][8]
+__global__ __launch_bounds__(1024) void upconv_wgrad_reduce_pw_kernel(const float* __restrict__ ws, float* __restrict__ dweff,
+                                                                     int cin_p, int n_ci_g, int gx) {
+    __shared__ float red[RPARTS][64];
+    const int e = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int el = blockIdx.x * 64 + e;                  // element of the [12][16][16] slab
+    const int yb = blockIdx.y;                           // par4 * n_ci_g + cig
+    float s = 0.f;
+    const float* src = ws + (size_t)yb * gx * (12 * 256) + el;
+    for (int k = part; k < gx; k += RPARTS) s += src[(size_t)k * (12 * 256)];
+    red[part][e] = s;
+    __syncthreads();
+    if (part != 0) return;
+    const float tot = red_total(red, e);
+    const int t = el >> 8, i = (el >> 4) & 15, j = el & 15;
+    const int cig = yb % n_ci_g, par4 = yb / n_ci_g;
+    const int px = j >> 3, co = j & 7, jx = t % 3 - px, rp = cig * 16 + i;
+    if ((jx == 0 || jx == 1) && rp < cin_p)
+        dweff[((size_t)((par4 * 2 + px) * 8 + (t / 3) * 2 + jx) * cin_p + rp) * 8 + co] = tot;
+}
+
+struct UpWgGeom { int ntiles, n_ci_g, n_co_g, pairs, gx, tpb, nmf; };
+static UpWgGeom upwg_geom(int N, int D, int H, int W, int cin_p, int nout_p, bool pw) {
     UpWgGeom g;
+    if (pw) {
+        g.ntiles = N * ceil_div(D, 4) * ceil_div(H, 4) * ceil_div(W, 8);
+        g.n_ci_g = ceil_div(cin_p, 16); g.n_co_g = 1; g.pairs = 4 * g.n_ci_g; g.nmf = 12;
+        g.gx = wgrad_gx(g.ntiles, g.pairs);
+        g.tpb = ceil_div(g.ntiles, g.gx);
+        g.gx = ceil_div(g.ntiles, g.tpb);
+        return g;
+    }
+    g.nmf = 8;
     g.ntiles = N * ceil_div(D, 4) * ceil_div(H, 4) * ceil_div(W, 8);
     g.n_ci_g = ceil_div(cin_p, 16);
     g.n_co_g = ceil_div(nout_p, 16);
@@ -1489,8 +1522,9 @@ extern "C" int ctu_conv3d_wgrad(const float* in, int in_cs, int cin_p, const flo
 
 // ---- fused decoder up-convolution: weight gradient w.r.t. the composite weights (see upconv_fused.hip)
 extern "C" size_t ctu_upconv_fused_wgrad_ws_floats(int N, int D, int H, int W, int cin_p, int nout_p) {
-    const UpWgGeom g = upwg_geom(N, D, H, W, cin_p, nout_p);
-    return (size_t)g.pairs * g.gx * 8 * 256;
+    const UpWgGeom a = upwg_geom(N, D, H, W, cin_p, nout_p, false), b = upwg_geom(N, D, H, W, cin_p, nout_p, true);
+    const size_t na = (size_t)a.pairs * a.gx * a.nmf * 256, nb = (size_t)b.pairs * b.gx * b.nmf * 256;
+    return na > nb ? na : nb;                            // either tiling (the w-parity tile needs nout_p = 8 = g_cs)
 }
 
 extern "C" int ctu_upconv_fused_wgrad(const float* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
@@ -1504,14 +1538,23 @@ extern "C" int ctu_upconv_fused_wgrad(const float* in, int in_cs, int cin_p, con
     CTU_REQUIRE((int64_t)(2 * H * W + 2 * W + 2) * in_cs * 4 < (int64_t)1 << 31 && (int64_t)(8 * 2 * H + 8) * 2 * W * g_cs * 4 < (int64_t)1 << 31,
                 "upconv_fused_wgrad: volume too large for 32-bit offsets");
     hipStream_t st = (hipStream_t)stream;
-    const UpWgGeom g = upwg_geom(N, D, H, W, cin_p, nout_p);
+    const bool pw = nout_p == 8 && g_cs == 8;             // (w-parity, c_out) tile: the two fine voxels are 16 contiguous floats
+    const UpWgGeom g = upwg_geom(N, D, H, W, cin_p, nout_p, pw);
     WgP p;
     p.in = in; p.in_scale = in_scale; p.in_shift = in_shift; p.g = gout; p.ws = ws;
     p.in_cs = in_cs; p.cin_p = cin_p; p.in_relu = in_relu; p.g_cs = g_cs; p.cout_p = nout_p;
     p.N = N; p.D = D; p.H = H; p.W = W;
     p.tiles_d = ceil_div(D, 4); p.tiles_h = ceil_div(H, 4); p.tiles_w = ceil_div(W, 8);
     p.ntiles = g.ntiles; p.n_ci_t = g.n_ci_g; p.n_co_t = g.n_co_g;
-    conv3d_wgrad_k3s_kernel<1, 1, true><<<dim3(g.gx, g.pairs), 256, 0, st>>>(p, g.tpb);
+    if (pw) {
+        p.cout_p = 16;                                   // all 4 channel quads of the (w-parity, c_out) tile are real
+        conv3d_wgrad_k3s_kernel<1, 1, 2><<<dim3(g.gx, g.pairs), 256, 0, st>>>(p, g.tpb);
+        CTU_CHECK_LAUNCH("upconv_fused_wgrad(pw)");
+        upconv_wgrad_reduce_pw_kernel<<<dim3(12 * 256 / 64, g.pairs), 64 * RPARTS, 0, st>>>(ws, dweff, cin_p, g.n_ci_g, g.gx);
+        CTU_CHECK_LAUNCH("upconv_fused_wgrad_reduce(pw)");
+        return CTU_OK;
+    }
+    conv3d_wgrad_k3s_kernel<1, 1, 1><<<dim3(g.gx, g.pairs), 256, 0, st>>>(p, g.tpb);
     CTU_CHECK_LAUNCH("upconv_fused_wgrad");
     upconv_wgrad_reduce_kernel<<<dim3(8 * 256 / 64, g.pairs), 64 * RPARTS, 0, st>>>(ws, dweff, cin_p, nout_p, g.n_ci_g, g.n_co_g, g.gx);
     CTU_CHECK_LAUNCH("upconv_fused_wgrad_reduce");
