@@ -10,7 +10,7 @@ ks = list(csv.DictReader(open(f"{ROOT}/profiles/r01_kernel_stats.csv")))
 n = [int(r["Calls"]) for r in ks if "adam_amsgrad_kernel" in r["Name"]][0]
 tot = sum(float(r["TotalDurationNs"]) for r in ks) / 1e6 / n
 grp = lambda pred: sum(float(r["TotalDurationNs"]) for r in ks if pred(r["Name"])) / 1e6 / n
-conv = grp(lambda s: ("conv3d" in s or "first_" in s) and "upconv" not in s)
+conv = grp(lambda s: ("conv3d" in s or "first_" in s) and "upconv" not in s and "k3s_kernel<1, 1, 1>" not in s and "k3s_kernel<1, 1, 2>" not in s)
 up = grp(lambda s: "upconv" in s or "k3s_kernel<1, 1, true>" in s)
 convt = grp(lambda s: "convt2" in s)
 bn = grp(lambda s: "bn_" in s)
@@ -69,7 +69,7 @@ kernels, batched weight packing → 5.5 explicit `ds_read_b64` fragment reads, h
 5.4 uniform interior fast paths → 5.2 pipelined persistent weight-gradient kernel for every k=3 layer →
 5.05 two-stage LDS weight gradient → 4.94 BN replay folded into backward, quad-mapped head backward →
 4.84 fused up-convolution forward → 4.57 + its parameter gradients → 4.09 + its data gradient and cheaper
-projections → {d['ms_per_step']:.2f}.
+projections → 3.98 → 3.93 w-parity-in-tile forward for 8 output channels → {d['ms_per_step']:.2f} the same for the weight gradient.
 """
 open(f"{ROOT}/profiles/README.md", "w").write(txt)
 print(txt[:600])
