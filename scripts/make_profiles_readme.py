@@ -10,8 +10,9 @@ ks = list(csv.DictReader(open(f"{ROOT}/profiles/r01_kernel_stats.csv")))
 n = [int(r["Calls"]) for r in ks if "adam_amsgrad_kernel" in r["Name"]][0]
 tot = sum(float(r["TotalDurationNs"]) for r in ks) / 1e6 / n
 grp = lambda pred: sum(float(r["TotalDurationNs"]) for r in ks if pred(r["Name"])) / 1e6 / n
-conv = grp(lambda s: ("conv3d" in s or "first_" in s) and "upconv" not in s and "k3s_kernel<1, 1, 1>" not in s and "k3s_kernel<1, 1, 2>" not in s)
-up = grp(lambda s: "upconv" in s or "k3s_kernel<1, 1, true>" in s)
+isup = lambda s: "upconv" in s or "k3s_kernel<1, 1, 1>" in s or "k3s_kernel<1, 1, 2>" in s or "channel_sum" in s
+conv = grp(lambda s: ("conv3d" in s or "first_" in s) and not isup(s))
+up = grp(isup)
 convt = grp(lambda s: "convt2" in s)
 bn = grp(lambda s: "bn_" in s)
 tr = json.load(open(f"{ROOT}/profiles/r01_hbm_traffic.json"))["kernels"]
