@@ -41,7 +41,7 @@ struct UpP {
 // p_w = 0 half, offset 2 only the p_w = 1 half, zeros elsewhere): 48 tile-taps instead of 64.
 template <int PB, int NTP, bool PW = false>
 __global__ __launch_bounds__(256, 2) void upconv_fused_fwd_kernel(UpP p, int ntiles, int tiles_per_block) {
-    static_assert(PW ? (PB == 4 && NTP == 1) : (PB * NTP == 8 && (PB == 8 || PB == 4 || PB == 2)), "tile-parities per block");
+    static_assert(PW ? (PB == 4 && NTP == 1) : ((PB * NTP == 8 || (PB == 4 && NTP == 1)) && (PB == 8 || PB == 4 || PB == 2)), "tile-parities per block");
     constexpr int NTW = PW ? 3 : 2, TAPS = 4 * NTW;      // taps along w / per parity
     constexpr int MT = 4, TD = 4, TH = 4, TW = 16;
     constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2, HV = HD * HH * HW;
@@ -838,7 +838,12 @@ static void up_grid(int ntiles, int ny, int* gx, int* tpb) {
     *gx = ceil_div(ntiles, *tpb);
 }
 
-static int up_ny(int nout_p) { return nout_p <= 16 ? 1 : (nout_p <= 32 ? 2 : 4); }
+// parity groups (blockIdx.y) of the forward kernel: all 8 parities in one block for <= 16 output channels, unless the
+// coarse volume has fewer than 256 boxes -- then 16-channel layers split the parities over two blocks so every CU gets one
+static int up_ny(int nout_p, int ntiles) {
+    if (nout_p == 16 && ntiles < 256) return 2;
+    return nout_p <= 16 ? 1 : (nout_p <= 32 ? 2 : 4);
+}
 
 }  // namespace
 
@@ -858,8 +863,9 @@ extern "C" size_t ctu_upconv_fused_packed_floats(int cin_p, int nout_p) {
 
 extern "C" int ctu_upconv_fused_num_blocks(int N, int D, int H, int W, int nout_p) {
     int gx, tpb;
-    const int ny = up_ny(nout_p);
-    up_grid(N * ceil_div(D, 4) * ceil_div(H, 4) * ceil_div(W, 16), ny, &gx, &tpb);
+    const int ntiles = N * ceil_div(D, 4) * ceil_div(H, 4) * ceil_div(W, 16);
+    const int ny = up_ny(nout_p, ntiles);
+    up_grid(ntiles, ny, &gx, &tpb);
     return gx * ny;
 }
 
@@ -908,11 +914,13 @@ extern "C" int ctu_upconv_fused_fwd(const float* in, int in_cs, int cin_p, const
     p.N = N; p.D = D; p.H = H; p.W = W;
     p.tiles_d = ceil_div(D, 4); p.tiles_h = ceil_div(H, 4); p.tiles_w = ceil_div(W, 16);
     const int ntiles = N * p.tiles_d * p.tiles_h * p.tiles_w;
-    const int ny = up_ny(nout_p);
+    const int ny = up_ny(nout_p, ntiles);
     int gx, tpb;
     up_grid(ntiles, ny, &gx, &tpb);
     hipStream_t st = (hipStream_t)stream;
-    if (nout_p == 8) {
+    if (nout_p == 16 && ny == 2) {
+        upconv_fused_fwd_kernel<4, 1><<<dim3(gx, 2), 256, 0, st>>>(p, ntiles, tpb);
+    } else if (nout_p == 8) {
         p.wp = wp + up_std_packed(cin_p, nout_p);                 // w-parity-in-tile packing
         upconv_fused_fwd_kernel<4, 1, true><<<dim3(gx, 1), 256, 0, st>>>(p, ntiles, tpb);
     } else if (ny == 1) upconv_fused_fwd_kernel<8, 1><<<dim3(gx, 1), 256, 0, st>>>(p, ntiles, tpb);
@@ -984,7 +992,8 @@ extern "C" int ctu_upconv_fused_bwd_data(const float* gout, int g_cs, int nout_p
     p.tiles_d = ceil_div(D, 4); p.tiles_h = ceil_div(H, 4); p.tiles_w = ceil_div(W, 16);
     p.n16 = ceil_div(cin_p, 16);
     const int ntiles = N * p.tiles_d * p.tiles_h * p.tiles_w;
-    const int NT = p.n16 >= 4 ? 4 : (p.n16 >= 2 ? 2 : 1);
+    int NT = p.n16 >= 4 ? 4 : (p.n16 >= 2 ? 2 : 1);
+    while (NT > 1 && (long)ntiles * ceil_div(p.n16, NT) < 256) NT >>= 1;      // few boxes: narrower blocks so every CU gets one
     const int ny = ceil_div(p.n16, NT);
     int gx, tpb;
     up_grid(ntiles, ny, &gx, &tpb);
