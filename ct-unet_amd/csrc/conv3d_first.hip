@@ -335,8 +335,19 @@ __global__ __launch_bounds__(1024) void first_wgrad_reduce_kernel(const float* _
     const int e = threadIdx.x & 63, part = threadIdx.x >> 6;          // 1024 threads: 16 slab groups x 64 elements
     const int el = blockIdx.x * 64 + e;
     float s = 0.f;
-    if (el < MTN * 256)
-        for (int k = part; k < gx; k += 16) s += ws[(size_t)k * (MTN * 256) + el];
+    if (el < MTN * 256) {
+        // 4 independent chains per thread (coalesced 256-byte rows of 4 slabs in flight), combined in a fixed order
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int k = part;
+        for (; k + 48 < gx; k += 64) {
+            s0 += ws[(size_t)k * (MTN * 256) + el];
+            s1 += ws[(size_t)(k + 16) * (MTN * 256) + el];
+            s2 += ws[(size_t)(k + 32) * (MTN * 256) + el];
+            s3 += ws[(size_t)(k + 48) * (MTN * 256) + el];
+        }
+        for (; k < gx; k += 16) s0 += ws[(size_t)k * (MTN * 256) + el];
+        s = (s0 + s1) + (s2 + s3);
+    }
     red[part][e] = s;
     __syncthreads();
     if (part != 0 || el >= MTN * 256) return;

@@ -306,25 +306,35 @@ __global__ __launch_bounds__(HB) void loss_fwd_kernel(const float* __restrict__ 
 }
 
 // ws tail: [N][2] = (num+eps, den+eps) per item, used by backward
+// one wave: lane l sums the block partials l, l + 64, ... in double, then a fixed-order butterfly -> deterministic
 __global__ void loss_final_kernel(float* __restrict__ ws, int N, int nbx, int64_t V, float ce_lambda,
                                   float dice_lambda, float* __restrict__ terms) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (blockIdx.x != 0) return;
+    const int lane = threadIdx.x;
     const double eps = 0.0000001;
     double ce = 0.0, dsum = 0.0;
     float* tail = ws + (size_t)N * nbx * 4;
     for (int n = 0; n < N; ++n) {
         double c = 0.0, num = 0.0, d1 = 0.0, d2 = 0.0;
-        for (int b = 0; b < nbx; ++b) {
-            const float* r = ws + ((size_t)n * nbx + b) * 4;
-            c += r[0]; num += r[1]; d1 += r[2]; d2 += r[3];
+        for (int b = lane; b < nbx; b += 64) {
+            const float4 r = *reinterpret_cast<const float4*>(ws + ((size_t)n * nbx + b) * 4);
+            c += r.x; num += r.y; d1 += r.z; d2 += r.w;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            c += __shfl_xor(c, o); num += __shfl_xor(num, o); d1 += __shfl_xor(d1, o); d2 += __shfl_xor(d2, o);
         }
         ce += c;
         dsum += (num + eps) / (d1 + d2 + eps);
-        tail[n * 2 + 0] = (float)(num + eps);
-        tail[n * 2 + 1] = (float)(d1 + d2 + eps);
+        if (lane == 0) {
+            tail[n * 2 + 0] = (float)(num + eps);
+            tail[n * 2 + 1] = (float)(d1 + d2 + eps);
+        }
     }
-    terms[0] = ce_lambda != 0.f ? (float)(ce_lambda * ce / ((double)N * (double)V)) : 0.f;
-    terms[1] = dice_lambda != 0.f ? (float)(dice_lambda * (1.0 - 2.0 * dsum / N)) : 0.f;
+    if (lane == 0) {
+        terms[0] = ce_lambda != 0.f ? (float)(ce_lambda * ce / ((double)N * (double)V)) : 0.f;
+        terms[1] = dice_lambda != 0.f ? (float)(dice_lambda * (1.0 - 2.0 * dsum / N)) : 0.f;
+    }
 }
 
 __global__ __launch_bounds__(HB) void loss_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ tgt,
