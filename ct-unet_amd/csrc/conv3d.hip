@@ -30,6 +30,8 @@
 
 namespace {
 
+typedef float gv2f __attribute__((ext_vector_type(2)));
+
 struct ConvP {
     const float* in;
     const float* in_scale;
@@ -109,6 +111,92 @@ __global__ __launch_bounds__(256) void conv3d_fwd_kernel(ConvP p) {
     const bool has_xf = p.in_scale != nullptr;
     const int n16 = p.n16;
 
+    if constexpr (CCH > 1) {
+        // Small deep-level volumes: one block per CU and one wave per SIMD, so nothing hides a latency unless the kernel
+        // does it itself.  (a) the NEXT stage's halo and weights are fetched into registers (all loads issued together,
+        // branch-free: out-of-volume items read voxel 0 and are zeroed at the LDS write) while this stage's taps run;
+        // (b) the (chunk, tap) fragment pairs go through a ring of R registers refilled R steps ahead, the order
+        // MFMA / 2 reads / MFMA pinned for the scheduler.
+        static_assert(MT == 1 && NT == 1 && NSTAGE == 1, "multi-chunk staging: one accumulator, all taps in one stage");
+        constexpr int WITER = (CCH * WFL + 1023) / 1024;
+        f32x4 vals[AITER], wv[WITER];                 // (ext vectors: float4 arrays end up as LDS-promoted stack objects)
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        unsigned aoff[AITER], amask = 0;              // element offset of each halo item, in-volume bits
+#pragma unroll
+        for (int it = 0; it < AITER; ++it) {
+            const int i = tid + it * 256;
+            const int v = i / AQ;
+            const int pw = v % HW, t2 = v / HW, ph = t2 % HH, pd = t2 / HH;
+            const int gd = d0 + pd - PAD, gh = h0 + ph - PAD, gw = w0 + pw - PAD;
+            const bool ok = i < AITEMS && (unsigned)gd < (unsigned)p.D && (unsigned)gh < (unsigned)p.H && (unsigned)gw < (unsigned)p.W;
+            aoff[it] = ok ? (unsigned)(((gd * p.H + gh) * p.W + gw) * p.in_cs + half * 4) : 0u;
+            amask |= ok ? (1u << it) : 0u;
+        }
+        const float* in_img = p.in + (size_t)n_img * p.D * p.H * p.W * p.in_cs;
+        const float* w_blk = p.wp + (size_t)by * 128;
+        auto fetch = [&](int c) {
+#pragma unroll
+            for (int it = 0; it < AITER; ++it) vals[it] = *reinterpret_cast<const f32x4*>(in_img + aoff[it] + c * 8);
+#pragma unroll
+            for (int wi = 0; wi < WITER; ++wi) {
+                int i = tid * 4 + wi * 1024;
+                if (i >= CCH * WFL) i = 0;             // (the last pass is ragged: re-read item 0, not stored)
+                const int g = i / WFL, j = i % WFL;
+                wv[wi] = *reinterpret_cast<const f32x4*>(w_blk + ((size_t)(c + g) * STAPS + j / 128) * n16 * 128 + j % 128);
+            }
+            if (has_xf) {
+                sc = *reinterpret_cast<const float4*>(p.in_scale + c * 8 + half * 4);
+                sh = *reinterpret_cast<const float4*>(p.in_shift + c * 8 + half * 4);
+            }
+        };
+        fetch(0);
+        for (int c = 0; c < nchunk; c += CCH) {
+            __syncthreads();   // previous stage's readers are done with sA / sW
+#pragma unroll
+            for (int it = 0; it < AITER; ++it) {
+                const int i = tid + it * 256;
+                float4 v = make_float4(vals[it][0], vals[it][1], vals[it][2], vals[it][3]);
+                if (has_xf) v = xform4(v, sc, sh, p.in_relu);
+                const bool ok = (amask >> it) & 1u;
+                if (i < AITEMS)
+                    *reinterpret_cast<float4*>(&sA[(i / AQ) * VSL + half * 4]) =
+                        make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+            }
+#pragma unroll
+            for (int wi = 0; wi < WITER; ++wi) {
+                const int i = tid * 4 + wi * 1024;
+                if (i < CCH * WFL) *reinterpret_cast<f32x4*>(&sW[i]) = wv[wi];
+            }
+            __syncthreads();
+            if (c + CCH < nchunk) fetch(c + CCH);
+            __builtin_amdgcn_sched_barrier(0);         // (the loads are issued HERE, in front of the taps)
+            constexpr int R = 8, NJ = CCH * STAPS;
+            gv2f ar[R], br[R];
+            auto rd = [&](int j, gv2f& a, gv2f& b) {
+                const int g = j / STAPS, ts = j % STAPS;
+                const int kd = ts / (KS * KS), kh = (ts / KS) % KS, kw = ts % KS;
+                a = *reinterpret_cast<const gv2f*>(&sA[abase[0] + ((kd * HH + kh) * HW + kw) * VSL + g * 8]);
+                b = *reinterpret_cast<const gv2f*>(&sW[g * WFL + ts * 128 + bbase]);
+            };
+#pragma unroll
+            for (int j = 0; j < R; ++j) rd(j, ar[j], br[j]);
+            // the whole ring is in flight before the first MFMA (fake use: keeps the fill reads from trickling in)
+            static_assert(R == 8, "fake-use list");
+            asm volatile("" : "+v"(ar[0]), "+v"(ar[1]), "+v"(ar[2]), "+v"(ar[3]), "+v"(ar[4]), "+v"(ar[5]), "+v"(ar[6]),
+                         "+v"(ar[7]), "+v"(br[0]), "+v"(br[1]), "+v"(br[2]), "+v"(br[3]), "+v"(br[4]), "+v"(br[5]),
+                         "+v"(br[6]), "+v"(br[7]));
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const gv2f a = ar[j % R], b = br[j % R];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[0][0], 0, 0, 0);
+                if (j + R < NJ) rd(j + R, ar[j % R], br[j % R]);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[0][0], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (j + R < NJ) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            }
+        }
+    } else
     for (int c = 0; c < nchunk; c += CCH) {
         float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
         if (has_xf) {
