@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libctunet_hip.so")
+# CTUNET_HIP_LIB: load a differently built libctunet_hip.so (development A/B runs); there is no other fallback
+LIB_PATH = os.environ.get("CTUNET_HIP_LIB") or os.path.join(_HERE, "libctunet_hip.so")
 
 P = C.c_void_p          # device pointer / stream
 I = C.c_int
