@@ -1257,6 +1257,13 @@ static K3sGeom k3s_geom(int N, int D, int H, int W, int cin_p, int cout_p) {
     g.n_ci_g = ceil_div(cin_p, 16 / g.sm);
     g.pairs = g.n_ci_g * ceil_div(cout_p, 16 / g.sn);
     g.gx = wgrad_gx(g.ntiles, g.pairs);
+    // small layers: with fewer than 4 boxes per block the 27-tap slab a block writes (and the reduce kernel re-reads)
+    // outweighs its MFMA work -- one block per CU instead of two (64->64 @16^3: 28.4 -> 23.8 us, 32->32 @32^3: 34.4 -> 30.4)
+    if (g.ntiles / g.gx < 4) {
+        g.gx = (CTU_WG_BLOCKS / 2) / g.pairs;
+        if (g.gx < 1) g.gx = 1;
+        if (g.gx > g.ntiles) g.gx = g.ntiles;
+    }
     g.tpb = ceil_div(g.ntiles, g.gx);
     g.gx = ceil_div(g.ntiles, g.tpb);
     return g;
@@ -1334,6 +1341,13 @@ static UpWgGeom upwg_geom(int N, int D, int H, int W, int cin_p, int nout_p, boo
     g.n_co_g = ceil_div(nout_p, 16);
     g.pairs = 8 * g.n_ci_g * g.n_co_g;
     g.gx = wgrad_gx(g.ntiles, g.pairs);
+    // small layers: with fewer than 4 boxes per block the 27-tap slab a block writes (and the reduce kernel re-reads)
+    // outweighs its MFMA work -- one block per CU instead of two (64->64 @16^3: 28.4 -> 23.8 us, 32->32 @32^3: 34.4 -> 30.4)
+    if (g.ntiles / g.gx < 4) {
+        g.gx = (CTU_WG_BLOCKS / 2) / g.pairs;
+        if (g.gx < 1) g.gx = 1;
+        if (g.gx > g.ntiles) g.gx = g.ntiles;
+    }
     g.tpb = ceil_div(g.ntiles, g.gx);
     g.gx = ceil_div(g.ntiles, g.tpb);
     return g;
