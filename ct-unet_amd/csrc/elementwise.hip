@@ -21,7 +21,7 @@ extern "C" const char* ctu_arch(void) { return "gfx950"; }
 namespace {
 
 constexpr int EW_BLOCK = 256;
-constexpr int FIN_BLOCK = 1024;   // threads of the per-channel statistics finalisation
+constexpr int FIN_BLOCK = 256;    // threads of the per-channel statistics finalisation
 constexpr int MAX_RED_BLOCKS = 1024;
 
 // ------------------------------------------------------------------ layout
@@ -55,6 +55,20 @@ __global__ void ndhwc_to_ncdhw_kernel(const float* __restrict__ src, float* __re
     dst[(n * C + c) * V + v] = src[vox * cs + c];
 }
 
+// Sum of (a, b) over the NT threads of a block, in every thread: wave butterflies, one LDS exchange, a fixed-order sum
+// over the waves (deterministic; one barrier instead of a log2(NT)-step LDS tree -- these kernels are all latency).
+template <int NT>
+__device__ __forceinline__ void block_sum2(double& a, double& b) {
+    __shared__ double sm[2 * (NT / 64)];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+    if ((threadIdx.x & 63) == 0) { sm[(threadIdx.x >> 6) * 2] = a; sm[(threadIdx.x >> 6) * 2 + 1] = b; }
+    __syncthreads();
+    a = 0.0; b = 0.0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) { a += sm[w * 2]; b += sm[w * 2 + 1]; }
+}
+
 // ------------------------------------------------------------------ BN finalize
 __global__ void bn_finalize_kernel(const float* __restrict__ stats, int nblocks, int C, int cp, double count,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -62,7 +76,6 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stats, int nblocks,
                                    int n_updates, float* __restrict__ scale, float* __restrict__ shift,
                                    float* __restrict__ mean_out, float* __restrict__ invstd_out) {
     const int c = blockIdx.x;
-    __shared__ double r1[FIN_BLOCK], r2[FIN_BLOCK];
     double s1 = 0.0, s2 = 0.0;
     if (c < C) {
 #pragma unroll 4
@@ -71,16 +84,11 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stats, int nblocks,
             s2 += (double)stats[(size_t)b * 2 * cp + cp + c];
         }
     }
-    r1[threadIdx.x] = s1; r2[threadIdx.x] = s2;
-    __syncthreads();
-    for (int o = FIN_BLOCK / 2; o > 0; o >>= 1) {
-        if (threadIdx.x < o) { r1[threadIdx.x] += r1[threadIdx.x + o]; r2[threadIdx.x] += r2[threadIdx.x + o]; }
-        __syncthreads();
-    }
+    block_sum2<FIN_BLOCK>(s1, s2);
     if (threadIdx.x == 0) {
         if (c < C) {
-            const double mean = r1[0] / count;
-            double var = r2[0] / count - mean * mean;
+            const double mean = s1 / count;
+            double var = s2 / count - mean * mean;
             if (var < 0.0) var = 0.0;
             const float invstd = (float)(1.0 / sqrt(var + (double)eps));
             const float sc = gamma[c] * invstd;
@@ -166,26 +174,22 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int n
                                        float* __restrict__ coef, const float* __restrict__ mean,
                                        float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps) {
     const int c = blockIdx.x;
-    __shared__ double r1[EW_BLOCK], r2[EW_BLOCK];
     double s1 = 0.0, s2 = 0.0;
-    if (c < C)
-        for (int b = threadIdx.x; b < nb; b += blockDim.x) {
+    if (c < C) {
+#pragma unroll 4
+        for (int b = threadIdx.x; b < nb; b += EW_BLOCK) {
             s1 += (double)partials[(size_t)b * 2 * cp + c];
             s2 += (double)partials[(size_t)b * 2 * cp + cp + c];
         }
-    r1[threadIdx.x] = s1; r2[threadIdx.x] = s2;
-    __syncthreads();
-    for (int o = EW_BLOCK / 2; o > 0; o >>= 1) {
-        if (threadIdx.x < o) { r1[threadIdx.x] += r1[threadIdx.x + o]; r2[threadIdx.x] += r2[threadIdx.x + o]; }
-        __syncthreads();
     }
+    block_sum2<EW_BLOCK>(s1, s2);
     if (threadIdx.x == 0) {
         if (c < C) {
-            dbeta[c] = (float)r1[0];
-            dgamma[c] = (float)r2[0];
+            dbeta[c] = (float)s1;
+            dgamma[c] = (float)s2;
             coef[c] = gamma[c] * invstd[c];
-            coef[cp + c] = (float)(r1[0] / count);
-            coef[2 * cp + c] = (float)(r2[0] / count);
+            coef[cp + c] = (float)(s1 / count);
+            coef[2 * cp + c] = (float)(s2 / count);
             if (rmean) {
                 // the running-stat update torch.utils.checkpoint's recompute repeats in backward (models.py:232-255):
                 // same batch statistics as the forward update; the biased variance is recovered from invstd

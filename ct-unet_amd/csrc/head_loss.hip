@@ -340,10 +340,11 @@ __global__ void loss_final_kernel(float* __restrict__ ws, int N, int nbx, int64_
 __global__ __launch_bounds__(HB) void loss_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ tgt,
                                                       int N, int64_t V, float ce_lambda, float dice_lambda,
                                                       int dice_softmax, const float* __restrict__ tail,
-                                                      const float* __restrict__ gscale, float* __restrict__ gpred,
+                                                      const float* __restrict__ gscale_ce,
+                                                      const float* __restrict__ gscale_dice, float* __restrict__ gpred,
                                                       int accumulate) {
     const int n = blockIdx.y;
-    const float gs_ce = gscale ? gscale[0] : 1.f, gs_d = gscale ? gscale[1] : 1.f;
+    const float gs_ce = gscale_ce ? gscale_ce[0] : 1.f, gs_d = gscale_dice ? gscale_dice[0] : 1.f;
     const float kce = gs_ce * ce_lambda / ((float)N * (float)V);
     const float nume = tail[n * 2 + 0], dene = tail[n * 2 + 1];
     const float kd = gs_d * dice_lambda * (-2.f / (float)N);
@@ -457,12 +458,12 @@ extern "C" int ctu_loss_fwd(const float* pred, const float* target, int N, int64
 }
 
 extern "C" int ctu_loss_bwd(const float* pred, const float* target, int N, int64_t V, float ce_lambda,
-                            float dice_lambda, int dice_softmax, const float* ws, const float* gscale, float* gpred,
-                            int accumulate, void* stream) {
+                            float dice_lambda, int dice_softmax, const float* ws, const float* gscale_ce,
+                            const float* gscale_dice, float* gpred, int accumulate, void* stream) {
     CTU_REQUIRE(pred && target && ws && gpred && N > 0 && V > 0, "loss_bwd: bad argument");
     loss_bwd_kernel<<<dim3(LOSS_BX, N), HB, 0, (hipStream_t)stream>>>(pred, target, N, V, ce_lambda, dice_lambda,
                                                                       dice_softmax, ws + (size_t)N * LOSS_BX * 4,
-                                                                      gscale, gpred, accumulate);
+                                                                      gscale_ce, gscale_dice, gpred, accumulate);
     CTU_CHECK_LAUNCH("loss_bwd");
     return CTU_OK;
 }

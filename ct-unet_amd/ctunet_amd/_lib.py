@@ -69,7 +69,7 @@ SIGNATURES = {
     "ctu_head_bwd": (I, [P, I, I, P, P, I, P, P, P, I, I, I, I, P, P, P, I, P, P, P, I, L, P]),
     "ctu_loss_ws_floats": (Z, [I, L]),
     "ctu_loss_fwd": (I, [P, P, I, L, F, F, I, P, P, P]),
-    "ctu_loss_bwd": (I, [P, P, I, L, F, F, I, P, P, P, I, P]),
+    "ctu_loss_bwd": (I, [P, P, I, L, F, F, I, P, P, P, P, I, P]),
     "ctu_skip_add": (I, [P, I, P, P, I, P, I, P, P, I, P, I, I, L, P]),
     "ctu_upconv_fused_supported": (I, [I, I, I, I, I, I]),
     "ctu_upconv_fused_packed_floats": (Z, [I, I]),

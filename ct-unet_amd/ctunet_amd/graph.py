@@ -96,7 +96,9 @@ class GraphedTrainStep:
                 terms.append(ce)
             if self.dice:
                 terms.append(dc)
-        loss = sum(terms)
+        loss = terms[0]
+        for t in terms[1:]:
+            loss = loss + t
         loss.backward()
         if not self.distributed:
             self.opt.step()

@@ -35,9 +35,9 @@ class _FusedLoss(torch.autograd.Function):
     def backward(ctx, g_ce, g_dice):
         pred, target, ws = ctx.saved_tensors
         ce, dc, sm = ctx.cfg
-        z = torch.zeros((), device=pred.device)
-        gs = torch.stack([z if g_ce is None else g_ce.float(), z if g_dice is None else g_dice.float()])
-        gp = ops.loss_bwd(pred, target, ce, dc, sm, ws, gs)
+        # a term nobody differentiated contributes nothing (lambda 0); the other upstream scalars are read in place
+        gp = ops.loss_bwd(pred, target, ce if g_ce is not None else 0.0, dc if g_dice is not None else 0.0, sm, ws,
+                          None if g_ce is None else g_ce.float(), None if g_dice is None else g_dice.float())
         return gp, None, None, None, None
 
 
@@ -57,6 +57,14 @@ class dice_loss(nn.Module):
 
     def forward(self, output, masks):
         return fused_ce_dice(output, masks, 0.0, 1.0, False)[1]
+
+
+def _total(terms: Sequence[torch.Tensor]) -> torch.Tensor:
+    """terms[0] + terms[1] + ... (the builtin sum() starts from int 0: one more elementwise launch per step)."""
+    total = terms[0]
+    for t in terms[1:]:
+        total = total + t
+    return total
 
 
 def _append(lm: Dict[str, List], key: str, value) -> None:
@@ -86,7 +94,7 @@ def comp_losses_metrics_single(model, prediction, target, idx, n_imgs):
         keys.append("ce"); terms.append(ce)
     if dc_l != 0:
         keys.append("dice_loss"); terms.append(dc)
-    model.pt_loss = sum(terms)
+    model.pt_loss = _total(terms)
     _metrics(model, [("dice_coef", prediction, target)])
     _publish(model, keys, terms, idx, n_imgs, getattr(model, "verbose", True))
 
@@ -104,7 +112,7 @@ def comp_losses_metrics_double(model, prediction, target, idx, n_imgs):
         keys += ["ce_sk", "ce_fl"]; terms += [ce_s, ce_f]
     if dc_l != 0:
         keys += ["dice_loss_sk", "dice_loss_fl"]; terms += [dc_s, dc_f]
-    model.pt_loss = sum(terms)
+    model.pt_loss = _total(terms)
     _metrics(model, [("dice_coef_sk", sk_p, sk_t), ("dice_coef_fl", fl_p, fl_t)])
     _publish(model, keys, terms, idx, n_imgs, getattr(model, "verbose", True))
 

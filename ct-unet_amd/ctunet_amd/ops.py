@@ -478,15 +478,19 @@ def loss_fwd(pred: torch.Tensor, target: torch.Tensor, ce_lambda: float, dice_la
     return terms, ws
 
 
-def loss_bwd(pred, target, ce_lambda, dice_lambda, dice_softmax, ws, gscale: Optional[torch.Tensor],
-             out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+def loss_bwd(pred, target, ce_lambda, dice_lambda, dice_softmax, ws, g_ce: Optional[torch.Tensor],
+             g_dice: Optional[torch.Tensor], out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    """g_ce / g_dice: the upstream gradients of the two terms (0-d float32 device tensors, read in place; None = 1)."""
     pred, target = pred.contiguous(), target.contiguous()
+    for g_ in (g_ce, g_dice):
+        assert g_ is None or (g_.is_cuda and g_.dtype == torch.float32 and g_.numel() == 1)
     n = pred.shape[0]
     v = pred[0, 0].numel()
     g = out if out is not None else torch.empty_like(pred)
     lib = _lib.load()
     _lib.check(lib.ctu_loss_bwd(pred.data_ptr(), target.data_ptr(), n, v, ce_lambda, dice_lambda, int(dice_softmax),
-                                ws.data_ptr(), _ptr(gscale), g.data_ptr(), int(accumulate), _stream()), "loss_bwd")
+                                ws.data_ptr(), _ptr(g_ce), _ptr(g_dice), g.data_ptr(), int(accumulate), _stream()),
+               "loss_bwd")
     return g
 
 

@@ -246,14 +246,15 @@ int ctu_head_bwd(const float* in, int in_cs, int cin_p, const float* in_scale,
  *  dice term = dice_lambda * dice_loss(P, target), P = softmax(pred,1) if dice_softmax else pred
  * terms (device, float[2]) = {ce term, dice term}.  ws: ctu_loss_ws_floats(N, V) floats,
  * kept until ctu_loss_bwd, which writes
- *   gpred = gscale[0] * d(ce term)/dpred + gscale[1] * d(dice term)/dpred
- * (gscale: device float[2], NULL = {1,1}; accumulate != 0: gpred += ). */
+ *   gpred = gscale_ce[0] * d(ce term)/dpred + gscale_dice[0] * d(dice term)/dpred
+ * (gscale_*: one device float each -- the two upstream gradients autograd hands over, read in place; NULL = 1;
+ *  accumulate != 0: gpred += ). */
 size_t ctu_loss_ws_floats(int N, int64_t V);
 int ctu_loss_fwd(const float* pred, const float* target, int N, int64_t V, float ce_lambda,
                  float dice_lambda, int dice_softmax, float* terms, float* ws, void* stream);
 int ctu_loss_bwd(const float* pred, const float* target, int N, int64_t V, float ce_lambda,
-                 float dice_lambda, int dice_softmax, const float* ws, const float* gscale,
-                 float* gpred, int accumulate, void* stream);
+                 float dice_lambda, int dice_softmax, const float* ws, const float* gscale_ce,
+                 const float* gscale_dice, float* gpred, int accumulate, void* stream);
 
 /* -------------------------------------------------------------- utilities ---- */
 /* Additive skip connection, UNet(cat=False): out = act_a(a) + act_b(b) on channels-last tensors, where act_x is the

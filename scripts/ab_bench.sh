@@ -1,5 +1,5 @@
-# dev: whole-step A/B of two library builds on one box, alternating (ALT = the other build)
-for LIB in ct-unet_amd/ctunet_amd/libctunet_hip.so ${ALT:-scripts/build/lib_noxcd.so} ct-unet_amd/ctunet_amd/libctunet_hip.so ${ALT:-scripts/build/lib_noxcd.so}; do
+# dev: whole-step A/B of two library builds on one box, alternating (ALT = the other build; without it the shipped library runs twice)
+for LIB in ct-unet_amd/ctunet_amd/libctunet_hip.so $ALT ct-unet_amd/ctunet_amd/libctunet_hip.so $ALT; do
   CTUNET_HIP_LIB=$PWD/$LIB python bench.py --no-cpu-baseline > gpurun_out/ab_one.json 2>/dev/null || exit 1
   python -c "
 import json,sys

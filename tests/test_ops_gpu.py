@@ -383,9 +383,9 @@ def test_loss_fwd_bwd(ce, dice, sm):
     total.backward()
     tg, ws = ops.loss_fwd(p.detach().cuda(), t.cuda(), ce, dice, sm)
     assert abs(tg.sum().item() - total.item()) < 1e-5 * max(1.0, abs(total.item()))
-    gp = ops.loss_bwd(p.detach().cuda(), t.cuda(), ce, dice, sm, ws, None)
+    gp = ops.loss_bwd(p.detach().cuda(), t.cuda(), ce, dice, sm, ws, None, None)
     assert rel_err(gp.cpu(), p.grad) < 1e-4
-    gp2 = ops.loss_bwd(p.detach().cuda(), t.cuda(), ce, dice, sm, ws, torch.tensor([2.0, 2.0]).cuda(), gp.clone(), True)
+    gp2 = ops.loss_bwd(p.detach().cuda(), t.cuda(), ce, dice, sm, ws, torch.tensor(2.0).cuda(), torch.tensor(2.0).cuda(), gp.clone(), True)
     assert rel_err(gp2.cpu(), 3 * p.grad) < 1e-4
 
 
