@@ -776,7 +776,9 @@ __device__ __forceinline__ int weff_index(int t, int a) {                    // 
     return ((pz * 4 + py * 2 + px) * 8) + (jz * 4 + jy * 2 + jx);
 }
 
-// 8 lanes per output element; grid covers dWT (C*C*8), then dW3 (Co*C*27), then dbT (C)
+// 8 lanes per output element; grid covers dWT (C*C*8), then dW3 (Co*C*27), then dbT (C).  These sums are a few MFLOP:
+// the time is the number of cache lines a wave touches per load, so (a) the dWT lanes read their c_out runs of dW_eff / W3
+// as float4, (b) the dW3 outputs are dealt c_out-fastest: a wave's (c_in lane, c_out) pairs then read contiguous dW_eff rows.
 __global__ void upconv_project_kernel(const float* __restrict__ dweff, const float* __restrict__ V, const float* __restrict__ wtt,
                                       const float* __restrict__ w3t, const float* __restrict__ bt,
                                       const int32_t* __restrict__ imap, int C, int Co, int cin_p, int nout_p,
@@ -795,18 +797,24 @@ __global__ void upconv_project_kernel(const float* __restrict__ dweff, const flo
         for (int k = 0; k < 4; ++k) {                              // t = sub, sub + 8, sub + 16, sub + 24: independent chains
             const int t = sub + 8 * k;
             if (t < 27) {
-                const float* g = dweff + ((size_t)weff_index(t, a) * cin_p + pos) * nout_p;
-                const float* w = w3t + ((size_t)t * C + cm) * nout_p;
+                const float4* g = reinterpret_cast<const float4*>(dweff + ((size_t)weff_index(t, a) * cin_p + pos) * nout_p);
+                const float4* w = reinterpret_cast<const float4*>(w3t + ((size_t)t * C + cm) * nout_p);
                 float s = 0.f;
-#pragma unroll 8
-                for (int co = 0; co < Co; ++co) s = fmaf(g[co], w[co], s);
+                for (int c4 = 0; c4 * 4 < Co; ++c4) {              // (rows are nout_p = 8k floats: 16-byte aligned)
+                    const float4 gv = g[c4], wv = w[c4];
+                    const int co = c4 * 4;
+                    s = fmaf(gv.x, wv.x, s);
+                    if (co + 1 < Co) s = fmaf(gv.y, wv.y, s);
+                    if (co + 2 < Co) s = fmaf(gv.z, wv.z, s);
+                    if (co + 3 < Co) s = fmaf(gv.w, wv.w, s);
+                }
                 v += s;
             }
         }
         dst = dwt + idx;
-    } else if (idx < n1 + n2) {                                   // dW3[co][cm][t]
+    } else if (idx < n1 + n2) {                                   // dW3[co][cm][t], dealt co-fastest
         const int k = idx - n1;
-        const int t = k % 27, cm = (k / 27) % C, co = k / (27 * C);
+        const int co = k % Co, cm = (k / Co) % C, t = k / (Co * C);
 #pragma unroll
         for (int a = 0; a < 8; ++a) {                              // 8 independent chains
             const float* g = dweff + (size_t)weff_index(t, a) * cin_p * nout_p + co;
@@ -817,7 +825,7 @@ __global__ void upconv_project_kernel(const float* __restrict__ dweff, const flo
             v += s;
         }
         if (sub == 0) v = fmaf(V[t * nout_p + co], bt[cm], v);
-        dst = dw3 + k;
+        dst = dw3 + ((size_t)co * C + cm) * 27 + t;
     } else {                                                      // dbT[cm]
         const int cm = idx - n1 - n2;
         for (int t = sub; t < 27; t += 8) {
@@ -946,6 +954,7 @@ extern "C" int ctu_upconv_fused_project(const float* dweff, const float* gout, i
     CTU_REQUIRE(dweff && gout && bt && pack_ws && dwt && dbt && dw3 && ws, "upconv_fused_project: null pointer");
     CTU_REQUIRE(nout_p == 8 || nout_p == 16 || nout_p == 32 || nout_p == 64, "upconv_fused_project: nout_p=%d", nout_p);
     CTU_REQUIRE(C > 0 && Co > 0 && Co <= nout_p && g_cs >= nout_p && g_cs % 4 == 0, "upconv_fused_project: bad channels");
+    CTU_REQUIRE(((uintptr_t)dweff & 15) == 0 && ((uintptr_t)pack_ws & 15) == 0, "upconv_fused_project: dweff / pack_ws must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     float* tpart = ws;
     float* V = ws + (size_t)27 * FS_SPLIT * nout_p;
