@@ -289,15 +289,21 @@ __global__ void skip_add_kernel(const float* __restrict__ a, int a_cs, const flo
     *reinterpret_cast<float4*>(out + v * out_cs + qd * 4) = x;
 }
 
+// RED: the pooled tensor is relu(BN(raw conv output)) and gin is the gradient w.r.t. that activated tensor, complete once
+// this kernel has added its share -- so the BatchNorm-backward reduction of that layer (sum gz, sum gz * xhat per channel,
+// gz = gradient masked by the ReLU) rides along: one block-partial row per block, same layout as bn_relu_bwd_reduce.
+template <bool RED>
 __global__ void maxpool2_bwd_kernel(const float* __restrict__ in, int in_cs, int cp, const float* __restrict__ scale,
                                     const float* __restrict__ shift, int relu, const float* __restrict__ gout,
                                     int gout_cs, float* __restrict__ gin, int gin_cs, int accumulate, int N, int D,
-                                    int H, int W) {
+                                    int H, int W, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                    float* __restrict__ partials) {
     const int nq = cp >> 2;
     const int Do = D >> 1, Ho = H >> 1, Wo = W >> 1;
     const int64_t total = (int64_t)N * Do * Ho * Wo * nq;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
+    float4 a1 = make_float4(0.f, 0.f, 0.f, 0.f), a2 = a1;
+    if (idx < total) {
     const int qd = (int)(idx % nq);
     int64_t o = idx / nq;
     const int wo = (int)(o % Wo); o /= Wo;
@@ -310,7 +316,12 @@ __global__ void maxpool2_bwd_kernel(const float* __restrict__ in, int in_cs, int
         sc = *reinterpret_cast<const float4*>(scale + qd * 4);
         sh = *reinterpret_cast<const float4*>(shift + qd * 4);
     }
-    float4 vals[8];
+    float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), is = mu;
+    if constexpr (RED) {
+        mu = *reinterpret_cast<const float4*>(mean + qd * 4);
+        is = *reinterpret_cast<const float4*>(invstd + qd * 4);
+    }
+    float4 raw[8];
     float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
     int bi[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -318,8 +329,8 @@ __global__ void maxpool2_bwd_kernel(const float* __restrict__ in, int in_cs, int
         const int d = dd * 2 + (t >> 2), h = ho * 2 + ((t >> 1) & 1), w = wo * 2 + (t & 1);
         const size_t vox = (((size_t)n * D + d) * H + h) * W + w;
         float4 v = *reinterpret_cast<const float4*>(in + vox * in_cs + qd * 4);
+        raw[t] = v;
         if (xf) v = xform4(v, sc, sh, relu);
-        vals[t] = v;
         // first maximum in (d,h,w) scan order wins, as ATen's max_pool3d does (strict >)
         if (v.x > best.x) { best.x = v.x; bi[0] = t; }
         if (v.y > best.y) { best.y = v.y; bi[1] = t; }
@@ -339,6 +350,32 @@ __global__ void maxpool2_bwd_kernel(const float* __restrict__ in, int in_cs, int
         if (bi[2] == t) r.z += g.z;
         if (bi[3] == t) r.w += g.w;
         *gp = r;
+        if constexpr (RED) {
+            const float4 y = raw[t];
+            float gz;
+            gz = (fmaf(y.x, sc.x, sh.x) > 0.f) ? r.x : 0.f; a1.x += gz; a2.x += gz * (y.x - mu.x) * is.x;
+            gz = (fmaf(y.y, sc.y, sh.y) > 0.f) ? r.y : 0.f; a1.y += gz; a2.y += gz * (y.y - mu.y) * is.y;
+            gz = (fmaf(y.z, sc.z, sh.z) > 0.f) ? r.z : 0.f; a1.z += gz; a2.z += gz * (y.z - mu.z) * is.z;
+            gz = (fmaf(y.w, sc.w, sh.w) > 0.f) ? r.w : 0.f; a1.w += gz; a2.w += gz * (y.w - mu.w) * is.w;
+        }
+    }
+    }
+    if constexpr (RED) {
+        // thread t < cp sums channel t over the block's voxel lanes in a fixed order (threadIdx % nq is the channel quad)
+        __shared__ float red[EW_BLOCK * 8];
+        float* r = &red[threadIdx.x * 8];
+        r[0] = a1.x; r[1] = a1.y; r[2] = a1.z; r[3] = a1.w; r[4] = a2.x; r[5] = a2.y; r[6] = a2.z; r[7] = a2.w;
+        __syncthreads();
+        if (threadIdx.x < cp) {
+            const int c = threadIdx.x, q = c >> 2, j = c & 3;
+            float s1 = 0.f, s2 = 0.f;
+            for (int l = 0; l < EW_BLOCK / nq; ++l) {
+                s1 += red[(l * nq + q) * 8 + j];
+                s2 += red[(l * nq + q) * 8 + 4 + j];
+            }
+            partials[(size_t)blockIdx.x * 2 * cp + c] = s1;
+            partials[(size_t)blockIdx.x * 2 * cp + cp + c] = s2;
+        }
     }
 }
 
@@ -538,9 +575,28 @@ extern "C" int ctu_maxpool2_bwd(const float* in, int in_cs, int cp, const float*
     CTU_REQUIRE(in && gout && gin, "maxpool2_bwd: null pointer");
     CTU_REQUIRE(cp % 8 == 0 && cp > 0 && D % 2 == 0 && H % 2 == 0 && W % 2 == 0, "maxpool2_bwd: D,H,W must be even");
     const int64_t total = (int64_t)N * (D / 2) * (H / 2) * (W / 2) * (cp >> 2);
-    maxpool2_bwd_kernel<<<(unsigned)ceil_div64(total, EW_BLOCK), EW_BLOCK, 0, (hipStream_t)stream>>>(
-        in, in_cs, cp, in_scale, in_shift, in_relu, gout, gout_cs, gin, gin_cs, accumulate, N, D, H, W);
+    maxpool2_bwd_kernel<false><<<(unsigned)ceil_div64(total, EW_BLOCK), EW_BLOCK, 0, (hipStream_t)stream>>>(
+        in, in_cs, cp, in_scale, in_shift, in_relu, gout, gout_cs, gin, gin_cs, accumulate, N, D, H, W, nullptr, nullptr, nullptr);
     CTU_CHECK_LAUNCH("maxpool2_bwd");
+    return CTU_OK;
+}
+
+extern "C" int ctu_maxpool2_bwd_bn_num_blocks(int N, int D, int H, int W, int cp) {
+    // 0 = not available for this channel count (the in-block reduction needs threadIdx % (cp/4) to be the channel quad)
+    if (cp <= 0 || cp % 8 != 0 || cp > EW_BLOCK || EW_BLOCK % (cp >> 2) != 0) return 0;
+    return (int)ceil_div64((int64_t)N * (D / 2) * (H / 2) * (W / 2) * (cp >> 2), EW_BLOCK);
+}
+
+extern "C" int ctu_maxpool2_bwd_bn(const float* in, int in_cs, int cp, const float* in_scale, const float* in_shift,
+                                   const float* mean, const float* invstd, const float* gout, int gout_cs, float* gin,
+                                   int gin_cs, int accumulate, int N, int D, int H, int W, float* partials, void* stream) {
+    CTU_REQUIRE(in && gout && gin && in_scale && in_shift && mean && invstd && partials, "maxpool2_bwd_bn: null pointer");
+    CTU_REQUIRE(cp % 8 == 0 && cp > 0 && cp <= EW_BLOCK && EW_BLOCK % (cp >> 2) == 0 && D % 2 == 0 && H % 2 == 0 && W % 2 == 0,
+                "maxpool2_bwd_bn: cp=%d must be a multiple of 8 whose quads divide the block; D,H,W even", cp);
+    const int nb = ctu_maxpool2_bwd_bn_num_blocks(N, D, H, W, cp);
+    maxpool2_bwd_kernel<true><<<nb, EW_BLOCK, 0, (hipStream_t)stream>>>(
+        in, in_cs, cp, in_scale, in_shift, 1, gout, gout_cs, gin, gin_cs, accumulate, N, D, H, W, mean, invstd, partials);
+    CTU_CHECK_LAUNCH("maxpool2_bwd_bn");
     return CTU_OK;
 }
 

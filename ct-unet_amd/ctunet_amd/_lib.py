@@ -58,6 +58,8 @@ SIGNATURES = {
     "ctu_bn_relu_bwd_apply": (I, [P, I, P, I, I, P, P, P, P, P, L, P]),
     "ctu_maxpool2_fwd": (I, [P, I, I, P, P, I, P, I, I, I, I, I, P]),
     "ctu_maxpool2_bwd": (I, [P, I, I, P, P, I, P, I, P, I, I, I, I, I, I, P]),
+    "ctu_maxpool2_bwd_bn_num_blocks": (I, [I, I, I, I, I]),
+    "ctu_maxpool2_bwd_bn": (I, [P, I, I, P, P, P, P, P, I, P, I, I, I, I, I, I, P, P]),
     "ctu_convt_packed_floats": (Z, [I, I]),
     "ctu_pack_convt_weight": (I, [P, P, I, I, P, I, I, I, P]),
     "ctu_convt2_fwd": (I, [P, I, I, P, P, I, P, P, I, P, I, I, I, I, I, I, P]),

@@ -31,6 +31,8 @@ BN_EPS = 1e-5
 # decoder ConvTranspose3d -> Conv3d pairs run as one coarse-grid kernel (CTUNET_FUSE_UP=0: the two separate kernels)
 FUSE_UP = os.environ.get("CTUNET_FUSE_UP", "1") != "0"
 FUSE_UP_MAX_CO = int(os.environ.get("CTUNET_FUSE_UP_MAXCO", "16"))     # widest (padded) conv output that takes the fused path
+# the max-pool backward also emits the BatchNorm-backward reduction of the layer it pools (CTUNET_POOL_BN=0: separate pass)
+POOL_BN = os.environ.get("CTUNET_POOL_BN", "1") != "0"
 BN_MOMENTUM = 0.1
 
 
@@ -353,14 +355,15 @@ class UNetEngine:
         return out0, out1, ctx
 
     # ------------------------------------------------------------------ backward pieces
-    def _conv_bn_bwd(self, P, rec: _ConvRec, ga: CL, gin: Optional[CL], grads: Dict[str, torch.Tensor], ws, part):
+    def _conv_bn_bwd(self, P, rec: _ConvRec, ga: CL, gin: Optional[CL], grads: Dict[str, torch.Tensor], ws, part,
+                     pre_reduced: Optional[int] = None):
         """ga: gradient w.r.t. the ACTIVATED output (overwritten with the raw-output gradient).
         gin: where to write the gradient w.r.t. this conv's activated input (None: not needed)."""
         k = self.plan.k
         # use_checkpoint=True: the recompute in backward repeats every live BN's running-stat update
         # (models.py:232-255; SURVEY K10) -- folded into this BN's backward finalize
         replay = (P[rec.bn + ".running_mean"], P[rec.bn + ".running_var"], BN_MOMENTUM, BN_EPS) if self._replay_stats else None
-        dg, db = ops.bn_relu_bwd(rec.y, ga, rec.vec, P[rec.bn + ".weight"].detach(), rec.cout, part, replay)
+        dg, db = ops.bn_relu_bwd(rec.y, ga, rec.vec, P[rec.bn + ".weight"].detach(), rec.cout, part, replay, pre_reduced)
         grads[rec.bn + ".weight"], grads[rec.bn + ".bias"] = dg, db
         if rec.first is not None:                  # direct C_in <= 2 kernels; gin is a request flag here
             grads[rec.conv + ".weight"] = ops.conv_first_wgrad(rec.first, ga, rec.cout, ws)
@@ -406,6 +409,8 @@ class UNetEngine:
             part_n = max(part_n, ops.bn_bwd_partials_floats(r.y.nvox, r.y.cp))
         for x_in, blk in zip(ctx["dec_in"], plan.dec):
             ws_n = max(ws_n, ops.convt_wgrad_ws(x_in.dims, x_in.cp, pad8(blk.cin)))
+        for dsk in ctx["dskip"]:
+            part_n = max(part_n, ops.maxpool_bwd_bn_blocks(dsk.dims, dsk.cp) * 2 * dsk.cp)
         ws = torch.empty(ws_n, dtype=torch.float32, device=dev)
         part = torch.empty(part_n, dtype=torch.float32, device=dev)
 
@@ -498,9 +503,14 @@ class UNetEngine:
             cp = pad8(blk.cout)
             r1, r2 = recs[(blk.prefix, 1)], recs[(blk.prefix, 2)]
             g_d2 = CL(gcat[i], cp, cp)
-            ops.maxpool_bwd(ctx["dskip"][i], g_pool, g_d2, plan.skip != "none")     # accumulate onto the skip's gradient
+            # accumulate onto the skip's gradient; g_d2 is then complete, so the pass also carries the reduction of r2's
+            # BatchNorm backward (the pooled tensor is that BatchNorm's activated output)
+            dsk = ctx["dskip"][i]
+            fuse = (POOL_BN and dsk.scale is not None and dsk.relu and dsk.scale.data_ptr() == r2.vec[0].data_ptr()
+                    and ops.maxpool_bwd_bn_blocks(dsk.dims, dsk.cp) > 0)
+            nb = ops.maxpool_bwd(dsk, g_pool, g_d2, plan.skip != "none", (r2.vec, part) if fuse else None)
             g_d1 = CL(torch.empty_like(r1.y.buf), 0, cp)
-            self._conv_bn_bwd(P, r2, g_d2, g_d1, grads, ws, part)
+            self._conv_bn_bwd(P, r2, g_d2, g_d1, grads, ws, part, nb)
             if i > 0:
                 g_pool = CL(torch.empty_like(ctx["pooled"][i - 1].buf), 0, ctx["pooled"][i - 1].cp)
                 self._conv_bn_bwd(P, r1, g_d1, g_pool, grads, ws, part)

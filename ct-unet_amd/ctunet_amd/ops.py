@@ -341,19 +341,20 @@ def bn_eval_affine(gamma, beta, rmean, rvar, eps, c, cp):
 
 
 def bn_relu_bwd(y: CL, ga: CL, vec: torch.Tensor, gamma: torch.Tensor, c: int, partials: torch.Tensor,
-                replay=None):
+                replay=None, pre_reduced: Optional[int] = None):
     """In place: ga <- gradient w.r.t. the raw conv output y.  Returns (dgamma, dbeta).
     replay = (running_mean, running_var, momentum, eps): also apply the running-stat update a second time (the one
     torch.utils.checkpoint's recompute performs in backward, models.py:232-255)."""
     lib = _lib.load()
     nvox = y.nvox
     cp = y.cp
-    nb = lib.ctu_bn_bwd_num_blocks(nvox)
+    nb = lib.ctu_bn_bwd_num_blocks(nvox) if pre_reduced is None else pre_reduced
     assert partials.numel() >= nb * 2 * cp
     sc, sh, mu, istd = (vec[i].data_ptr() for i in range(4))
     st = _stream()
-    _lib.check(lib.ctu_bn_relu_bwd_reduce(y.ptr, y.cs, ga.ptr, ga.cs, cp, sc, sh, mu, istd, nvox, partials.data_ptr(),
-                                          st), "bn_relu_bwd_reduce")
+    if pre_reduced is None:       # (else: the kernel that produced ga wrote the nb reduction rows, maxpool_bwd(bn=...))
+        _lib.check(lib.ctu_bn_relu_bwd_reduce(y.ptr, y.cs, ga.ptr, ga.cs, cp, sc, sh, mu, istd, nvox, partials.data_ptr(),
+                                              st), "bn_relu_bwd_reduce")
     dgb = torch.empty((2, c), dtype=torch.float32, device=y.buf.device)
     coef = torch.empty((3, cp), dtype=torch.float32, device=y.buf.device)
     rm, rv, mom, eps = replay if replay is not None else (None, None, 0.0, 0.0)
@@ -377,9 +378,25 @@ def maxpool_fwd(x: CL, out: CL) -> None:
                                     n, d, h, w, _stream()), "maxpool2_fwd")
 
 
-def maxpool_bwd(x: CL, gout: CL, gin: CL, accumulate: bool) -> None:
+def maxpool_bwd_bn_blocks(dims, cp: int) -> int:
+    n, d, h, w = dims
+    return _lib.load().ctu_maxpool2_bwd_bn_num_blocks(n, d, h, w, cp)
+
+
+def maxpool_bwd(x: CL, gout: CL, gin: CL, accumulate: bool, bn=None) -> Optional[int]:
+    """bn = (vec [4, cp] scale/shift/mean/invstd of x's BatchNorm, partials): also emit that BatchNorm's backward
+    reduction rows into partials; returns their number (pass it to bn_relu_bwd(pre_reduced=...))."""
     n, d, h, w = x.dims
     lib = _lib.load()
+    if bn is not None:
+        vec, partials = bn
+        nb = lib.ctu_maxpool2_bwd_bn_num_blocks(n, d, h, w, x.cp)
+        assert x.scale is not None and x.relu and partials.numel() >= nb * 2 * x.cp
+        assert vec[0].data_ptr() == x.scale.data_ptr() and vec[1].data_ptr() == x.shift.data_ptr()
+        _lib.check(lib.ctu_maxpool2_bwd_bn(x.ptr, x.cs, x.cp, vec[0].data_ptr(), vec[1].data_ptr(), vec[2].data_ptr(),
+                                           vec[3].data_ptr(), gout.ptr, gout.cs, gin.ptr, gin.cs, int(accumulate), n, d, h, w,
+                                           partials.data_ptr(), _stream()), "maxpool2_bwd_bn")
+        return nb
     _lib.check(lib.ctu_maxpool2_bwd(x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), gout.ptr, gout.cs,
                                     gin.ptr, gin.cs, int(accumulate), n, d, h, w, _stream()), "maxpool2_bwd")
 

@@ -193,6 +193,16 @@ int ctu_maxpool2_bwd(const float* in, int in_cs, int cp, const float* in_scale,
                      const float* in_shift, int in_relu, const float* gout, int gout_cs,
                      float* gin, int gin_cs, int accumulate, int N, int D, int H, int W,
                      void* stream);
+/* The same, when in is the raw output of a conv whose train-mode BatchNorm + ReLU (in_scale/in_shift, mean/invstd) the
+ * pooled tensor is, and gin is complete after this call (the reference's encoder: pool(block(x)), models.py:233-246,
+ * with the skip's share already in gin): also emits that BatchNorm's backward reduction -- one row {sum gz[c], sum
+ * gz[c]*xhat[c]} per block, ctu_maxpool2_bwd_bn_num_blocks rows of 2*cp floats, consumed by ctu_bn_bwd_finalize in place
+ * of ctu_bn_relu_bwd_reduce's rows (saves one pass over y and the gradient).  ctu_maxpool2_bwd_bn_num_blocks returns 0
+ * for channel counts the fused form does not take (cp/4 must divide 256): use ctu_maxpool2_bwd + the separate reduce. */
+int ctu_maxpool2_bwd_bn_num_blocks(int N, int D, int H, int W, int cp);
+int ctu_maxpool2_bwd_bn(const float* in, int in_cs, int cp, const float* in_scale, const float* in_shift,
+                        const float* mean, const float* invstd, const float* gout, int gout_cs, float* gin,
+                        int gin_cs, int accumulate, int N, int D, int H, int W, float* partials, void* stream);
 
 /* -------------------------------------------------- ConvTranspose3d k2 s2 ---- */
 /* nn.ConvTranspose3d(C, C, 2, 2) with bias (models.py:37,427-429):

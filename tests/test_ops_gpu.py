@@ -292,6 +292,47 @@ def test_maxpool_fwd_bwd(shape, xf):
         assert torch.allclose(got - base, xa.grad)
 
 
+@pytest.mark.parametrize("shape", [(1, 8, 8, 8, 8), (2, 7, 4, 6, 10), (1, 64, 4, 4, 4), (1, 16, 16, 16, 32)])
+def test_maxpool_bwd_with_bn_reduction(shape):
+    """maxpool_bwd(bn=...) + bn_relu_bwd(pre_reduced=...) vs autograd of skip + max_pool3d(relu(batch_norm(y))):
+    the pool backward adds its share to the skip's gradient and emits the BatchNorm-backward reduction rows itself."""
+    ops = _ops()
+    n, c, d, h, w = shape
+    cp = ops.pad8(c)
+    y = (torch.randn(shape, generator=g(1)) * 1.3 + 0.2)
+    gamma = torch.rand(c, generator=g(2)) + 0.25
+    beta = torch.randn(c, generator=g(3)) * 0.2
+    yr = y.clone().requires_grad_(True); gr = gamma.clone().requires_grad_(True); br = beta.clone().requires_grad_(True)
+    a = F.relu(F.batch_norm(yr, None, None, gr, br, True, 0.1, 1e-5))
+    gskip = torch.randn(shape, generator=g(4))                  # the concat consumer's gradient w.r.t. a
+    gpool = torch.randn(n, c, d // 2, h // 2, w // 2, generator=g(5))
+    ((a * gskip).sum() + (F.max_pool3d(a, 2, 2) * gpool).sum()).backward()
+    # ours: batch statistics through the channel-sum partials of an identity conv, as in test_batchnorm_train_fwd_bwd
+    wt = torch.zeros(c, c, 3, 3, 3); wt[range(c), range(c), 1, 1, 1] = 1.0
+    wp = ops.pack_conv_w(wt.cuda(), None, cp, cp, 0)
+    out = ops.CL(torch.empty(n, d, h, w, cp, device="cuda"), 0, cp)
+    nb = ops.conv_num_blocks((n, d, h, w), cp, 0, 3)
+    stats = torch.zeros(nb, 2, cp, device="cuda")
+    ops.conv3d_fwd(to_cl(y), wp, None, out, 3, stats)
+    vec = ops.bn_finalize(stats, nb, c, cp, n * d * h * w, gamma.cuda(), beta.cuda(), torch.zeros(c).cuda(), torch.ones(c).cuda(),
+                          0.1, 1e-5, 1)
+    act = out.with_xf(vec[0], vec[1], True)
+    res = {}
+    for fused in (False, True):
+        ga = to_cl(gskip)
+        part = torch.empty(max(ops.bn_bwd_partials_floats(n * d * h * w, cp), ops.maxpool_bwd_bn_blocks((n, d, h, w), cp) * 2 * cp),
+                           device="cuda")
+        rows = ops.maxpool_bwd(act, to_cl(gpool), ga, True, (vec, part) if fused else None)
+        assert (rows is not None) == fused
+        dgam, dbet = ops.bn_relu_bwd(out, ga, vec, gamma.cuda(), c, part, None, rows)
+        torch.cuda.synchronize()
+        res[fused] = (dgam.cpu(), dbet.cpu(), from_cl(ga, c))
+        assert rel_err(dgam.cpu(), gr.grad) < 1e-4
+        assert rel_err(dbet.cpu(), br.grad) < 1e-4
+        assert rel_err(from_cl(ga, c), yr.grad) < 2e-4
+    assert rel_err(res[True][2], res[False][2]) < 1e-5
+
+
 @pytest.mark.parametrize("case", [(1, 8, 8, 4, 4, 4, False), (2, 32, 32, 4, 6, 10, True), (1, 14, 14, 4, 4, 4, True),
                                   (1, 128, 128, 2, 2, 2, True), (1, 6, 6, 1, 1, 1, False)])
 def test_convtranspose(case):
