@@ -117,13 +117,18 @@ __global__ __launch_bounds__(HB) void head_fwd_kernel(HeadP p, float* __restrict
 // the streaming loop is hidden by occupancy instead of being latency-bound at one voxel per 64-accumulator thread).
 // Logits are quad partial sums reduced across the voxel's lanes; block partials keep the layout above.
 template <int CP>
+// bn_partials != NULL: the first bn_cp input channels are relu(BN(raw conv output)) of ONE layer whose activated-output
+// gradient is complete with this kernel's gin (the decoder's last conv feeding the head): the kernel also emits that
+// BatchNorm's backward reduction rows {sum gz, sum gz * xhat} per block (layout of bn_relu_bwd_reduce).
 __global__ __launch_bounds__(HB) void head_bwd_q_kernel(HeadP p, const float* __restrict__ g0,
                                                         const float* __restrict__ g1, float* __restrict__ gin,
-                                                        int gin_cs, float* __restrict__ partials) {
+                                                        int gin_cs, float* __restrict__ partials,
+                                                        const float* __restrict__ bn_mean, const float* __restrict__ bn_invstd,
+                                                        int bn_cp, float* __restrict__ bn_partials) {
     constexpr int Q = CP / 4;
     __shared__ float sWp[MAXCO * CP];
     __shared__ float sB[MAXCO];
-    __shared__ float sRed[HB / 64][MAXCO * CP + MAXCO];
+    __shared__ float sRed[HB / 64][MAXCO * CP + MAXCO + 2 * CP];
     head_load_weights<CP>(p, sWp, sB);
     const int qd = threadIdx.x % Q;
     float wq[MAXCO][4], dw[MAXCO][4], db[MAXCO];
@@ -139,10 +144,17 @@ __global__ __launch_bounds__(HB) void head_bwd_q_kernel(HeadP p, const float* __
         sh = *reinterpret_cast<const float4*>(p.in_shift + qd * 4);
     }
     const int xrelu = p.in_scale ? p.in_relu : 0;
+    const bool bnq = bn_partials != nullptr && qd * 4 < bn_cp;
+    float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), is = mu, r1 = mu, r2 = mu;
+    if (bnq) {
+        mu = *reinterpret_cast<const float4*>(bn_mean + qd * 4);
+        is = *reinterpret_cast<const float4*>(bn_invstd + qd * 4);
+    }
     const int64_t total = (int64_t)p.N * p.V;
     constexpr int VPB = HB / Q;                       // voxels per block and iteration
     for (int64_t gv = (int64_t)blockIdx.x * VPB + threadIdx.x / Q; gv < total; gv += (int64_t)gridDim.x * VPB) {
-        const float4 a = xform4(*reinterpret_cast<const float4*>(p.in + (size_t)gv * p.in_cs + qd * 4), sc, sh, xrelu);
+        const float4 raw = *reinterpret_cast<const float4*>(p.in + (size_t)gv * p.in_cs + qd * 4);
+        const float4 a = xform4(raw, sc, sh, xrelu);
         float lg[MAXCO], u[MAXCO], y[MAXCO], gy[MAXCO];
 #pragma unroll
         for (int co = 0; co < MAXCO; ++co) {
@@ -211,8 +223,25 @@ __global__ __launch_bounds__(HB) void head_bwd_q_kernel(HeadP p, const float* __
             for (int j = 0; j < 4; ++j) dw[co][j] = fmaf(gl[co], av[j], dw[co][j]);
         }
         *reinterpret_cast<float4*>(gin + (size_t)gv * gin_cs + qd * 4) = o;
+        if (bnq) {
+            float gz;
+            gz = (fmaf(raw.x, sc.x, sh.x) > 0.f) ? o.x : 0.f; r1.x += gz; r2.x += gz * (raw.x - mu.x) * is.x;
+            gz = (fmaf(raw.y, sc.y, sh.y) > 0.f) ? o.y : 0.f; r1.y += gz; r2.y += gz * (raw.y - mu.y) * is.y;
+            gz = (fmaf(raw.z, sc.z, sh.z) > 0.f) ? o.z : 0.f; r1.z += gz; r2.z += gz * (raw.z - mu.z) * is.z;
+            gz = (fmaf(raw.w, sc.w, sh.w) > 0.f) ? o.w : 0.f; r1.w += gz; r2.w += gz * (raw.w - mu.w) * is.w;
+        }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (bn_partials) {
+        const float rv[8] = {r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float s = rv[j];
+#pragma unroll
+            for (int o = 32; o >= Q; o >>= 1) s += __shfl_xor(s, o);        // over the lanes that own this quad
+            if (lane < Q) sRed[wave][MAXCO * CP + MAXCO + (j >> 2) * CP + lane * 4 + (j & 3)] = s;
+        }
+    }
 #pragma unroll
     for (int co = 0; co < MAXCO; ++co) {
 #pragma unroll
@@ -232,6 +261,14 @@ __global__ __launch_bounds__(HB) void head_bwd_q_kernel(HeadP p, const float* __
         for (int w = 0; w < HB / 64; ++w) s += sRed[w][i];
         partials[(size_t)blockIdx.x * (MAXCO * CP + MAXCO) + i] = s;
     }
+    if (bn_partials)
+        for (int i = threadIdx.x; i < 2 * bn_cp; i += HB) {
+            const int col = MAXCO * CP + MAXCO + (i / bn_cp) * CP + i % bn_cp;
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < HB / 64; ++w) s += sRed[w][col];
+            bn_partials[(size_t)blockIdx.x * 2 * bn_cp + i] = s;
+        }
 }
 
 // one block per output (dW element or db element); fixed-order tree over the block partials
@@ -414,27 +451,40 @@ extern "C" size_t ctu_head_bwd_ws_floats(int N, int64_t nvox_per_item, int cin_p
     return (size_t)head_blocks((int64_t)N * nvox_per_item) * (MAXCO * cin_p + MAXCO);
 }
 
+extern "C" int ctu_head_bwd_num_blocks(int N, int64_t nvox_per_item) { return head_blocks((int64_t)N * nvox_per_item); }
+
 extern "C" int ctu_head_bwd(const float* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
                             int in_relu, const float* w, const float* bias, const int32_t* imap, int Ci, int Co, int act,
                             int head_mode, const float* g0, const float* g1, float* gin, int gin_cs, float* dw,
                             float* db, float* ws, int N, int64_t nvox_per_item, void* stream) {
+    return ctu_head_bwd_bn(in, in_cs, cin_p, in_scale, in_shift, in_relu, w, bias, imap, Ci, Co, act, head_mode, g0, g1, gin,
+                           gin_cs, dw, db, ws, N, nvox_per_item, nullptr, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int ctu_head_bwd_bn(const float* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
+                               int in_relu, const float* w, const float* bias, const int32_t* imap, int Ci, int Co, int act,
+                               int head_mode, const float* g0, const float* g1, float* gin, int gin_cs, float* dw,
+                               float* db, float* ws, int N, int64_t nvox_per_item, const float* bn_mean,
+                               const float* bn_invstd, int bn_cp, float* bn_partials, void* stream) {
     HeadP p;
     int rc = fill_head(p, in, in_cs, cin_p, in_scale, in_shift, in_relu, w, bias, imap, Ci, Co, act, head_mode, N,
                        nvox_per_item, "head_bwd");
     if (rc != CTU_OK) return rc;
     CTU_REQUIRE(g0 && (head_mode == 0 || g1) && gin && dw && db && ws, "head_bwd: null pointer");
     CTU_REQUIRE(gin_cs >= cin_p && gin_cs % 4 == 0, "head_bwd: bad gin stride");
+    CTU_REQUIRE(!bn_partials || (bn_mean && bn_invstd && in_scale && in_relu && bn_cp > 0 && bn_cp % 4 == 0 && bn_cp <= cin_p),
+                "head_bwd: the BatchNorm reduction needs mean/invstd, a BN+ReLU input transform and bn_cp <= cin_p (bn_cp=%d)", bn_cp);
     const int nb = head_blocks((int64_t)N * nvox_per_item);
     hipStream_t st = (hipStream_t)stream;
     const int nfin = Co * Ci + Co;
     if (cin_p == 8) {
-        head_bwd_q_kernel<8><<<nb, HB, 0, st>>>(p, g0, g1, gin, gin_cs, ws);
+        head_bwd_q_kernel<8><<<nb, HB, 0, st>>>(p, g0, g1, gin, gin_cs, ws, bn_mean, bn_invstd, bn_cp, bn_partials);
         head_bwd_final_kernel<8><<<nfin, HB, 0, st>>>(ws, nb, Ci, Co, imap, dw, db);
     } else if (cin_p == 16) {
-        head_bwd_q_kernel<16><<<nb, HB, 0, st>>>(p, g0, g1, gin, gin_cs, ws);
+        head_bwd_q_kernel<16><<<nb, HB, 0, st>>>(p, g0, g1, gin, gin_cs, ws, bn_mean, bn_invstd, bn_cp, bn_partials);
         head_bwd_final_kernel<16><<<nfin, HB, 0, st>>>(ws, nb, Ci, Co, imap, dw, db);
     } else {
-        head_bwd_q_kernel<32><<<nb, HB, 0, st>>>(p, g0, g1, gin, gin_cs, ws);
+        head_bwd_q_kernel<32><<<nb, HB, 0, st>>>(p, g0, g1, gin, gin_cs, ws, bn_mean, bn_invstd, bn_cp, bn_partials);
         head_bwd_final_kernel<32><<<nfin, HB, 0, st>>>(ws, nb, Ci, Co, imap, dw, db);
     }
     CTU_CHECK_LAUNCH("head_bwd");

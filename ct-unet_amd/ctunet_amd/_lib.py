@@ -69,6 +69,8 @@ SIGNATURES = {
     "ctu_head_fwd": (I, [P, I, I, P, P, I, P, P, P, I, I, I, I, P, P, I, L, P]),
     "ctu_head_bwd_ws_floats": (Z, [I, L, I, I]),
     "ctu_head_bwd": (I, [P, I, I, P, P, I, P, P, P, I, I, I, I, P, P, P, I, P, P, P, I, L, P]),
+    "ctu_head_bwd_num_blocks": (I, [I, L]),
+    "ctu_head_bwd_bn": (I, [P, I, I, P, P, I, P, P, P, I, I, I, I, P, P, P, I, P, P, P, I, L, P, P, I, P, P]),
     "ctu_loss_ws_floats": (Z, [I, L]),
     "ctu_loss_fwd": (I, [P, P, I, L, F, F, I, P, P, P]),
     "ctu_loss_bwd": (I, [P, P, I, L, F, F, I, P, P, P, P, I, P]),

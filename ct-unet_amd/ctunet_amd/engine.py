@@ -411,6 +411,7 @@ class UNetEngine:
             ws_n = max(ws_n, ops.convt_wgrad_ws(x_in.dims, x_in.cp, pad8(blk.cin)))
         for dsk in ctx["dskip"]:
             part_n = max(part_n, ops.maxpool_bwd_bn_blocks(dsk.dims, dsk.cp) * 2 * dsk.cp)
+        part_n = max(part_n, ops.head_bwd_blocks(ctx["head_in"].dims) * 2 * pad8(plan.dec[-1].cout))
         ws = torch.empty(ws_n, dtype=torch.float32, device=dev)
         part = torch.empty(part_n, dtype=torch.float32, device=dev)
 
@@ -439,8 +440,18 @@ class UNetEngine:
                 half = gcat[level].shape[-1] // 2
                 ops.skip_add(CL(gcat[level], 0, half), None, CL(gcat[level], half, half))
 
-        dwl, dbl = ops.head_bwd(head_in, w2, bl.detach(), ctx["imap_h"], plan.act, plan.head_mode, g0.contiguous(),
-                                None if g1 is None else g1.contiguous(), g_skip_target(0))
+        # the head's input gradient completes the activated-output gradient of the last decoder conv: its BatchNorm-backward
+        # reduction rides on the head backward (as the encoder ones ride on the max-pool backward)
+        r_last = recs[(plan.dec[-1].prefix, 2)]
+        head_rows = None
+        if (POOL_BN and head_in.scale is not None and head_in.relu and head_in.scale.data_ptr() == r_last.vec[0].data_ptr()
+                and head_in.c0 == r_last.y.c0 and head_in.buf is r_last.y.buf):
+            dwl, dbl, head_rows = ops.head_bwd(head_in, w2, bl.detach(), ctx["imap_h"], plan.act, plan.head_mode,
+                                               g0.contiguous(), None if g1 is None else g1.contiguous(), g_skip_target(0),
+                                               (r_last.vec, part))
+        else:
+            dwl, dbl = ops.head_bwd(head_in, w2, bl.detach(), ctx["imap_h"], plan.act, plan.head_mode, g0.contiguous(),
+                                    None if g1 is None else g1.contiguous(), g_skip_target(0))
         g_skip_fanout(0)
         grads[plan.head + ".weight"], grads[plan.head + ".bias"] = dwl.reshape(wl.shape), dbl
         emit()
@@ -453,7 +464,7 @@ class UNetEngine:
             r1, r2 = recs[(blk.prefix, 1)], recs[(blk.prefix, 2)]
             g_u2 = CL(gcat[i], 0, cp)
             g_u1 = CL(torch.empty_like(r1.y.buf), 0, cp)
-            self._conv_bn_bwd(P, r2, g_u2, g_u1, grads, ws, part)
+            self._conv_bn_bwd(P, r2, g_u2, g_u1, grads, ws, part, head_rows if j == nlev - 1 else None)
             x_in = ctx["dec_in"][j]
             ct = blk.cin
             if j > 0 and plan.skip == "cat":

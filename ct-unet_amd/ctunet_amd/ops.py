@@ -464,7 +464,9 @@ def head_fwd(x: CL, w: torch.Tensor, b: torch.Tensor, imap, act: int, head_mode:
 
 
 def head_bwd(x: CL, w: torch.Tensor, b: torch.Tensor, imap, act: int, head_mode: int, g0: torch.Tensor,
-             g1: Optional[torch.Tensor], gin: CL):
+             g1: Optional[torch.Tensor], gin: CL, bn=None):
+    """bn = (vec [4, bn_cp] of the BatchNorm whose activated output is x's first bn_cp channels, partials): also emit
+    that BatchNorm's backward reduction rows; returns (dw, db, rows) then (rows -> bn_relu_bwd(pre_reduced=...))."""
     n, d, h, w_ = x.dims
     co, ci = w.shape[0], w.shape[1]
     v = d * h * w_
@@ -473,10 +475,25 @@ def head_bwd(x: CL, w: torch.Tensor, b: torch.Tensor, imap, act: int, head_mode:
     ws = torch.empty(lib.ctu_head_bwd_ws_floats(n, v, x.cp, co), dtype=torch.float32, device=dev)
     dw = torch.empty_like(w)
     db = torch.empty_like(b)
+    if bn is not None:
+        vec, partials = bn
+        bn_cp = vec.shape[1]
+        rows = lib.ctu_head_bwd_num_blocks(n, v)
+        assert x.scale is not None and x.relu and vec[0].data_ptr() == x.scale.data_ptr() and partials.numel() >= rows * 2 * bn_cp
+        _lib.check(lib.ctu_head_bwd_bn(x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), w.data_ptr(),
+                                       b.data_ptr(), _ptr(imap), ci, co, act, head_mode, g0.data_ptr(), _ptr(g1), gin.ptr,
+                                       gin.cs, dw.data_ptr(), db.data_ptr(), ws.data_ptr(), n, v, vec[2].data_ptr(),
+                                       vec[3].data_ptr(), bn_cp, partials.data_ptr(), _stream()), "head_bwd_bn")
+        return dw, db, rows
     _lib.check(lib.ctu_head_bwd(x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), w.data_ptr(),
                                 b.data_ptr(), _ptr(imap), ci, co, act, head_mode, g0.data_ptr(), _ptr(g1), gin.ptr,
                                 gin.cs, dw.data_ptr(), db.data_ptr(), ws.data_ptr(), n, v, _stream()), "head_bwd")
     return dw, db
+
+
+def head_bwd_blocks(dims) -> int:
+    n, d, h, w_ = dims
+    return _lib.load().ctu_head_bwd_num_blocks(n, d * h * w_)
 
 
 # ---------------------------------------------------------------------------- loss

@@ -248,6 +248,17 @@ int ctu_head_bwd(const float* in, int in_cs, int cin_p, const float* in_scale,
                  const int32_t* imap, int Ci, int Co, int act, int head_mode,
                  const float* g0, const float* g1, float* gin, int gin_cs,
                  float* dw, float* db, float* ws, int N, int64_t nvox_per_item, void* stream);
+/* The same, when the first bn_cp input channels are the train-mode BatchNorm + ReLU output of one conv (in_scale/in_shift,
+ * bn_mean/bn_invstd) and nothing else consumes that tensor (the decoder's last block feeding the head, models.py:252-255):
+ * also emits that BatchNorm's backward reduction, ctu_head_bwd_num_blocks rows of 2*bn_cp floats {sum gz, sum gz*xhat},
+ * consumed by ctu_bn_bwd_finalize in place of ctu_bn_relu_bwd_reduce's rows. */
+int ctu_head_bwd_num_blocks(int N, int64_t nvox_per_item);
+int ctu_head_bwd_bn(const float* in, int in_cs, int cin_p, const float* in_scale,
+                    const float* in_shift, int in_relu, const float* w, const float* bias,
+                    const int32_t* imap, int Ci, int Co, int act, int head_mode,
+                    const float* g0, const float* g1, float* gin, int gin_cs,
+                    float* dw, float* db, float* ws, int N, int64_t nvox_per_item,
+                    const float* bn_mean, const float* bn_invstd, int bn_cp, float* bn_partials, void* stream);
 
 /* ------------------------------------------------------------------- loss ---- */
 /* Fused Dice + cross-entropy on one 2-channel NCDHW map (utilities.py:35-50,

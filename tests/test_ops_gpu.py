@@ -406,6 +406,44 @@ def test_head_fwd_bwd(co, act, mode):
     assert rel_err(db.cpu(), b.grad) < 1e-4
 
 
+@pytest.mark.parametrize("cp,bn_cp,co,act,mode", [(16, 8, 2, 1, 0), (8, 8, 2, 0, 0), (32, 16, 3, 2, 1)])
+def test_head_bwd_with_bn_reduction(cp, bn_cp, co, act, mode):
+    """head_bwd(bn=...) emits the BatchNorm-backward reduction rows of the layer behind its first bn_cp input channels:
+    the rows summed must equal those of bn_relu_bwd_reduce on the gradient the head wrote, and the full BatchNorm backward
+    (dgamma, dbeta, raw-output gradient) must agree between the two routes."""
+    ops = _ops()
+    n, d, h, w = 2, 4, 6, 10
+    nvox = n * d * h * w
+    buf = (torch.randn(n, d, h, w, cp, generator=g(1)) * 1.2 + 0.1).cuda()
+    vec = torch.zeros(4, cp)
+    vec[0] = torch.rand(cp, generator=g(2)) + 0.3                   # scale = gamma * invstd
+    vec[1] = torch.randn(cp, generator=g(3)) * 0.3                  # shift
+    vec[2] = torch.randn(cp, generator=g(4)) * 0.2                  # mean
+    vec[3] = torch.rand(cp, generator=g(5)) + 0.5                   # invstd
+    vec = vec.cuda()
+    gamma = (vec[0] / vec[3])[:bn_cp].contiguous()
+    xc = ops.CL(buf, 0, cp, vec[0], vec[1], True)
+    wt = (torch.randn(co, cp, generator=g(6)) * 0.4).cuda()
+    b = torch.randn(co, generator=g(7)).cuda()
+    o0, o1 = ops.head_fwd(xc, wt, b, None, act, mode)
+    g0 = torch.randn(o0.shape, generator=g(8)).cuda()
+    g1 = torch.randn(o1.shape, generator=g(9)).cuda() if mode else None
+    bnvec = vec[:, :bn_cp]
+    res = {}
+    for fused in (False, True):
+        gin = ops.CL(torch.empty(n, d, h, w, cp, device="cuda"), 0, cp)
+        part = torch.empty(max(ops.bn_bwd_partials_floats(nvox, bn_cp), ops.head_bwd_blocks((n, d, h, w)) * 2 * bn_cp), device="cuda")
+        out = ops.head_bwd(xc, wt, b, None, act, mode, g0, g1, gin, (bnvec, part) if fused else None)
+        rows = out[2] if fused else None
+        assert len(out) == (3 if fused else 2)
+        ga = ops.CL(gin.buf, 0, bn_cp)
+        dgam, dbet = ops.bn_relu_bwd(ops.CL(buf, 0, bn_cp), ga, bnvec, gamma, bn_cp, part, None, rows)
+        torch.cuda.synchronize()
+        res[fused] = (out[0].cpu(), out[1].cpu(), dgam.cpu(), dbet.cpu(), gin.buf.cpu())
+    for a_, b_ in zip(res[True], res[False]):
+        assert rel_err(a_, b_) < 1e-5
+
+
 @pytest.mark.parametrize("ce,dice,sm", [(1.0, 1.0, False), (1.0, 1.0, True), (0.0, 1.0, True), (1.0, 0.0, False),
                                         (0.5, 2.0, True)])
 def test_loss_fwd_bwd(ce, dice, sm):
