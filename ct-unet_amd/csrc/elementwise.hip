@@ -74,8 +74,10 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stats, int nblocks,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps,
                                    int n_updates, float* __restrict__ scale, float* __restrict__ shift,
-                                   float* __restrict__ mean_out, float* __restrict__ invstd_out) {
+                                   float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                   long long* __restrict__ nbt) {
     const int c = blockIdx.x;
+    if (nbt && c == 0 && threadIdx.x == 0 && n_updates > 0) nbt[0] += n_updates;     // num_batches_tracked
     double s1 = 0.0, s2 = 0.0;
     if (c < C) {
 #pragma unroll 4
@@ -172,8 +174,10 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int n
                                        const float* __restrict__ gamma, const float* __restrict__ invstd,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta,
                                        float* __restrict__ coef, const float* __restrict__ mean,
-                                       float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps) {
+                                       float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps,
+                                       long long* __restrict__ nbt) {
     const int c = blockIdx.x;
+    if (nbt && rmean && c == 0 && threadIdx.x == 0) nbt[0] += 1;                      // the replayed update counts too
     double s1 = 0.0, s2 = 0.0;
     if (c < C) {
 #pragma unroll 4
@@ -494,12 +498,12 @@ extern "C" int ctu_ndhwc_to_ncdhw(const float* src, float* dst, int N, int C, in
 extern "C" int ctu_bn_finalize(const float* stats, int nblocks, int C, int cp, double count, const float* gamma,
                                const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                                int n_updates, float* scale, float* shift, float* mean_out, float* invstd_out,
-                               void* stream) {
+                               long long* num_batches_tracked, void* stream) {
     CTU_REQUIRE(stats && gamma && beta && scale && shift && mean_out && invstd_out, "bn_finalize: null pointer");
     CTU_REQUIRE(C > 0 && cp >= C && cp % 8 == 0 && nblocks > 0 && count > 0, "bn_finalize: bad sizes");
     bn_finalize_kernel<<<cp, FIN_BLOCK, 0, (hipStream_t)stream>>>(stats, nblocks, C, cp, count, gamma, beta,
                                                                 running_mean, running_var, momentum, eps, n_updates,
-                                                                scale, shift, mean_out, invstd_out);
+                                                                scale, shift, mean_out, invstd_out, num_batches_tracked);
     CTU_CHECK_LAUNCH("bn_finalize");
     return CTU_OK;
 }
@@ -535,13 +539,14 @@ extern "C" int ctu_bn_relu_bwd_reduce(const float* y, int y_cs, const float* ga,
 
 extern "C" int ctu_bn_bwd_finalize(const float* partials, int nb, int C, int cp, double count, const float* gamma,
                                    const float* invstd, float* dgamma, float* dbeta, float* coef, const float* mean,
-                                   float* running_mean, float* running_var, float momentum, float eps, void* stream) {
+                                   float* running_mean, float* running_var, float momentum, float eps,
+                                   long long* num_batches_tracked, void* stream) {
     CTU_REQUIRE(partials && gamma && invstd && dgamma && dbeta && coef, "bn_bwd_finalize: null pointer");
     CTU_REQUIRE((running_mean == nullptr) == (running_var == nullptr) && (!running_mean || mean),
                 "bn_bwd_finalize: the running-stat replay needs mean, running_mean and running_var together");
     bn_bwd_finalize_kernel<<<cp, EW_BLOCK, 0, (hipStream_t)stream>>>(partials, nb, C, cp, count, gamma, invstd, dgamma,
                                                                     dbeta, coef, mean, running_mean, running_var,
-                                                                    momentum, eps);
+                                                                    momentum, eps, num_batches_tracked);
     CTU_CHECK_LAUNCH("bn_bwd_finalize");
     return CTU_OK;
 }

@@ -50,11 +50,11 @@ SIGNATURES = {
     "ctu_conv3d_first_bwd_data": (I, [P, I, P, I, I, P, I, I, I, I, P]),
     "ctu_conv3d_first_wgrad_ws_floats": (Z, [I, I, I, I, I]),
     "ctu_conv3d_first_wgrad": (I, [P, I, P, I, P, I, P, I, I, I, I, P]),
-    "ctu_bn_finalize": (I, [P, I, I, I, D, P, P, P, P, F, F, I, P, P, P, P, P]),
+    "ctu_bn_finalize": (I, [P, I, I, I, D, P, P, P, P, F, F, I, P, P, P, P, P, P]),
     "ctu_bn_eval_affine": (I, [P, P, P, P, F, I, I, P, P, P]),
     "ctu_bn_bwd_num_blocks": (I, [L]),
     "ctu_bn_relu_bwd_reduce": (I, [P, I, P, I, I, P, P, P, P, L, P, P]),
-    "ctu_bn_bwd_finalize": (I, [P, I, I, I, D, P, P, P, P, P, P, P, P, F, F, P]),
+    "ctu_bn_bwd_finalize": (I, [P, I, I, I, D, P, P, P, P, P, P, P, P, F, F, P, P]),
     "ctu_bn_relu_bwd_apply": (I, [P, I, P, I, I, P, P, P, P, P, L, P]),
     "ctu_maxpool2_fwd": (I, [P, I, I, P, P, I, P, I, I, I, I, I, P]),
     "ctu_maxpool2_bwd": (I, [P, I, I, P, P, I, P, I, P, I, I, I, I, I, I, P]),

@@ -141,9 +141,8 @@ class UNetEngine:
             stats = torch.empty((nblk, 2, out.cp), dtype=torch.float32, device=x.buf.device)
             ops.conv3d_fwd(x, wp, bias_p, out, k, stats, (cin, cout), lay)
             ops.bn_finalize_into(stats, nblk, c, out.cp, x.nvox, P[bn + ".weight"], P[bn + ".bias"],
-                                 P[bn + ".running_mean"], P[bn + ".running_var"], BN_MOMENTUM, BN_EPS, n_upd, vec4)
-            if n_upd:
-                self._nbt.append(P[bn + ".num_batches_tracked"])
+                                 P[bn + ".running_mean"], P[bn + ".running_var"], BN_MOMENTUM, BN_EPS, n_upd, vec4,
+                                 P.get(bn + ".num_batches_tracked") if n_upd else None)
         else:
             stats, nblk = None, 0
             ops.conv3d_fwd(x, wp, bias_p, out, k, None, (cin, cout), lay)
@@ -185,9 +184,8 @@ class UNetEngine:
             stats = torch.empty((nblk, 2, out.cp), dtype=torch.float32, device=x.buf.device)
             ops.upconv_fused_fwd(x, wp, beff, out, stats, (ct, cout))
             ops.bn_finalize_into(stats, nblk, cout, out.cp, nvox, P[bn + ".weight"], P[bn + ".bias"],
-                                 P[bn + ".running_mean"], P[bn + ".running_var"], BN_MOMENTUM, BN_EPS, n_upd, vec4)
-            if n_upd:
-                self._nbt.append(P[bn + ".num_batches_tracked"])
+                                 P[bn + ".running_mean"], P[bn + ".running_var"], BN_MOMENTUM, BN_EPS, n_upd, vec4,
+                                 P.get(bn + ".num_batches_tracked") if n_upd else None)
         else:
             stats, nblk = None, 0
             ops.upconv_fused_fwd(x, wp, beff, out, None, (ct, cout))
@@ -215,9 +213,8 @@ class UNetEngine:
             stats = torch.empty((nblk, 2, out.cp), dtype=torch.float32, device=x.device)
             ops.conv_first_fwd(x, w, bias_p, out, stats)
             ops.bn_finalize_into(stats, nblk, cout, out.cp, nvox, P[bn + ".weight"], P[bn + ".bias"],
-                                 P[bn + ".running_mean"], P[bn + ".running_var"], BN_MOMENTUM, BN_EPS, n_upd, vec4)
-            if n_upd:
-                self._nbt.append(P[bn + ".num_batches_tracked"])
+                                 P[bn + ".running_mean"], P[bn + ".running_var"], BN_MOMENTUM, BN_EPS, n_upd, vec4,
+                                 P.get(bn + ".num_batches_tracked") if n_upd else None)
         else:
             stats, nblk = None, 0
             ops.conv_first_fwd(x, w, bias_p, out, None)
@@ -248,7 +245,6 @@ class UNetEngine:
         ctx = {"recs": {}, "levels": [], "training": training, "chk": chk} if save else None
         n_upd = 1 if training else 0
         self.refresh_packs(P)
-        self._nbt: List[torch.Tensor] = []
 
         x = x.contiguous()
         e0 = plan.enc[0]
@@ -261,10 +257,15 @@ class UNetEngine:
         dskip: List[CL] = []
         dd, hh, ww = d, h, w
         recs = {}
+        # one zero-filled allocation for every level's [4, 2Cp] vector block (one fill launch instead of one per level)
+        xf_sizes = [8 * pad8(blk.cout) for blk in plan.enc]
+        xf_all = torch.zeros(sum(xf_sizes), dtype=torch.float32, device=dev)
+        xf_off = 0
         for i, blk in enumerate(plan.enc):
             cp = pad8(blk.cout)
             cat.append(torch.empty((n, dd, hh, ww, 2 * cp), dtype=torch.float32, device=dev))
-            xf.append(torch.zeros((4, 2 * cp), dtype=torch.float32, device=dev))
+            xf.append(xf_all[xf_off:xf_off + 8 * cp].view(4, 2 * cp))
+            xf_off += 8 * cp
             t1 = CL(torch.empty((n, dd, hh, ww, cp), dtype=torch.float32, device=dev), 0, cp)
             v1 = torch.empty((4, cp), dtype=torch.float32, device=dev)
             imap = None
@@ -344,8 +345,6 @@ class UNetEngine:
                 cur_segs = ((blk.cout, 0),)
         # ---- head
         imap_h, _ = self._maps(cur_segs, cur.cp, dev)
-        if self._nbt:
-            torch._foreach_add_(self._nbt, 1)      # one launch for every num_batches_tracked counter
         wl, bl = P[plan.head + ".weight"], P[plan.head + ".bias"]
         w2 = wl.detach().reshape(wl.shape[0], wl.shape[1])
         out0, out1 = ops.head_fwd(cur, w2, bl.detach(), imap_h, plan.act, plan.head_mode)
@@ -362,7 +361,8 @@ class UNetEngine:
         k = self.plan.k
         # use_checkpoint=True: the recompute in backward repeats every live BN's running-stat update
         # (models.py:232-255) -- folded into this BN's backward finalize
-        replay = (P[rec.bn + ".running_mean"], P[rec.bn + ".running_var"], BN_MOMENTUM, BN_EPS) if self._replay_stats else None
+        replay = ((P[rec.bn + ".running_mean"], P[rec.bn + ".running_var"], BN_MOMENTUM, BN_EPS,
+                   P.get(rec.bn + ".num_batches_tracked")) if self._replay_stats else None)
         dg, db = ops.bn_relu_bwd(rec.y, ga, rec.vec, P[rec.bn + ".weight"].detach(), rec.cout, part, replay, pre_reduced)
         grads[rec.bn + ".weight"], grads[rec.bn + ".bias"] = dg, db
         if rec.first is not None:                  # direct C_in <= 2 kernels; gin is a request flag here
@@ -419,10 +419,6 @@ class UNetEngine:
         # (models.py:232-255) rides on each live BN's backward finalize; the dead centre block is
         # never recomputed and has no backward.
         self._replay_stats = bool(ctx["training"] and ctx["chk"])
-        if self._replay_stats:
-            nbt = [P[r.bn + ".num_batches_tracked"] for r in recs.values() if r is not None and r.stats is not None]
-            if nbt:
-                torch._foreach_add_(nbt, 1)
 
         cat, head_in = ctx["cat"], ctx["head_in"]
         gcat = [torch.empty_like(c) for c in cat]

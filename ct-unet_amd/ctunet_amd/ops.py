@@ -314,12 +314,15 @@ def conv_first_wgrad_ws(dims, cin: int) -> int:
 
 
 # ---------------------------------------------------------------------------- batch norm
-def bn_finalize_into(stats, nblocks, c, cp, count, gamma, beta, rmean, rvar, momentum, eps, n_updates, vec4):
-    """vec4: [4, cp] view (rows may be strided) receiving scale, shift, mean, invstd."""
+def bn_finalize_into(stats, nblocks, c, cp, count, gamma, beta, rmean, rvar, momentum, eps, n_updates, vec4, nbt=None):
+    """vec4: [4, cp] view (rows may be strided) receiving scale, shift, mean, invstd.
+    nbt: the BatchNorm's num_batches_tracked (int64 device scalar), advanced by n_updates in the same launch."""
     lib = _lib.load()
+    assert nbt is None or (nbt.dtype == torch.int64 and nbt.is_cuda and nbt.numel() == 1)
     _lib.check(lib.ctu_bn_finalize(stats.data_ptr(), nblocks, c, cp, float(count), gamma.data_ptr(), beta.data_ptr(),
                                    _ptr(rmean), _ptr(rvar), momentum, eps, n_updates, vec4[0].data_ptr(),
-                                   vec4[1].data_ptr(), vec4[2].data_ptr(), vec4[3].data_ptr(), _stream()), "bn_finalize")
+                                   vec4[1].data_ptr(), vec4[2].data_ptr(), vec4[3].data_ptr(),
+                                   None if nbt is None else nbt.data_ptr(), _stream()), "bn_finalize")
 
 
 def bn_finalize(stats, nblocks, c, cp, count, gamma, beta, rmean, rvar, momentum, eps, n_updates):
@@ -343,8 +346,8 @@ def bn_eval_affine(gamma, beta, rmean, rvar, eps, c, cp):
 def bn_relu_bwd(y: CL, ga: CL, vec: torch.Tensor, gamma: torch.Tensor, c: int, partials: torch.Tensor,
                 replay=None, pre_reduced: Optional[int] = None):
     """In place: ga <- gradient w.r.t. the raw conv output y.  Returns (dgamma, dbeta).
-    replay = (running_mean, running_var, momentum, eps): also apply the running-stat update a second time (the one
-    torch.utils.checkpoint's recompute performs in backward, models.py:232-255)."""
+    replay = (running_mean, running_var, momentum, eps[, num_batches_tracked]): also apply the running-stat update a
+    second time (the one torch.utils.checkpoint's recompute performs in backward, models.py:232-255)."""
     lib = _lib.load()
     nvox = y.nvox
     cp = y.cp
@@ -357,10 +360,11 @@ def bn_relu_bwd(y: CL, ga: CL, vec: torch.Tensor, gamma: torch.Tensor, c: int, p
                                               st), "bn_relu_bwd_reduce")
     dgb = torch.empty((2, c), dtype=torch.float32, device=y.buf.device)
     coef = torch.empty((3, cp), dtype=torch.float32, device=y.buf.device)
-    rm, rv, mom, eps = replay if replay is not None else (None, None, 0.0, 0.0)
+    rm, rv, mom, eps, nbt = (tuple(replay) + (None,))[:5] if replay is not None else (None, None, 0.0, 0.0, None)
+    assert nbt is None or (nbt.dtype == torch.int64 and nbt.is_cuda and nbt.numel() == 1)
     _lib.check(lib.ctu_bn_bwd_finalize(partials.data_ptr(), nb, c, cp, float(nvox), gamma.data_ptr(), istd,
                                        dgb[0].data_ptr(), dgb[1].data_ptr(), coef.data_ptr(), mu, _ptr(rm), _ptr(rv),
-                                       mom, eps, st), "bn_bwd_finalize")
+                                       mom, eps, None if nbt is None else nbt.data_ptr(), st), "bn_bwd_finalize")
     _lib.check(lib.ctu_bn_relu_bwd_apply(y.ptr, y.cs, ga.ptr, ga.cs, cp, sc, sh, mu, istd, coef.data_ptr(), nvox, st),
                "bn_relu_bwd_apply")
     return dgb[0], dgb[1]

@@ -156,7 +156,9 @@ int ctu_bn_finalize(const float* stats, int nblocks, int C, int cp, double count
                     const float* gamma, const float* beta,
                     float* running_mean, float* running_var, float momentum, float eps,
                     int n_updates, float* scale, float* shift, float* mean_out,
-                    float* invstd_out, void* stream);
+                    float* invstd_out, long long* num_batches_tracked, void* stream);
+/* (num_batches_tracked: the BatchNorm's int64 counter on the device, += n_updates by the same launch; NULL = none.
+ *  ctu_bn_bwd_finalize takes it too and adds 1 when it replays the running-stat update.) */
 /* Eval mode: scale/shift from the running statistics. */
 int ctu_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
                        const float* running_var, float eps, int C, int cp,
@@ -176,7 +178,8 @@ int ctu_bn_relu_bwd_reduce(const float* y, int y_cs, const float* ga, int g_cs, 
 int ctu_bn_bwd_finalize(const float* partials, int nb, int C, int cp, double count,
                         const float* gamma, const float* invstd,
                         float* dgamma, float* dbeta, float* coef, const float* mean,
-                        float* running_mean, float* running_var, float momentum, float eps, void* stream);
+                        float* running_mean, float* running_var, float momentum, float eps,
+                        long long* num_batches_tracked, void* stream);
 int ctu_bn_relu_bwd_apply(const float* y, int y_cs, float* ga, int g_cs, int cp,
                           const float* scale, const float* shift, const float* mean,
                           const float* invstd, const float* coef, int64_t nvox, void* stream);
