@@ -98,6 +98,7 @@ SIGNATURES = {
 }
 
 _lib = None
+ABI_VERSION = 2          # CTU_ABI_VERSION of the csrc/ this file mirrors (bumped on any signature change)
 
 
 class CtuError(RuntimeError):
@@ -121,6 +122,9 @@ def load() -> C.CDLL:
             raise ImportError(f"{LIB_PATH} does not export {name}; rebuild the library") from e
         fn.restype = res
         fn.argtypes = args
+    if lib.ctu_abi_version() != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH} is ABI v{lib.ctu_abi_version()}, this package binds v{ABI_VERSION}: "
+                          "a stale build -- run `python __graft_entry__.py` (or `make -C ct-unet_amd/csrc`)")
     _lib = lib
     return lib
 
