@@ -77,29 +77,45 @@ __global__ __launch_bounds__(256) void convt2_kernel(CtP p, int tps) {
 
     for (int tap0 = 0; tap0 < 8; tap0 += tps) {
         __syncthreads();
+        // Staging is all latency here (deep levels: a few hundred blocks, one per CU): every batch of loads is issued
+        // together, branch-free (items past the end re-read a valid address and are not stored), then stored.
         if (MODE == 0 && tap0 == 0) {
-            for (int it = tid; it < 64 * nq; it += 256) {
+            f32x4 va[GMAX];
+#pragma unroll
+            for (int k = 0; k < GMAX; ++k) {
+                const int it = tid + k * 256;
                 const int vl = it / nq, qd = it % nq;
-                const int64_t v = v0 + vl;
-                float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (v < p.nvox) {
-                    val = *reinterpret_cast<const float4*>(p.in + (size_t)v * p.in_cs + qd * 4);
-                    if (has_xf) {
-                        const float4 sc = *reinterpret_cast<const float4*>(p.in_scale + qd * 4);
-                        const float4 sh = *reinterpret_cast<const float4*>(p.in_shift + qd * 4);
-                        val = xform4(val, sc, sh, p.in_relu);
-                    }
+                const bool ok = it < 64 * nq && v0 + vl < p.nvox;
+                va[k] = *reinterpret_cast<const f32x4*>(p.in + (ok ? (size_t)(v0 + vl) * p.in_cs : (size_t)0) + qd * 4);
+            }
+#pragma unroll
+            for (int k = 0; k < GMAX; ++k) {
+                const int it = tid + k * 256;
+                const int vl = it / nq, qd = it % nq;
+                if (it < 64 * nq) {
+                    float4 val = make_float4(va[k][0], va[k][1], va[k][2], va[k][3]);
+                    if (has_xf)
+                        val = xform4(val, *reinterpret_cast<const float4*>(p.in_scale + qd * 4),
+                                     *reinterpret_cast<const float4*>(p.in_shift + qd * 4), p.in_relu);
+                    if (v0 + vl >= p.nvox) val = make_float4(0.f, 0.f, 0.f, 0.f);
+                    *reinterpret_cast<float4*>(&sA[vl * AS + qd * 4]) = val;
                 }
-                *reinterpret_cast<float4*>(&sA[vl * AS + qd * 4]) = val;
             }
         }
         {
             // packed weights: [tap][g][ntt_total][128]; this block takes tiles by*NTT .. by*NTT+NTT-1
             const int tot = tps * wfl;
-            for (int i = tid * 4; i < tot; i += 1024) {
-                const int tl = i / wfl, rem = i % wfl, g = rem / (NTT * 128), r = rem % (NTT * 128);
-                *reinterpret_cast<float4*>(&sW[i]) = *reinterpret_cast<const float4*>(
-                    p.wp + ((size_t)((tap0 + tl) * ng + g) * p.ntt_total + by * NTT) * 128 + r);
+            for (int i0 = tid * 4; i0 < tot; i0 += 8 * 1024) {
+                f32x4 wv[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int i = (i0 + k * 1024 < tot) ? i0 + k * 1024 : i0;
+                    const int tl = i / wfl, rem = i % wfl, g = rem / (NTT * 128), r = rem % (NTT * 128);
+                    wv[k] = *reinterpret_cast<const f32x4*>(p.wp + ((size_t)((tap0 + tl) * ng + g) * p.ntt_total + by * NTT) * 128 + r);
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (i0 + k * 1024 < tot) *reinterpret_cast<f32x4*>(&sW[i0 + k * 1024]) = wv[k];
             }
         }
         if (MODE == 0) __syncthreads();
@@ -109,15 +125,20 @@ __global__ __launch_bounds__(256) void convt2_kernel(CtP p, int tps) {
                 // gather this tap's fine-grid voxels (the block's 64 coarse voxels) into sA
                 __syncthreads();
                 const int toff = tap_off(tap, p.H, p.W);
+                f32x4 vg[GMAX];
+#pragma unroll
+                for (int k = 0; k < GMAX; ++k) {
+                    const int qd = (tid + k * 256) % nq;
+                    const bool ok = gbase[k] != (size_t)-1;
+                    vg[k] = *reinterpret_cast<const f32x4*>(p.in + (ok ? (gbase[k] + toff) * p.in_cs : (size_t)0) + qd * 4);
+                }
 #pragma unroll
                 for (int k = 0; k < GMAX; ++k) {
                     const int it = tid + k * 256;
                     if (it < 64 * nq) {
                         const int vl = it / nq, qd = it % nq;
-                        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (gbase[k] != (size_t)-1)
-                            val = *reinterpret_cast<const float4*>(p.in + (gbase[k] + toff) * p.in_cs + qd * 4);
-                        *reinterpret_cast<float4*>(&sA[vl * AS + qd * 4]) = val;
+                        const bool ok = gbase[k] != (size_t)-1;
+                        *reinterpret_cast<f32x4*>(&sA[vl * AS + qd * 4]) = ok ? vg[k] : f32x4{0.f, 0.f, 0.f, 0.f};
                     }
                 }
                 __syncthreads();
