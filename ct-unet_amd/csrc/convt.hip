@@ -259,11 +259,14 @@ __global__ __launch_bounds__(256) void convt2_wgrad_kernel(CtWgP p, float* __res
             const int vl = tid / QG + j * (256 / QG);
             const int64_t v = v0 + vl;
             const bool ok = g_ok && v < p.nvox;
-            const float* gsrc = p.g + (ok ? fine_base(v, p.D, p.H, p.W) : 0) * p.g_cs + co0 + qg * 4;
+            // the 8 taps' loads are issued together, branch-free (items outside read voxel 0 / quad 0 and are zeroed)
+            const float* gsrc = p.g + (ok ? fine_base(v, p.D, p.H, p.W) : 0) * p.g_cs + (g_ok ? co0 + qg * 4 : 0);
+            f32x4 gl[8];
+#pragma unroll
+            for (int tap = 0; tap < 8; ++tap) gl[tap] = *reinterpret_cast<const f32x4*>(gsrc + (size_t)tap_off(tap, p.H, p.W) * p.g_cs);
 #pragma unroll
             for (int tap = 0; tap < 8; ++tap) {
-                float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ok) gv = *reinterpret_cast<const float4*>(gsrc + (size_t)tap_off(tap, p.H, p.W) * p.g_cs);
+                const float4 gv = ok ? make_float4(gl[tap][0], gl[tap][1], gl[tap][2], gl[tap][3]) : make_float4(0.f, 0.f, 0.f, 0.f);
                 *reinterpret_cast<float4*>(&sG[(tap * 64 + vl) * CG + qg * 4]) = gv;
                 gsum.x += gv.x; gsum.y += gv.y; gsum.z += gv.z; gsum.w += gv.w;
             }
