@@ -229,13 +229,27 @@ __global__ __launch_bounds__(256) void conv3d_fwd_kernel(ConvP p) {
         for (int s = 0; s < NSTAGE; ++s) {
             if (s > 0) __syncthreads();
             // packed weights: [chunk][stage][tap][n16 tile][128]; this block takes tiles by*NT .. by*NT+NT-1
-            for (int i = tid * 4; i < CCH * WFL; i += 1024) {
-                const int g = i / WFL, j = i % WFL;
-                const float* wsrc = p.wp + ((size_t)(c + g) * NSTAGE + s) * STAPS * n16 * 128 + (size_t)by * NT * 128;
-                const int ts = j / (NT * 128), r = j % (NT * 128);
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (by * NT * 128 + r < n16 * 128) v = *reinterpret_cast<const float4*>(wsrc + (size_t)ts * n16 * 128 + r);
-                *reinterpret_cast<float4*>(&sW[i]) = v;
+            // (loads in batches of 8, branch-free: a load/store pair per iteration exposes one L2 round trip each)
+            constexpr int WB = 8;
+            for (int i0 = tid * 4; i0 < CCH * WFL; i0 += WB * 1024) {
+                f32x4 wv[WB];
+#pragma unroll
+                for (int q = 0; q < WB; ++q) {
+                    const int i = (i0 + q * 1024 < CCH * WFL) ? i0 + q * 1024 : i0;
+                    const int g = i / WFL, j = i % WFL;
+                    const int ts = j / (NT * 128), r = j % (NT * 128);
+                    const bool ok = by * NT * 128 + r < n16 * 128;
+                    wv[q] = *reinterpret_cast<const f32x4*>(p.wp + ((size_t)(c + g) * NSTAGE + s) * STAPS * n16 * 128 +
+                                                            (size_t)ts * n16 * 128 + (ok ? (size_t)by * NT * 128 + r : (size_t)0));
+                }
+#pragma unroll
+                for (int q = 0; q < WB; ++q) {
+                    const int i = i0 + q * 1024;
+                    if (i < CCH * WFL) {
+                        const bool ok = by * NT * 128 + (i % WFL) % (NT * 128) < n16 * 128;
+                        *reinterpret_cast<f32x4*>(&sW[i]) = ok ? wv[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                }
             }
             __syncthreads();
 #pragma unroll 1
