@@ -804,29 +804,55 @@ __global__ __launch_bounds__(256, CTU_WG_OCC) void conv3d_wgrad_kernel(WgP p) {
         const int n_img = bx;
         const int d0 = tz * TD, h0 = ty * TH, w0 = tx * TW;
         __syncthreads();
-        for (int it = tid; it < HV * 4; it += 256) {
-            const int v = it >> 2;
-            const int pw = v % HW, t2 = v / HW, ph = t2 % HH, pd = t2 / HH;
-            const int gd = d0 + pd + kd0 - PAD, gh = h0 + ph - PAD, gw = w0 + pw - PAD;
-            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (a_ok && (unsigned)gd < (unsigned)p.D && (unsigned)gh < (unsigned)p.H &&
-                (unsigned)gw < (unsigned)p.W) {
-                const size_t vox = (((size_t)n_img * p.D + gd) * p.H + gh) * p.W + gw;
-                val = *reinterpret_cast<const float4*>(p.in + vox * p.in_cs + ci0 + quad * 4);
-                if (has_xf) val = xform4(val, sc, sh, p.in_relu);
+        // staging loads go out in batches, branch-free (items outside the volume / channel range read element 0 of the
+        // image and are zeroed at the LDS write): a load -> store pair per iteration would expose one round trip each
+        constexpr int SB = 8;
+        const size_t img = (size_t)n_img * p.D * p.H * p.W;
+        for (int it0 = tid; it0 < HV * 4; it0 += SB * 256) {
+            f32x4 vv[SB];
+            unsigned okm = 0;
+#pragma unroll
+            for (int q = 0; q < SB; ++q) {
+                const int it = it0 + q * 256;
+                const int v = (it < HV * 4 ? it : it0) >> 2;
+                const int pw = v % HW, t2 = v / HW, ph = t2 % HH, pd = t2 / HH;
+                const int gd = d0 + pd + kd0 - PAD, gh = h0 + ph - PAD, gw = w0 + pw - PAD;
+                const bool ok = a_ok && (unsigned)gd < (unsigned)p.D && (unsigned)gh < (unsigned)p.H && (unsigned)gw < (unsigned)p.W;
+                okm |= ok ? (1u << q) : 0u;
+                const size_t off = ok ? ((size_t)(gd * p.H + gh) * p.W + gw) * p.in_cs + ci0 + quad * 4 : (size_t)0;
+                vv[q] = *reinterpret_cast<const f32x4*>(p.in + img * p.in_cs + off);
             }
-            *reinterpret_cast<float4*>(&sA[v * 16 + quad * 4]) = val;
+#pragma unroll
+            for (int q = 0; q < SB; ++q) {
+                const int it = it0 + q * 256;
+                if (it < HV * 4) {
+                    float4 val = make_float4(vv[q][0], vv[q][1], vv[q][2], vv[q][3]);
+                    if (has_xf) val = xform4(val, sc, sh, p.in_relu);
+                    if (!((okm >> q) & 1u)) val = make_float4(0.f, 0.f, 0.f, 0.f);
+                    *reinterpret_cast<float4*>(&sA[(it >> 2) * 16 + quad * 4]) = val;
+                }
+            }
         }
-        for (int it = tid; it < NVOX * 4; it += 256) {
-            const int v = it >> 2;
-            const int tw = v % TW, th = (v / TW) % TH, td = v / (TW * TH);
-            const int gd = d0 + td, gh = h0 + th, gw = w0 + tw;
-            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (g_ok && gd < p.D && gh < p.H && gw < p.W) {
-                const size_t vox = (((size_t)n_img * p.D + gd) * p.H + gh) * p.W + gw;
-                val = *reinterpret_cast<const float4*>(p.g + vox * p.g_cs + co0 + quad * 4);
+        for (int it0 = tid; it0 < NVOX * 4; it0 += SB * 256) {
+            f32x4 vv[SB];
+            unsigned okm = 0;
+#pragma unroll
+            for (int q = 0; q < SB; ++q) {
+                const int it = it0 + q * 256;
+                const int v = (it < NVOX * 4 ? it : it0) >> 2;
+                const int tw = v % TW, th = (v / TW) % TH, td = v / (TW * TH);
+                const int gd = d0 + td, gh = h0 + th, gw = w0 + tw;
+                const bool ok = g_ok && gd < p.D && gh < p.H && gw < p.W;
+                okm |= ok ? (1u << q) : 0u;
+                const size_t off = ok ? ((size_t)(gd * p.H + gh) * p.W + gw) * p.g_cs + co0 + quad * 4 : (size_t)0;
+                vv[q] = *reinterpret_cast<const f32x4*>(p.g + img * p.g_cs + off);
             }
-            *reinterpret_cast<float4*>(&sG[v * 16 + quad * 4]) = val;
+#pragma unroll
+            for (int q = 0; q < SB; ++q) {
+                const int it = it0 + q * 256;
+                if (it < NVOX * 4)
+                    *reinterpret_cast<f32x4*>(&sG[(it >> 2) * 16 + quad * 4]) = ((okm >> q) & 1u) ? vv[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         }
         __syncthreads();
 #pragma unroll 2

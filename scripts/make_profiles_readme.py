@@ -59,9 +59,9 @@ kernel and launch, FETCH_SIZE doubled as the gfx950 guide prescribes.  The roofl
 the kernel is MFMA-bound either way.
 `r01_mid_kernel_stats.csv` — the same profile earlier in the round (10.1 ms/step) for comparison.
 
-Secondary numbers (`scripts/bench_classes.py`, eagerly launched train steps at 128³, same box class): `UNet` 4.02 ms,
-`UNetSP` 4.19 ms, `UNetSPSmall` (5 blocks) 4.61 ms; the legacy k = 5 nets `recAE_v2_fixed` 23.9 ms and `UNet4_2IC`
-23.6 ms (≈48 algorithmic TFLOP/s: they still run the non-persistent generic kernels — next round).
+Secondary numbers (`scripts/bench_classes.py`, eagerly launched train steps at 128³, same box class): `UNet` 4.08 ms,
+`UNetSP` 4.16 ms, `UNetSPSmall` (5 blocks) 4.52 ms; the legacy k = 5 nets `recAE_v2_fixed` 23.1 ms and `UNet4_2IC`
+22.7 ms (≈52 algorithmic TFLOP/s: they still run the non-persistent generic kernels — next round).
 
 History inside round 1 (ms/step): 18.8 first working path → 10.1 in-block wgrad reduction → 9.7 gather packing /
 exact BN rows → 8.5 (shift, channel) wgrad tiles → 8.1 pair-layout forward → 7.7 ConvTranspose float4 stores →
