@@ -49,7 +49,11 @@ class GraphedTrainStep:
                     self._eager_reduce_step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        with torch.cuda.graph(self.graph):
+        # capture_error_mode: with a process group alive, RCCL's watchdog THREAD polls its work events at any time; under
+        # the default "global" mode such a query from another thread invalidates the capture (and the watchdog aborts the
+        # process) -- a race that depends on when the last warm-up all-reduce retires.  Only this thread's calls matter.
+        mode = "thread_local" if distributed else "global"
+        with torch.cuda.graph(self.graph, capture_error_mode=mode):
             self.values = self._step()
         self.keys = self._keys()
         if distributed:
@@ -61,7 +65,7 @@ class GraphedTrainStep:
             for p, v in zip(self._live, self.flat.split([p.numel() for p in self._live])):
                 p.grad = v.view_as(p)
             self.graph2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph2):
+            with torch.cuda.graph(self.graph2, capture_error_mode=mode):
                 self._scale_and_step()
 
     def _keys(self) -> List[str]:
