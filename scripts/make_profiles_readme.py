@@ -73,8 +73,8 @@ kernels, batched weight packing → 5.5 explicit `ds_read_b64` fragment reads, h
 projections → 3.98 → 3.93 w-parity-in-tile forward for 8 output channels → 3.88 the same for the weight gradient → 3.80 narrower fused
 blocks where the coarse volume has fewer boxes than CUs → 3.76 parallel loss / first-layer slab reductions →
 3.60 register-prefetched, ring-pipelined small-volume forward kernel → 3.56 one block per CU for small weight
-gradients, shuffle finalizes, in-place loss scalars → {d['ms_per_step']:.2f} BatchNorm-backward reductions emitted by the max-pool and head
-backward kernels.
+gradients, shuffle finalizes, in-place loss scalars → 3.48 BatchNorm-backward reductions emitted by the max-pool and head
+backward kernels → {d['ms_per_step']:.2f} batched, branch-free staging loads in the ConvTranspose kernels.
 """
 open(f"{ROOT}/profiles/README.md", "w").write(txt)
 print(txt[:600])
