@@ -606,25 +606,26 @@ __global__ void upconv_transpose_kernel(const float* __restrict__ wt, const floa
     }
 }
 
-// Step 2: 8 lanes per (chunk, parity, tap, padded input channel, output channel): the W_eff entry = sum over its <= 8
-// (conv tap, transposed-conv tap) pairs of a C-long dot product; each lane takes every 8th cm, a 3-step shuffle
-// reduction combines them and lane 0 writes the value straight to its fragment position
+// Step 2: 8 lanes per (chunk, parity, tap, padded input channel, QUAD of output channels): a W_eff entry = sum over its
+// <= 8 (conv tap, transposed-conv tap) pairs of a C-long dot product; each lane takes every 8th cm (one W3 float4 and one
+// WT scalar per 4 multiply-adds: the kernel is bound by load instructions, not flops), a 3-step shuffle reduction combines
+// the lanes and lane 0 writes the four values straight to their fragment positions
 __global__ void upconv_pack_kernel(const float* __restrict__ wtt, const float* __restrict__ w3t, float* __restrict__ wp,
                                    int C, int nout_p, const int32_t* __restrict__ cinv, int nchunk, int ntpt) {
     const int gidx = blockIdx.x * blockDim.x + threadIdx.x;
     const int sub = gidx & 7, idx = gidx >> 3;
-    const int ncol = ntpt * 16;
-    if (idx >= nchunk * 8 * 8 * 8 * ncol) return;       // (whole 8-lane groups leave together)
+    const int ncol4 = ntpt * 4;                          // output-channel quads per row of N-tiles
+    if (idx >= nchunk * 8 * 8 * 8 * ncol4) return;      // (whole 8-lane groups leave together)
     int r = idx;
-    const int co = r % ncol; r /= ncol;
+    const int co = (r % ncol4) * 4; r /= ncol4;
     const int r8 = r & 7; r >>= 3;                       // channel inside the chunk (= kq*2 + j)
     const int tap = r & 7; r >>= 3;
     const int par = r & 7; r >>= 3;
     const int c = r;
     const int rp = c * 8 + r8;
     const int ci = cinv ? cinv[rp] : (rp < C ? rp : -1);
-    float v = 0.f;
-    if (ci >= 0 && co < nout_p) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ci >= 0 && co < nout_p) {                        // (nout_p is a multiple of 8: a quad is inside or outside as a whole)
         int tz[2], az[2], ty[2], ay[2], tx[2], ax[2];
         const int nz = axis_pairs((par >> 2) & 1, (tap >> 2) & 1, tz, az);
         const int ny = axis_pairs((par >> 1) & 1, (tap >> 1) & 1, ty, ay);
@@ -634,16 +635,24 @@ __global__ void upconv_pack_kernel(const float* __restrict__ wtt, const float* _
                 for (int ix = 0; ix < nx; ++ix) {
                     const float* a = wtt + ((size_t)((az[iz] * 2 + ay[iy]) * 2 + ax[ix]) * C + ci) * C;
                     const float* b = w3t + (size_t)((tz[iz] * 3 + ty[iy]) * 3 + tx[ix]) * C * nout_p + co;
-                    float s = 0.f;
+                    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 4
-                    for (int cm = sub; cm < C; cm += 8) s = fmaf(a[cm], b[(size_t)cm * nout_p], s);
-                    v += s;
+                    for (int cm = sub; cm < C; cm += 8) {
+                        const float av = a[cm];
+                        const float4 bv = *reinterpret_cast<const float4*>(b + (size_t)cm * nout_p);
+                        s.x = fmaf(av, bv.x, s.x); s.y = fmaf(av, bv.y, s.y); s.z = fmaf(av, bv.z, s.z); s.w = fmaf(av, bv.w, s.w);
+                    }
+                    v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w;
                 }
     }
-    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+    float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { vv[q] += __shfl_xor(vv[q], 1); vv[q] += __shfl_xor(vv[q], 2); vv[q] += __shfl_xor(vv[q], 4); }
     if (sub == 0) {
         const int nt = co >> 4, n = co & 15, kq = r8 >> 1, j = r8 & 1;
-        wp[((((size_t)c * 8 + par) * 8 + tap) * ntpt + nt) * 128 + kq * 32 + n * 2 + j] = v;
+        float* dst = wp + ((((size_t)c * 8 + par) * 8 + tap) * ntpt + nt) * 128 + kq * 32 + n * 2 + j;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dst[q * 2] = vv[q];
     }
 }
 
@@ -886,12 +895,13 @@ extern "C" int ctu_upconv_fused_pack(const float* wt, const float* bt, const flo
                 "upconv_fused_pack: C=%d Co=%d cin_p=%d nout_p=%d", C, Co, cin_p, nout_p);
     hipStream_t st = (hipStream_t)stream;
     const int ntpt = ceil_div(nout_p, 16);
+    CTU_REQUIRE(((uintptr_t)ws & 15) == 0, "upconv_fused_pack: ws must be 16-byte aligned");
     float* w3t = ws;
     float* wtt = ws + (size_t)27 * C * nout_p;
     const int ntr = 27 * C * nout_p + 8 * C * C;
     upconv_transpose_kernel<<<ceil_div(ntr, 256), 256, 0, st>>>(wt, w3, wtt, w3t, C, Co, nout_p);
     CTU_CHECK_LAUNCH("upconv_fused_transpose");
-    const int total = (cin_p / 8) * 8 * 8 * 8 * ntpt * 16 * 8;           // 8 lanes per packed element
+    const int total = (cin_p / 8) * 8 * 8 * 8 * ntpt * 4 * 8;            // 8 lanes per quad of packed elements
     upconv_pack_kernel<<<ceil_div(total, 256), 256, 0, st>>>(wtt, w3t, wp, C, nout_p, cinv, cin_p / 8, ntpt);
     CTU_CHECK_LAUNCH("upconv_fused_pack");
     if (nout_p == 8) {
