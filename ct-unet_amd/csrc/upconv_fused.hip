@@ -787,7 +787,8 @@ __device__ __forceinline__ int weff_index(int t, int a) {                    // 
 
 // 8 lanes per output element; grid covers dWT (C*C*8), then dW3 (Co*C*27), then dbT (C).  These sums are a few MFLOP:
 // the time is the number of cache lines a wave touches per load, so (a) the dWT lanes read their c_out runs of dW_eff / W3
-// as float4, (b) the dW3 outputs are dealt c_out-fastest: a wave's (c_in lane, c_out) pairs then read contiguous dW_eff rows.
+// as float4, (b) the dW3 outputs are dealt in c_out quads, c_out-fastest: a wave's (c_in lane, c_out quad) pairs read contiguous dW_eff
+// rows as float4 (4 multiply-adds per load pair).
 __global__ void upconv_project_kernel(const float* __restrict__ dweff, const float* __restrict__ V, const float* __restrict__ wtt,
                                       const float* __restrict__ w3t, const float* __restrict__ bt,
                                       const int32_t* __restrict__ imap, int C, int Co, int cin_p, int nout_p,
@@ -795,10 +796,37 @@ __global__ void upconv_project_kernel(const float* __restrict__ dweff, const flo
     const int gidx = blockIdx.x * blockDim.x + threadIdx.x;
     const int sub = gidx & 7;
     int idx = gidx >> 3;
-    const int n1 = C * C * 8, n2 = Co * C * 27, n3 = C;
+    const int coq = (Co + 3) >> 2;                                // output-channel quads of the dW3 part
+    const int n1 = C * C * 8, n2 = coq * C * 27, n3 = C;
     if (idx >= n1 + n2 + n3) return;
     float v = 0.f;
     float* dst;
+    if (idx >= n1 && idx < n1 + n2) {                             // dW3[co .. co+3][cm][t], dealt co-quad-fastest
+        const int k = idx - n1;
+        const int co = (k % coq) * 4, cm = (k / coq) % C, t = k / (coq * C);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {                              // 8 independent chains
+            const float* g = dweff + (size_t)weff_index(t, a) * cin_p * nout_p + co;
+            const float* w = wtt + (size_t)a * C * C + cm;
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+            for (int ci = sub; ci < C; ci += 8) {
+                const float4 gv = *reinterpret_cast<const float4*>(g + (size_t)(imap ? imap[ci] : ci) * nout_p);
+                const float wv = w[(size_t)ci * C];
+                s.x = fmaf(gv.x, wv, s.x); s.y = fmaf(gv.y, wv, s.y); s.z = fmaf(gv.z, wv, s.z); s.w = fmaf(gv.w, wv, s.w);
+            }
+            acc.x += s.x; acc.y += s.y; acc.z += s.z; acc.w += s.w;
+        }
+        float av[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (sub == 0 && co + q < Co) av[q] = fmaf(V[t * nout_p + co + q], bt[cm], av[q]);
+            av[q] += __shfl_xor(av[q], 1); av[q] += __shfl_xor(av[q], 2); av[q] += __shfl_xor(av[q], 4);
+            if (sub == 0 && co + q < Co) dw3[((size_t)(co + q) * C + cm) * 27 + t] = av[q];
+        }
+        return;
+    }
     if (idx < n1) {                                               // dWT[ci][cm][a]
         const int a = idx & 7, cm = (idx >> 3) % C, ci = idx / (8 * C);
         const int pos = imap ? imap[ci] : ci;
@@ -821,20 +849,6 @@ __global__ void upconv_project_kernel(const float* __restrict__ dweff, const flo
             }
         }
         dst = dwt + idx;
-    } else if (idx < n1 + n2) {                                   // dW3[co][cm][t], dealt co-fastest
-        const int k = idx - n1;
-        const int co = k % Co, cm = (k / Co) % C, t = k / (Co * C);
-#pragma unroll
-        for (int a = 0; a < 8; ++a) {                              // 8 independent chains
-            const float* g = dweff + (size_t)weff_index(t, a) * cin_p * nout_p + co;
-            const float* w = wtt + (size_t)a * C * C + cm;
-            float s = 0.f;
-#pragma unroll 4
-            for (int ci = sub; ci < C; ci += 8) s = fmaf(g[(size_t)(imap ? imap[ci] : ci) * nout_p], w[(size_t)ci * C], s);
-            v += s;
-        }
-        if (sub == 0) v = fmaf(V[t * nout_p + co], bt[cm], v);
-        dst = dw3 + ((size_t)co * C + cm) * 27 + t;
     } else {                                                      // dbT[cm]
         const int cm = idx - n1 - n2;
         for (int t = sub; t < 27; t += 8) {
@@ -979,7 +993,7 @@ extern "C" int ctu_upconv_fused_project(const float* dweff, const float* gout, i
     CTU_CHECK_LAUNCH("upconv_v");
     const float* w3t = pack_ws;
     const float* wtt = pack_ws + (size_t)27 * C * nout_p;
-    const int total = (C * C * 8 + Co * C * 27 + C) * 8;
+    const int total = (C * C * 8 + ((Co + 3) / 4) * C * 27 + C) * 8;
     upconv_project_kernel<<<ceil_div(total, 256), 256, 0, st>>>(dweff, V, wtt, w3t, bt, imap, C, Co, cin_p, nout_p, dwt, dw3, dbt);
     CTU_CHECK_LAUNCH("upconv_project");
     return CTU_OK;

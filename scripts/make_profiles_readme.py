@@ -74,7 +74,8 @@ projections → 3.98 → 3.93 w-parity-in-tile forward for 8 output channels →
 blocks where the coarse volume has fewer boxes than CUs → 3.76 parallel loss / first-layer slab reductions →
 3.60 register-prefetched, ring-pipelined small-volume forward kernel → 3.56 one block per CU for small weight
 gradients, shuffle finalizes, in-place loss scalars → 3.48 BatchNorm-backward reductions emitted by the max-pool and head
-backward kernels → {d['ms_per_step']:.2f} batched, branch-free staging loads in the ConvTranspose kernels.
+backward kernels → {d['ms_per_step']:.2f} batched, branch-free staging loads in the ConvTranspose kernels, output-channel quads per lane in the
+composite-weight packing and projection kernels.
 """
 open(f"{ROOT}/profiles/README.md", "w").write(txt)
 print(txt[:600])
