@@ -50,6 +50,25 @@ def test_library_exports_every_declared_symbol():
     assert loaded.ctu_conv3d_num_blocks(1, 8, 8, 8, 5, 16, 0) == 8              # generic kernel: one row per box
 
 
+def test_stale_library_is_refused(monkeypatch):
+    """A libctunet_hip.so whose ABI version differs from the one _lib.py binds must fail at load, not misbehave later
+    (signatures changed during the round: ctu_loss_bwd, ctu_bn_finalize, ctu_bn_bwd_finalize)."""
+    from ctunet_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "ABI_VERSION", _lib.ABI_VERSION + 1000)
+    with pytest.raises(ImportError, match="stale build"):
+        _lib.load()
+    monkeypatch.undo()
+    assert _lib.load().ctu_abi_version() == _lib.ABI_VERSION
+
+
+def test_loss_total_adds_terms_without_an_int_zero():
+    from ctunet_amd import losses
+    a, b, c = torch.tensor(1.5), torch.tensor(2.0), torch.tensor(-0.25)
+    assert losses._total([a]) is a
+    assert float(losses._total([a, b, c])) == 3.25
+
+
 def test_no_gpu_no_fallback():
     """The product path refuses CPU tensors instead of silently computing elsewhere."""
     import ctunet_amd
