@@ -57,6 +57,8 @@ kernel and launch, FETCH_SIZE doubled as the gfx950 guide prescribes.  The roofl
 {pk['hbm_bytes_per_launch'] / 1e6:.0f} MB per launch ({pk['read_bytes_per_launch'] / 1e6:.0f} read + {pk['write_bytes_per_launch'] / 1e6:.0f} written) against {d['roofline']['algorithmic_mb_per_launch']:.0f} MB algorithmic (halo overlap of a
 4×4×32 box; FETCH_SIZE counts L2 misses that the Infinity Cache absorbs, so this is fabric traffic, not DRAM traffic);
 the kernel is MFMA-bound either way.
+`r01_pmc_roofline_kernel.txt` — SQ counters of the roofline kernel (`scripts/pmc_roofline_kernel.sh`): the MFMA count equals
+the pair layout's 36-tap count exactly, the matrix pipe is busy 72 % of the kernel's shader cycles, VALU/MFMA co-execution is 0.
 `r01_mid_kernel_stats.csv` — the same profile earlier in the round (10.1 ms/step) for comparison.
 
 Secondary numbers (`scripts/bench_classes.py`, eagerly launched train steps at 128³, same box class): `UNet` 4.08 ms,
