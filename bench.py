@@ -178,20 +178,15 @@ def main():
     step = eager_step
     mode = "eager"
     if use_graph:
-        try:
-            from ctunet_amd.graph import GraphedTrainStep
-            gstep = GraphedTrainStep(net, opt, x, [target], 1.0, 1.0, input_requires_grad=True,
-                                     distributed=distributed)
+        # a failed capture is fatal (non-zero exit): the headline number is never silently measured on eager launches;
+        # eager is the explicit --eager flag, decided identically on every rank before any step runs
+        from ctunet_amd.graph import GraphedTrainStep
+        gstep = GraphedTrainStep(net, opt, x, [target], 1.0, 1.0, input_requires_grad=True, distributed=distributed)
 
-            def step():
-                vals = gstep(x, [target])                   # same batch each step (synthetic), copied in like a loader would
-                holder.losses_and_metrics.setdefault("epoch_loss", []).append(vals.tolist()[-1])   # one D2H sync
-            mode = "hipgraph"
-        except Exception as e:                              # capture unsupported -> measured eagerly, and said so
-            log(f"graph capture failed ({type(e).__name__}: {e}); falling back to eager launches")
-            step = eager_step
-            if distributed:
-                parallel.distribute(net, broadcast=False)
+        def step():
+            vals = gstep(x, [target])                   # same batch each step (synthetic), copied in like a loader would
+            holder.losses_and_metrics.setdefault("epoch_loss", []).append(vals.tolist()[-1])   # one D2H sync
+        mode = "hipgraph"
 
     def barrier():
         if distributed:

@@ -92,13 +92,17 @@ SIGNATURES = {
     "ctu_one_hot": (I, [P, I, I, L, P, P]),
     "ctu_hard_dice_ws_doubles": (Z, [I]),
     "ctu_hard_dice_counts": (I, [P, P, I, I, L, P, P, P]),
+    "ctu_hausdorff_ws_bytes": (Z, [I, I, I, I, I]),
+    "ctu_hausdorff": (I, [P, P, I, I, I, I, I, P, P, P]),
+    "ctu_extract_patches": (I, [P, P, I, I, I, I, I, I, I, I, P, P]),
+    "ctu_stitch_patches": (I, [P, P, I, I, I, I, I, I, I, I, P, P]),
     "ctu_channel_sum_num_blocks": (I, [L]),
     "ctu_channel_sum": (I, [P, I, I, L, P, P, I, P]),
     "ctu_adam_amsgrad": (I, [P, P, I, P, D, D, D, D, D, I, P]),
 }
 
 _lib = None
-ABI_VERSION = 2          # CTU_ABI_VERSION of the csrc/ this file mirrors (bumped on any signature change)
+ABI_VERSION = 3          # CTU_ABI_VERSION of the csrc/ this file mirrors (bumped on any signature change)
 
 
 class CtuError(RuntimeError):

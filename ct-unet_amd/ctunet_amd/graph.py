@@ -26,6 +26,7 @@ class GraphedTrainStep:
                  example_targets: Sequence[torch.Tensor], ce_lambda: float, dice_lambda: float,
                  input_requires_grad: bool = True, warmup: int = 3, distributed: bool = False, process_group=None):
         self.model, self.opt = model, optimizer
+        self._params = [p for p in model.parameters()]
         self.distributed, self.group = distributed, process_group
         if distributed and model.__dict__.get("_grad_sync_cfg") is not None:
             raise RuntimeError("GraphedTrainStep(distributed=True) does its own all-reduce: do not also call "
@@ -144,4 +145,8 @@ class GraphedTrainStep:
             import torch.distributed as dist
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
             self.graph2.replay()
+        # the replayed optimizer kernel wrote the parameters through raw pointers: bump their version counters, so that
+        # an eagerly launched forward after this replay (the reference's train-then-validate epoch loop,
+        # Model.py:240-243) re-packs the engine's MFMA-ordered weight copies instead of hitting a stale cache entry
+        torch.autograd.graph.increment_version(self._params)
         return self.values

@@ -59,8 +59,12 @@ class dice_loss(nn.Module):
         return fused_ce_dice(output, masks, 0.0, 1.0, False)[1]
 
 
-def _total(terms: Sequence[torch.Tensor]) -> torch.Tensor:
-    """terms[0] + terms[1] + ... (the builtin sum() starts from int 0: one more elementwise launch per step)."""
+def _total(terms: Sequence[torch.Tensor], like: torch.Tensor = None) -> torch.Tensor:
+    """terms[0] + terms[1] + ... (the builtin sum() starts from int 0: one more elementwise launch per step).
+    No term at all (both lambdas 0): the reference's ``sum([])`` is the int 0 (ProblemHandler.py:91) -- a zero scalar
+    here, so that ``float(model.pt_loss)`` and the epoch_loss log behave the same."""
+    if not terms:
+        return torch.zeros((), dtype=torch.float32, device=None if like is None else like.device)
     total = terms[0]
     for t in terms[1:]:
         total = total + t
@@ -87,14 +91,22 @@ def comp_losses_metrics_single(model, prediction, target, idx, n_imgs):
     """``ProblemHandler.comp_losses_metrics`` (ProblemHandler.py:44-102): CE + Dice on the raw map."""
     ce_l, dc_l = model.params["ce_lambda"], model.params["dice_lambda"]
     if target.dim() != 5:
-        raise NotImplementedError("ctunet_amd: integer (non one-hot) targets are not implemented")
+        # integer class labels [N,D,H,W] are used as they are by the cross entropy (ProblemHandler.py:67-68); the Dice
+        # term of the reference cannot take them (dice_loss multiplies [N,2V] by [N,V], utilities.py:45-47: RuntimeError)
+        if dc_l != 0:
+            raise RuntimeError("ctunet_amd: dice_loss needs a one-hot target of the prediction's shape "
+                               f"(got {tuple(target.shape)} for {tuple(prediction.shape)}), as in the reference")
+        if target.dim() != 4 or target.shape != prediction.shape[:1] + prediction.shape[2:]:
+            raise RuntimeError(f"ctunet_amd: class-index target {tuple(target.shape)} does not match {tuple(prediction.shape)}")
+        from . import ops
+        target = ops.one_hot(target.float().contiguous(), prediction.shape[1])
     ce, dc = fused_ce_dice(prediction, target, ce_l or 0.0, dc_l or 0.0, False)
     keys, terms = [], []
     if ce_l != 0:
         keys.append("ce"); terms.append(ce)
     if dc_l != 0:
         keys.append("dice_loss"); terms.append(dc)
-    model.pt_loss = _total(terms)
+    model.pt_loss = _total(terms, prediction)
     _metrics(model, [("dice_coef", prediction, target)])
     _publish(model, keys, terms, idx, n_imgs, getattr(model, "verbose", True))
 
@@ -112,16 +124,19 @@ def comp_losses_metrics_double(model, prediction, target, idx, n_imgs):
         keys += ["ce_sk", "ce_fl"]; terms += [ce_s, ce_f]
     if dc_l != 0:
         keys += ["dice_loss_sk", "dice_loss_fl"]; terms += [dc_s, dc_f]
-    model.pt_loss = _total(terms)
-    _metrics(model, [("dice_coef_sk", sk_p, sk_t), ("dice_coef_fl", fl_p, fl_t)])
+    model.pt_loss = _total(terms, sk_p)
+    _metrics(model, [("dice_coef_sk", sk_p, sk_t), ("dice_coef_fl", fl_p, fl_t)], hd=True)
     _publish(model, keys, terms, idx, n_imgs, getattr(model, "verbose", True))
 
 
-def _metrics(model, items) -> None:
+def _metrics(model, items, hd: bool = False) -> None:
     if model.params.get("save_dice_plots") is True:
         from .utilities import dice_coeff
         for key, p, t in items:
             _append(model.losses_and_metrics, key, dice_coeff(p, t))
-    if model.params.get("save_hd_plots") is True:
-        raise NotImplementedError("ctunet_amd: the Hausdorff-distance metric (monai, utilities.py:62-70) is out of "
-                                  "scope of the hot path; set b_save_hd_plots = False")
+    # Hausdorff: only the double-output handler logs it (ProblemHandler.py:287-295: keys hd_coef_sk / hd_coef_fl)
+    if hd and model.params.get("save_hd_plots") is True:
+        from .utilities import hausdorff
+        for key, p, t in items:
+            hk = key.replace("dice_coef", "hd_coef")
+            _append(model.losses_and_metrics, hk, hausdorff(p, t))

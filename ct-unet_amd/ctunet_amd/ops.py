@@ -693,3 +693,47 @@ def hard_dice_counts(pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
     _lib.check(lib.ctu_hard_dice_counts(pred.data_ptr(), target.data_ptr(), n, c, v, counts.data_ptr(), ws.data_ptr(),
                                         _stream()), "hard_dice_counts")
     return counts
+
+
+def hausdorff(pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """float32 [N, C-1]: symmetric Euclidean Hausdorff distance between the surfaces of argmax(pred, 1) == c and
+    target[:, c] for c = 1..C-1 (NaN where either surface is empty)."""
+    n, c, v = _ncv(pred)
+    if pred.dim() != 5 or target.shape != pred.shape or _ncv(target) != (n, c, v):
+        raise RuntimeError("ctunet_amd: hausdorff expects a [N,C,D,H,W] prediction and a one-hot target of the same shape")
+    d, h, w = pred.shape[2:]
+    lib = _lib.load()
+    ws = torch.empty(lib.ctu_hausdorff_ws_bytes(n, c, d, h, w), dtype=torch.uint8, device=pred.device)
+    out = torch.empty((n, c - 1), dtype=torch.float32, device=pred.device)
+    _lib.check(lib.ctu_hausdorff(pred.data_ptr(), target.data_ptr(), n, c, d, h, w, out.data_ptr(), ws.data_ptr(), _stream()),
+               "hausdorff")
+    return out
+
+
+def extract_patches(vol: torch.Tensor, coords: torch.Tensor, patch: Tuple[int, int, int]) -> torch.Tensor:
+    """vol [C,D,H,W] float32 CUDA, coords int32 CUDA [P,3] (z0,y0,x0) -> [P,C,pd,ph,pw] (zero outside the volume)."""
+    _need_cuda(vol, "volume")
+    _need_cuda(coords, "patch coordinates")
+    if vol.dim() != 4 or coords.dim() != 2 or coords.shape[1] != 3 or coords.dtype != torch.int32:
+        raise RuntimeError("ctunet_amd: extract_patches expects vol [C,D,H,W] and int32 coords [P,3]")
+    vol, coords = vol.contiguous(), coords.contiguous()
+    c, d, h, w = vol.shape
+    p = coords.shape[0]
+    out = torch.empty((p, c) + tuple(patch), dtype=torch.float32, device=vol.device)
+    _lib.check(_lib.load().ctu_extract_patches(vol.data_ptr(), coords.data_ptr(), p, c, d, h, w, patch[0], patch[1], patch[2],
+                                               out.data_ptr(), _stream()), "extract_patches")
+    return out
+
+
+def stitch_patches(patches: torch.Tensor, coords: torch.Tensor, shape: Tuple[int, int, int]) -> torch.Tensor:
+    """patches [P,C,pd,ph,pw] + coords -> [C,D,H,W]: mean over the patches covering each voxel."""
+    _need_cuda(patches, "patches")
+    _need_cuda(coords, "patch coordinates")
+    if patches.dim() != 5 or coords.shape != (patches.shape[0], 3) or coords.dtype != torch.int32:
+        raise RuntimeError("ctunet_amd: stitch_patches expects patches [P,C,pd,ph,pw] and int32 coords [P,3]")
+    patches, coords = patches.contiguous(), coords.contiguous()
+    p, c, pd, ph, pw = patches.shape
+    out = torch.empty((c,) + tuple(shape), dtype=torch.float32, device=patches.device)
+    _lib.check(_lib.load().ctu_stitch_patches(patches.data_ptr(), coords.data_ptr(), p, c, shape[0], shape[1], shape[2], pd, ph,
+                                              pw, out.data_ptr(), _stream()), "stitch_patches")
+    return out

@@ -6,6 +6,10 @@ builds them (ctunet/pytorch/Model.py:514-527): same hyper-parameter names and de
 ``None`` (the dead centre block) are skipped and keep no state, as in torch.  torch's own capturable
 amsgrad path issues two elementwise kernels per parameter tensor (116 launches per step for UNet()); this
 issues two launches in total and is safe to capture in a HIP graph (the step counter lives on the device).
+Deviation from torch: ONE step counter per parameter group (``group["step_t"]``, also what ``state[p]["step"]``
+refers to), where torch keeps one per tensor -- a parameter that receives its first gradient later than the others
+of its group therefore shares their bias correction (no shipped model has such a parameter: the dead centre block
+never gets a gradient at all).
 """
 from __future__ import annotations
 
@@ -40,6 +44,10 @@ class Adam(torch.optim.Optimizer):
                 continue
             if "step_t" not in group:
                 group["step_t"] = torch.zeros(1, dtype=torch.float32, device=live[0].device)
+            elif group["step_t"].device != live[0].device:
+                # load_state_dict casts per-parameter state to the parameter's device but leaves param_groups values
+                # where the checkpoint had them (map_location="cpu"): the kernel must never see a host pointer
+                group["step_t"] = group["step_t"].to(live[0].device)
             ptrs, sizes = [], []
             for p in live:
                 if not p.is_cuda or p.dtype != torch.float32:

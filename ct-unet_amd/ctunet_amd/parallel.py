@@ -100,16 +100,18 @@ def distribute(module: torch.nn.Module, process_group=None, bucket_bytes: int = 
     if not dist.is_initialized():
         raise RuntimeError("ctunet_amd.parallel.distribute: torch.distributed is not initialised")
     if broadcast:
-        for t in list(module.parameters()) + list(module.buffers()):
-            dist.broadcast(t.data, src=0, group=process_group)
+        broadcast_parameters(module, process_group)
     module.__dict__["_grad_sync_cfg"] = (process_group, bucket_bytes)
     return module
 
 
 def broadcast_parameters(module: torch.nn.Module, process_group=None) -> torch.nn.Module:
     """Make every rank start from rank 0's parameters and buffers (no gradient hook is installed)."""
-    for t in list(module.parameters()) + list(module.buffers()):
+    ts = list(module.parameters()) + list(module.buffers())
+    for t in ts:
         dist.broadcast(t.data, src=0, group=process_group)
+    # .data writes are invisible to the version counters the engine's packed-weight caches are keyed on
+    torch.autograd.graph.increment_version(ts)
     return module
 
 

@@ -65,10 +65,8 @@ class StepRunner:
             p["optimizer"] = torch.optim.SGD(net.parameters(), lr=lr, momentum=p.get("momentum", 0) or 0, weight_decay=wd)
         elif not isinstance(name, torch.optim.Optimizer):
             raise ValueError(f"ctunet_amd: unknown optimizer '{name}'")
-        if p.get("scheduler"):
+        if "scheduler" in p:      # built whenever the key exists, whatever its value (Model.py:544-546)
             p["scheduler"] = torch.optim.lr_scheduler.ReduceLROnPlateau(p["optimizer"])
-        else:
-            p["scheduler"] = None
 
     def forward_pass(self, phase: str, data_loader) -> None:
         """One pass over ``data_loader``: 'train' updates the parameters, 'validation'/'val' only evaluates the

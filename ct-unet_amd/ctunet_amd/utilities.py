@@ -63,3 +63,18 @@ def dice_coeff(pred, target):
     cnt = ops.hard_dice_counts(pred.detach().float().contiguous(), target.detach().float().contiguous())[:, 1:]
     inter, tot = cnt[..., 0], cnt[..., 1] + cnt[..., 2]
     return torch.where(tot > 0, 2 * inter / tot.clamp_min(1), torch.ones_like(tot)).mean().float()
+
+
+def hausdorff(result_b, reference_b):
+    """Hausdorff distance of argmax(result_b) against a one-hot reference, mean over batch and foreground classes.
+
+    The reference calls ``monai.metrics.compute_hausdorff_distance(one_hot(argmax(result_b, 1)), reference_b)`` and maps
+    nan / inf to ``max(reference_b.shape)`` (utilities.py:62-70).  monai is unpinned, un-vendored and absent here, so
+    the surface definition (mask & ~erode(mask), 6-neighbourhood), the Euclidean metric and the symmetric maximum follow
+    its published algorithm; PARITY UNPINNED (tests compare with the same definition on scipy.ndimage).
+    One exact integer distance transform per (item, class, side) on the GPU (``ctu_hausdorff``).
+    """
+    from . import ops
+    inf_alt = float(max(reference_b.shape))
+    hd = ops.hausdorff(result_b.detach().float().contiguous(), reference_b.detach().float().contiguous())
+    return torch.nan_to_num(hd, nan=inf_alt, posinf=inf_alt, neginf=inf_alt).mean()

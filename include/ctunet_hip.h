@@ -150,7 +150,7 @@ int ctu_conv3d_first_wgrad(const float* x, int cin, const float* g, int g_cs, fl
  *  scale = gamma*invstd, shift = beta - mean*scale (0 for padded channels)
  *  running_mean/var updated `n_updates` times with momentum (unbiased var), as
  *  nn.BatchNorm3d does; n_updates = 2 reproduces the double update that
- *  torch.utils.checkpoint causes (models.py:232-255).  num_batches_tracked is the host's.
+ *  torch.utils.checkpoint causes (models.py:232-255).
  * mean_out/invstd_out [cp] are saved for backward. */
 int ctu_bn_finalize(const float* stats, int nblocks, int C, int cp, double count,
                     const float* gamma, const float* beta,
@@ -308,8 +308,8 @@ int ctu_upconv_fused_fwd(const float* in, int in_cs, int cin_p, const float* in_
                          int in_relu, const float* wp, const float* beff, float* out, int out_cs, int nout_p,
                          float* stats, int N, int D, int H, int W, void* stream);
 
-/* Backward of the fused up-convolution w.r.t. the three parameter tensors (the data gradient still takes the two
- * unfused kernels).  ctu_upconv_fused_wgrad: dweff [8 parities][8 taps][cin_p][nout_p] = sum_i x[i+d]^T dy[2i+p]
+/* Backward of the fused up-convolution w.r.t. the three parameter tensors (its data gradient: ctu_upconv_fused_bwd_data
+ * below).  ctu_upconv_fused_wgrad: dweff [8 parities][8 taps][cin_p][nout_p] = sum_i x[i+d]^T dy[2i+p]
  * (in = COARSE activations with the lazy transform, gout = fine-grid gradient of the fused op's raw output).
  * ctu_upconv_fused_project: dWT, dbT, dW3 (torch layouts) from dweff and the border-aware sums of gout; pack_ws is
  * the scratch ctu_upconv_fused_pack filled in this step's forward, imap maps logical input channels to padded positions. */
@@ -343,6 +343,25 @@ int ctu_one_hot(const float* label, int N, int C, int64_t nvox_per_item, float* 
 size_t ctu_hard_dice_ws_doubles(int N);
 int ctu_hard_dice_counts(const float* pred, const float* target, int N, int C, int64_t nvox_per_item,
                          double* counts, double* ws, void* stream);
+
+/* hausdorff (ctunet/utilities.py:62-70 = monai compute_hausdorff_distance on one_hot(argmax(pred,1)), background
+ * excluded, Euclidean, symmetric, no percentile): out[n][c-1], c = 1..C-1 = max over the surface voxels of either set of
+ * the distance to the other set's surface; surface = mask & ~erode(mask) (6-neighbourhood, background outside the
+ * volume); the distances come from an exact integer squared-distance transform.  NaN where either surface is empty (the
+ * caller maps it, utilities.py:69).  pred / target [N,C,D,H,W]; ws: ctu_hausdorff_ws_bytes() bytes.  PARITY UNPINNED
+ * (monai is not in the reference tree); tested against the same definition on scipy.ndimage. */
+size_t ctu_hausdorff_ws_bytes(int N, int C, int D, int H, int W);
+int ctu_hausdorff(const float* pred, const float* target, int N, int C, int D, int H, int W, float* out, void* ws,
+                  void* stream);
+
+/* Patch tiling of whole volumes (BASELINE config 4: skull volumes tiled to 192^3 patches; the tiles carry the sample
+ * schema of ctunet/pytorch/datasets.py:89-112,195-235).  coords: DEVICE int32 [P][3] = (z0, y0, x0) of each patch.
+ *   extract: out [P,C,pd,ph,pw] = vol [C,D,H,W] windows, zero-filled outside the volume
+ *   stitch:  out [C,D,H,W] = mean over the patches covering each voxel (fixed patch order, no atomics), 0 if none */
+int ctu_extract_patches(const float* vol, const int32_t* coords, int P, int C, int D, int H, int W, int pd, int ph,
+                        int pw, float* out, void* stream);
+int ctu_stitch_patches(const float* patches, const int32_t* coords, int P, int C, int D, int H, int W, int pd, int ph,
+                       int pw, float* out, void* stream);
 
 /* Per-channel sum over voxels of a channels-last tensor: out[c] = sum_v x[v,c] (bias grads). */
 int ctu_channel_sum_num_blocks(int64_t nvox);

@@ -67,6 +67,24 @@ def test_loss_total_adds_terms_without_an_int_zero():
     a, b, c = torch.tensor(1.5), torch.tensor(2.0), torch.tensor(-0.25)
     assert losses._total([a]) is a
     assert float(losses._total([a, b, c])) == 3.25
+    z = losses._total([])                # both lambdas 0: the reference's sum([]) == 0 (ProblemHandler.py:91)
+    assert float(z) == 0.0 and z.dim() == 0
+
+
+def test_scheduler_is_built_whenever_the_key_exists(monkeypatch):
+    """Model.py:544-546: ``if 'scheduler' in self.params`` -- b_scheduler = False still gets a ReduceLROnPlateau."""
+    from ctunet_amd import trainer
+    import ctunet_amd
+
+    class _Run(trainer.StepRunner):
+        def __init__(self, params):
+            self.params = dict(params)
+            self.models = {"main": ctunet_amd.UNet(n_blocks=2, i_size=2)}
+            self.initialize_optimizer()
+    base = dict(optimizer="sgd", learning_rate=0.1, momentum=0.9, weight_decay=0.0)
+    r = _Run(dict(base, scheduler=False))
+    assert isinstance(r.params["scheduler"], torch.optim.lr_scheduler.ReduceLROnPlateau)
+    assert "scheduler" not in _Run(base).params
 
 
 def test_no_gpu_no_fallback():
