@@ -274,6 +274,7 @@ def main():
         real_stdout.flush()
     if distributed:
         dist.barrier()
+        parallel.close_communicators()
         dist.destroy_process_group()
 
 

@@ -16,8 +16,8 @@ struct FirstP {
     const float* x;        // NCDHW input planes [N][CIN][D][H][W]
     const float* w;        // torch weight [Co][CIN][27]
     const float* bias;
-    const float* g;        // channels-last gradient / output side tensor (8 padded channels)
-    float* out;            // fwd: channels-last output; bwd-data: NCDHW dx
+    const void* g;         // channels-last gradient / output side tensor (8 padded channels), element type T
+    void* out;             // fwd: channels-last output (T); bwd-data: NCDHW dx (float)
     float* stats;
     float* ws;
     int g_cs, out_cs, Co, nbias;
@@ -39,7 +39,7 @@ __device__ __forceinline__ void box_origin(const FirstP& p, int t, int TW, int& 
 //   out[(d,h,2m+s), co] = sum x[(d+kd, h+kh, 2m+kw') - 1][ci] * W[co][ci][kd,kh,kw'-s]   (0 <= kw'-s <= 2)
 // K = 36*CIN -> 9*CIN MFMAs per 32 voxels.  The per-lane weight fragments (9*CIN floats) and LDS offsets are
 // computed once per block; each MFMA needs a single ds_read_b32.  Box 4x4x32, persistent, register prefetch.
-template <int CIN>
+template <int CIN, class T>
 __global__ __launch_bounds__(256) void first_fwd_kernel(FirstP p, int tiles_per_block) {
     constexpr int TW = 32, HD = TD + 2, HH = TH + 2, HW = TW + 2, HV = HD * HH * HW;
     constexpr int NIT = (HV * CIN + 255) / 256;
@@ -116,8 +116,8 @@ __global__ __launch_bounds__(256) void first_fwd_kernel(FirstP p, int tiles_per_
         for (int mt = 0; mt < 4; ++mt) {
             const int gh = h0 + mt;
             if (gd < p.D && gh < p.H && gw < p.W) {
-                const float4 o = make_float4(acc[mt][0] + bv.x, acc[mt][1] + bv.y, acc[mt][2] + bv.z, acc[mt][3] + bv.w);
-                *reinterpret_cast<float4*>(p.out + ((((size_t)n * p.D + gd) * p.H + gh) * p.W + gw) * p.out_cs + cq) = o;
+                const float4 o = rnd4<T>(make_float4(acc[mt][0] + bv.x, acc[mt][1] + bv.y, acc[mt][2] + bv.z, acc[mt][3] + bv.w));
+                st4<T>(reinterpret_cast<T*>(p.out) + ((((size_t)n * p.D + gd) * p.H + gh) * p.W + gw) * p.out_cs + cq, o);
                 s1[0] += o.x; s1[1] += o.y; s1[2] += o.z; s1[3] += o.w;
                 s2[0] += o.x * o.x; s2[1] += o.y * o.y; s2[2] += o.z * o.z; s2[3] += o.w * o.w;
             }
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void first_fwd_kernel(FirstP p, int tiles_per_
 }
 
 // ------------------------------------------------------------------ input gradient: dx[v][ci] = sum g[v - tap + 1][co] W[co][ci][tap]
-template <int CIN>
+template <int CIN, class T>
 __global__ __launch_bounds__(256) void first_bwd_data_kernel(FirstP p, int tiles_per_block) {
     constexpr int TW = 32, HD = TD + 2, HH = TH + 2, HW = TW + 2, HV = HD * HH * HW, GS = 12;
     constexpr int NIT = (HV * 2 + 255) / 256;
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void first_bwd_data_kernel(FirstP p, int tiles
             const int gd = d0 + pd - 1, gh = h0 + ph - 1, gw = w0 + pw - 1;
             float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
             if (e < HV * 2 && (unsigned)gd < (unsigned)p.D && (unsigned)gh < (unsigned)p.H && (unsigned)gw < (unsigned)p.W)
-                val = *reinterpret_cast<const float4*>(p.g + ((((size_t)n * p.D + gd) * p.H + gh) * p.W + gw) * p.g_cs + half * 4);
+                val = ld4<T>(reinterpret_cast<const T*>(p.g) + ((((size_t)n * p.D + gd) * p.H + gh) * p.W + gw) * p.g_cs + half * 4);
             vg[it] = val;
         }
     };
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void first_bwd_data_kernel(FirstP p, int tiles
         if (gd < p.D && gh < p.H) {
 #pragma unroll
             for (int ci = 0; ci < CIN; ++ci) {
-                float* dst = p.out + ((int64_t)n * CIN + ci) * plane + ((int64_t)gd * p.H + gh) * p.W;
+                float* dst = reinterpret_cast<float*>(p.out) + ((int64_t)n * CIN + ci) * plane + ((int64_t)gd * p.H + gh) * p.W;
                 if (w0 + tw < p.W) dst[w0 + tw] = a0[ci];
                 if (w0 + tw + 16 < p.W) dst[w0 + tw + 16] = a1[ci];
             }
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void first_bwd_data_kernel(FirstP p, int tiles
 }
 
 // ------------------------------------------------------------------ weight gradient: M = (tap, ci), N = co, K = voxels
-template <int CIN>
+template <int CIN, class T>
 __global__ __launch_bounds__(256) void first_wgrad_kernel(FirstP p, int tiles_per_block) {
     constexpr int TW = 32, HD = TD + 2, HH = TH + 2, HW = TW + 2, HV = HD * HH * HW, NV = TD * TH * TW;
     constexpr int MTN = (27 * CIN + 15) / 16;                  // M tiles
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void first_wgrad_kernel(FirstP p, int tiles_pe
             const int gd = d0 + td_, gh = h0 + th_, gw = w0 + tw_;
             float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
             if (gd < p.D && gh < p.H && gw < p.W)
-                val = *reinterpret_cast<const float4*>(p.g + ((((size_t)n * p.D + gd) * p.H + gh) * p.W + gw) * p.g_cs + half * 4);
+                val = ld4<T>(reinterpret_cast<const T*>(p.g) + ((((size_t)n * p.D + gd) * p.H + gh) * p.W + gw) * p.g_cs + half * 4);
             vg[it] = val;
         }
     };
@@ -386,34 +386,79 @@ extern "C" int ctu_conv3d_first_num_blocks(int N, int D, int H, int W) {
     return gx;
 }
 
-extern "C" int ctu_conv3d_first_fwd(const float* x, int cin, const float* w, const float* bias, int nbias, float* out,
-                                    int out_cs, int Co, float* stats, int N, int D, int H, int W, void* stream) {
+namespace {
+
+template <class T>
+int first_fwd_impl(const float* x, int cin, const float* w, const float* bias, int nbias, T* out, int out_cs, int Co, float* stats,
+                   int N, int D, int H, int W, void* stream) {
     CTU_REQUIRE(x && w && out, "conv3d_first_fwd: null pointer");
     CTU_REQUIRE((cin == 1 || cin == 2) && Co >= 1 && Co <= 8, "conv3d_first_fwd: cin=%d Co=%d unsupported", cin, Co);
-    CTU_REQUIRE(out_cs >= 8 && out_cs % 4 == 0 && ((uintptr_t)out & 15) == 0, "conv3d_first_fwd: output slice alignment");
+    CTU_REQUIRE(out_cs >= 8 && out_cs % 4 == 0 && ((uintptr_t)out & (4 * sizeof(T) - 1)) == 0, "conv3d_first_fwd: output slice alignment");
     FirstP p{};
     p.x = x; p.w = w; p.bias = bias; p.nbias = bias ? nbias : 0; p.out = out; p.out_cs = out_cs; p.Co = Co; p.stats = stats;
     int gx, tpb;
     grid_for(fill(p, N, D, H, W, 32), 4, &gx, &tpb);
-    if (cin == 1) first_fwd_kernel<1><<<gx, 256, 0, (hipStream_t)stream>>>(p, tpb);
-    else first_fwd_kernel<2><<<gx, 256, 0, (hipStream_t)stream>>>(p, tpb);
+    if (cin == 1) first_fwd_kernel<1, T><<<gx, 256, 0, (hipStream_t)stream>>>(p, tpb);
+    else first_fwd_kernel<2, T><<<gx, 256, 0, (hipStream_t)stream>>>(p, tpb);
     CTU_CHECK_LAUNCH("conv3d_first_fwd");
     return CTU_OK;
 }
 
-extern "C" int ctu_conv3d_first_bwd_data(const float* g, int g_cs, const float* w, int cin, int Co, float* dx, int N, int D,
-                                         int H, int W, void* stream) {
+template <class T>
+int first_bwd_data_impl(const T* g, int g_cs, const float* w, int cin, int Co, float* dx, int N, int D, int H, int W, void* stream) {
     CTU_REQUIRE(g && w && dx, "conv3d_first_bwd_data: null pointer");
-    CTU_REQUIRE((cin == 1 || cin == 2) && Co >= 1 && Co <= 8 && g_cs >= 8 && g_cs % 4 == 0 && ((uintptr_t)g & 15) == 0,
+    CTU_REQUIRE((cin == 1 || cin == 2) && Co >= 1 && Co <= 8 && g_cs >= 8 && g_cs % 4 == 0 && ((uintptr_t)g & (4 * sizeof(T) - 1)) == 0,
                 "conv3d_first_bwd_data: bad argument");
     FirstP p{};
     p.g = g; p.g_cs = g_cs; p.w = w; p.out = dx; p.Co = Co;
     int gx, tpb;
     grid_for(fill(p, N, D, H, W, 32), 3, &gx, &tpb);
-    if (cin == 1) first_bwd_data_kernel<1><<<gx, 256, 0, (hipStream_t)stream>>>(p, tpb);
-    else first_bwd_data_kernel<2><<<gx, 256, 0, (hipStream_t)stream>>>(p, tpb);
+    if (cin == 1) first_bwd_data_kernel<1, T><<<gx, 256, 0, (hipStream_t)stream>>>(p, tpb);
+    else first_bwd_data_kernel<2, T><<<gx, 256, 0, (hipStream_t)stream>>>(p, tpb);
     CTU_CHECK_LAUNCH("conv3d_first_bwd_data");
     return CTU_OK;
+}
+
+template <class T>
+int first_wgrad_impl(const float* x, int cin, const T* g, int g_cs, float* dw, int Co, float* ws, int N, int D, int H, int W,
+                     void* stream) {
+    CTU_REQUIRE(x && g && dw && ws, "conv3d_first_wgrad: null pointer");
+    CTU_REQUIRE((cin == 1 || cin == 2) && Co >= 1 && Co <= 8 && g_cs >= 8 && g_cs % 4 == 0 && ((uintptr_t)g & (4 * sizeof(T) - 1)) == 0,
+                "conv3d_first_wgrad: bad argument");
+    FirstP p{};
+    p.x = x; p.g = g; p.g_cs = g_cs; p.ws = ws; p.Co = Co;
+    int gx, tpb;
+    grid_for(fill(p, N, D, H, W, 32), 5, &gx, &tpb);
+    hipStream_t st = (hipStream_t)stream;
+    if (cin == 1) {
+        first_wgrad_kernel<1, T><<<gx, 256, 0, st>>>(p, tpb);
+        first_wgrad_reduce_kernel<1><<<ceil_div(2 * 256, 64), 1024, 0, st>>>(ws, dw, Co, gx);
+    } else {
+        first_wgrad_kernel<2, T><<<gx, 256, 0, st>>>(p, tpb);
+        first_wgrad_reduce_kernel<2><<<ceil_div(4 * 256, 64), 1024, 0, st>>>(ws, dw, Co, gx);
+    }
+    CTU_CHECK_LAUNCH("conv3d_first_wgrad");
+    return CTU_OK;
+}
+
+}  // namespace
+
+extern "C" int ctu_conv3d_first_fwd(const float* x, int cin, const float* w, const float* bias, int nbias, float* out,
+                                    int out_cs, int Co, float* stats, int N, int D, int H, int W, void* stream) {
+    return first_fwd_impl<float>(x, cin, w, bias, nbias, out, out_cs, Co, stats, N, D, H, W, stream);
+}
+extern "C" int ctu_lp_conv3d_first_fwd(int dtype, const float* x, int cin, const float* w, const float* bias, int nbias, void* out,
+                                       int out_cs, int Co, float* stats, int N, int D, int H, int W, void* stream) {
+    CTU_DISPATCH_LP(dtype, return first_fwd_impl<T>(x, cin, w, bias, nbias, (T*)out, out_cs, Co, stats, N, D, H, W, stream));
+}
+
+extern "C" int ctu_conv3d_first_bwd_data(const float* g, int g_cs, const float* w, int cin, int Co, float* dx, int N, int D,
+                                         int H, int W, void* stream) {
+    return first_bwd_data_impl<float>(g, g_cs, w, cin, Co, dx, N, D, H, W, stream);
+}
+extern "C" int ctu_lp_conv3d_first_bwd_data(int dtype, const void* g, int g_cs, const float* w, int cin, int Co, float* dx, int N,
+                                            int D, int H, int W, void* stream) {
+    CTU_DISPATCH_LP(dtype, return first_bwd_data_impl<T>((const T*)g, g_cs, w, cin, Co, dx, N, D, H, W, stream));
 }
 
 extern "C" size_t ctu_conv3d_first_wgrad_ws_floats(int N, int D, int H, int W, int cin) {
@@ -425,21 +470,9 @@ extern "C" size_t ctu_conv3d_first_wgrad_ws_floats(int N, int D, int H, int W, i
 
 extern "C" int ctu_conv3d_first_wgrad(const float* x, int cin, const float* g, int g_cs, float* dw, int Co, float* ws, int N,
                                       int D, int H, int W, void* stream) {
-    CTU_REQUIRE(x && g && dw && ws, "conv3d_first_wgrad: null pointer");
-    CTU_REQUIRE((cin == 1 || cin == 2) && Co >= 1 && Co <= 8 && g_cs >= 8 && g_cs % 4 == 0 && ((uintptr_t)g & 15) == 0,
-                "conv3d_first_wgrad: bad argument");
-    FirstP p{};
-    p.x = x; p.g = g; p.g_cs = g_cs; p.ws = ws; p.Co = Co;
-    int gx, tpb;
-    grid_for(fill(p, N, D, H, W, 32), 5, &gx, &tpb);
-    hipStream_t st = (hipStream_t)stream;
-    if (cin == 1) {
-        first_wgrad_kernel<1><<<gx, 256, 0, st>>>(p, tpb);
-        first_wgrad_reduce_kernel<1><<<ceil_div(2 * 256, 64), 1024, 0, st>>>(ws, dw, Co, gx);
-    } else {
-        first_wgrad_kernel<2><<<gx, 256, 0, st>>>(p, tpb);
-        first_wgrad_reduce_kernel<2><<<ceil_div(4 * 256, 64), 1024, 0, st>>>(ws, dw, Co, gx);
-    }
-    CTU_CHECK_LAUNCH("conv3d_first_wgrad");
-    return CTU_OK;
+    return first_wgrad_impl<float>(x, cin, g, g_cs, dw, Co, ws, N, D, H, W, stream);
+}
+extern "C" int ctu_lp_conv3d_first_wgrad(int dtype, const float* x, int cin, const void* g, int g_cs, float* dw, int Co, float* ws,
+                                         int N, int D, int H, int W, void* stream) {
+    CTU_DISPATCH_LP(dtype, return first_wgrad_impl<T>(x, cin, (const T*)g, g_cs, dw, Co, ws, N, D, H, W, stream));
 }

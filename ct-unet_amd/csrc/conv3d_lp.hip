@@ -1,0 +1,655 @@
+// Reduced-precision (bf16 / fp16 storage, fp32 accumulate) 3D convolution for gfx950: BASELINE configs 4 and 5
+// ("bf16, 192^3 patches", "fp16 MFMA conv path, 256^3 patches").  nn.Conv3d(k = 3 | 5, stride 1, padding (k-1)/2) of
+// ctunet/pytorch/models.py:26,29,38,41,71,76,403,407,430,434,482-488 -- forward, data gradient (flipped / transposed
+// packing) and weight gradient -- on v_mfma_f32_16x16x32_{bf16,f16}.
+//
+// With 16-bit activations every 128^3 / 64^3 stage of the net is HBM-bound (the bf16 MFMA ridge is ~400
+// FLOP/B), so these kernels are built for bytes, not for MFMA issue rate: one voxel box per block, several blocks per
+// CU (latency hidden by occupancy instead of hand pipelining), 16-byte channels-last accesses, the lazy BatchNorm + ReLU
+// applied in fp32 while staging, BatchNorm partial sums taken from the ROUNDED outputs (the values consumers read back).
+//
+// forward / data gradient:  D[co][voxel] += A[co][k] * B[k][voxel],  k = (tap, 8-channel chunk) pairs, 4 pairs per MFMA.
+//   B fragment of a lane = 8 consecutive channels of one (voxel + tap) = ONE ds_read_b128 of the haloed LDS box;
+//   A fragment = packed weights in fragment order, read from global (L1 / L2 resident) through a register ring.
+// weight gradient:  D[ci][co] += X^T[ci][voxel] * G[voxel][co], K = 32 voxels per MFMA; both operands are channels-last
+//   LDS images read with ds_read_b64_tr_b16 (the hardware transpose), one accumulator per tap, one slab per block,
+//   deterministic slab reduction (no float atomics).
+#include "common.h"
+
+namespace {
+
+constexpr int LP_SC = 32;                 // input channels per stage (4 chunks of 8)
+
+__host__ __device__ inline int lp_nstage(int rin_p) { return (rin_p + LP_SC - 1) / LP_SC; }
+__host__ __device__ inline int lp_stage_nch(int rin_p, int st) {
+    const int r = rin_p - st * LP_SC;
+    return (r >= LP_SC ? LP_SC : r) >> 3;
+}
+__host__ __device__ inline int lp_ksteps(int taps, int nch) { return (taps * nch + 3) >> 2; }
+__host__ __device__ inline int lp_total_ksteps(int taps, int rin_p) {
+    const int ns = lp_nstage(rin_p);
+    return (ns - 1) * taps + lp_ksteps(taps, lp_stage_nch(rin_p, ns - 1));       // full stages: taps * 4 / 4
+}
+
+template <class T> struct Mfma;
+template <> struct Mfma<bf16_t> {
+    static __device__ __forceinline__ f32x4 run(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct Mfma<f16_t> {
+    static __device__ __forceinline__ f32x4 run(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+
+// ------------------------------------------------------------------------------------------------ weight packing
+// wp[kstep (global over stages)][16-wide out tile][lane][8]: element j of lane l = A[row l&15][k = 8 (l>>4) + j] of that
+// K-step: pair p = 4 s + (l >> 4) -> (tap, chunk) = (p / nch, p % nch) of the stage (nch chunks), zero for the padding pairs.
+template <class T, int KS>
+__global__ void lp_pack_conv_w_kernel(const float* __restrict__ w, T* __restrict__ wp, int Co, int Ci, const int32_t* __restrict__ cinv,
+                                      int rin_p, int nout_p, int mode) {
+    constexpr int TAPS = KS * KS * KS;
+    const int n16 = (nout_p + 15) >> 4;
+    const int total = lp_total_ksteps(TAPS, rin_p) * n16 * 512;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int j = idx & 7, lane = (idx >> 3) & 63;
+    const int nt = (idx >> 9) % n16, kg = (idx >> 9) / n16;
+    const int ns = lp_nstage(rin_p);
+    int st = kg / TAPS;
+    if (st > ns - 1) st = ns - 1;
+    const int s = kg - st * TAPS, nch = lp_stage_nch(rin_p, st);
+    const int pr = 4 * s + (lane >> 4), tap = pr / nch, ch = pr % nch;
+    const int rp = st * LP_SC + ch * 8 + j, np = nt * 16 + (lane & 15);
+    float v = 0.f;
+    if (tap < TAPS) {
+        if (mode == 0) {
+            const int ci = cinv ? cinv[rp] : (rp < Ci ? rp : -1);
+            if (ci >= 0 && np < Co) v = w[((size_t)np * Ci + ci) * TAPS + tap];
+        } else {
+            const int ci = (np < nout_p) ? (cinv ? cinv[np] : (np < Ci ? np : -1)) : -1;
+            if (ci >= 0 && rp < Co) v = w[((size_t)rp * Ci + ci) * TAPS + (TAPS - 1 - tap)];
+        }
+    }
+    wp[idx] = (T)v;
+}
+
+// ------------------------------------------------------------------------------------------------ forward / data gradient
+struct LpConvP {
+    const void* in;
+    const void* wp;
+    void* out;
+    const float* scale;
+    const float* shift;
+    const float* bias;
+    float* stats;
+    int in_cs, rin_p, relu, out_cs, nout_p, nbias;
+    int N, D, H, W, tiles_d, tiles_h, tiles_w;
+    int S;            // LDS bytes per halo voxel
+};
+
+template <class T, int KS, int NT, int BW>
+__global__ __launch_bounds__(256) void lp_conv_fwd_kernel(LpConvP p) {
+    typedef typename Vec<T>::v8 v8;
+    constexpr int TAPS = KS * KS * KS, PK = (KS - 1) / 2;
+    constexpr int TD = 4, TH = 64 / BW;
+    constexpr int HD = TD + 2 * PK, HH = TH + 2 * PK, HW = BW + 2 * PK, HV = HD * HH * HW;
+    constexpr int PF = 4;                                           // weight-fragment ring depth (K-steps ahead)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int* sK = reinterpret_cast<int*>(smem);                         // [TAPS * 4 padded to 512] byte offsets of the (tap, chunk) pairs
+    float* sXf = reinterpret_cast<float*>(smem + 2048);             // [2][32] scale / shift of the stage
+    float* sRed = reinterpret_cast<float*>(smem + 2048 + 256);      // [4 waves][NT][2][16]
+    unsigned char* sIn = smem + 2048 + 256 + 4 * NT * 32 * 4;       // haloed input box of the stage
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 15, kg = lane >> 4;
+    const int S = p.S;
+    int t = blockIdx.x;
+    const int tx = t % p.tiles_w; t /= p.tiles_w;
+    const int ty = t % p.tiles_h; t /= p.tiles_h;
+    const int tz = t % p.tiles_d;
+    const int n = t / p.tiles_d;
+    const int d0 = tz * TD, h0 = ty * TH, w0 = tx * BW;
+    const int n16 = (p.nout_p + 15) >> 4, nt0 = blockIdx.y * NT;
+    const T* in = reinterpret_cast<const T*>(p.in);
+    const T* wp = reinterpret_cast<const T*>(p.wp);
+    // this lane's voxel in each of the wave's 4 column tiles (16 voxels each): halo index of the top-left tap
+    int hb[4], lth[4], ltw;
+    ltw = (BW == 16) ? m : (m & 7);
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        lth[ct] = (BW == 16) ? ct : (ct * 2 + (m >> 3));
+        hb[ct] = ((wave * HH + lth[ct]) * HW + ltw) * S;
+    }
+    f32x4 acc[4][NT];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[ct][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ns = lp_nstage(p.rin_p);
+    const bool xf = p.scale != nullptr;
+    for (int st = 0; st < ns; ++st) {
+        const int nch = lp_stage_nch(p.rin_p, st);
+        const int nchp = nch == 3 ? 4 : nch, sh = nchp == 4 ? 2 : (nchp == 2 ? 1 : 0);
+        const int ks = lp_ksteps(TAPS, nch);
+        __syncthreads();                                            // the previous stage's reads are done
+        for (int i = tid; i < ks * 4; i += 256) {
+            const int tap = i / nch, ch = i % nch;
+            int off = 0;                                            // padding pairs: zero weights, any valid address
+            if (tap < TAPS) off = (((tap / (KS * KS)) * HH + (tap / KS) % KS) * HW + tap % KS) * S + ch * 16;
+            sK[i] = off;
+        }
+        if (xf && tid < 64) {
+            const int c = st * LP_SC + (tid & 31);
+            sXf[tid] = (c < p.rin_p) ? ((tid < 32) ? p.scale[c] : p.shift[c]) : 0.f;
+        }
+        // first weight fragments of the stage (independent of LDS)
+        const int kbase = st * TAPS;
+        v8 ring[PF][NT];
+#pragma unroll
+        for (int u = 0; u < PF; ++u)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int tile = min(nt0 + nt, n16 - 1), s = min(u, ks - 1);
+                ring[u][nt] = *reinterpret_cast<const v8*>(wp + ((size_t)((kbase + s) * n16 + tile) * 64 + lane) * 8);
+            }
+        if (xf) __syncthreads();                                    // sXf visible
+        // ---- stage the haloed box: 16-byte items (halo voxel, chunk), 4 loads in flight per thread
+        const int items = HV << sh;
+        for (int i0 = tid; i0 < items; i0 += 256 * 4) {
+            uint4 raw[4];
+            int dst[4], c8s[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * 256;
+                const int v = i >> sh, c = i & (nchp - 1);
+                c8s[u] = c * 8;
+                const int pw = v % HW, t2 = v / HW, ph = t2 % HH, pd = t2 / HH;
+                const int gd = d0 + pd - PK, gh = h0 + ph - PK, gw = w0 + pw - PK;
+                const bool ok = i < items && c < nch && (unsigned)gd < (unsigned)p.D && (unsigned)gh < (unsigned)p.H &&
+                                (unsigned)gw < (unsigned)p.W;
+                dst[u] = (i < items && c < nch) ? (v * S + c * 16) : -1;
+                raw[u] = make_uint4(0u, 0u, 0u, 0u);
+                if (ok) raw[u] = *reinterpret_cast<const uint4*>(in + ((((size_t)n * p.D + gd) * p.H + gh) * p.W + gw) * p.in_cs +
+                                                                 st * LP_SC + c * 8);
+                if (!ok && dst[u] >= 0) dst[u] |= 0x40000000;       // out of the volume: the ACTIVATED input is zero padded
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (dst[u] < 0) continue;
+                uint4 r = raw[u];
+                if (xf) {
+                    if (dst[u] & 0x40000000) r = make_uint4(0u, 0u, 0u, 0u);
+                    else {
+                        const int c8 = c8s[u];                                       // first channel of the item within the stage
+                        const f32x8 f = __builtin_convertvector(*reinterpret_cast<v8*>(&r), f32x8);
+                        f32x8 o;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const float a = fmaf(f[j], sXf[c8 + j], sXf[32 + c8 + j]);
+                            o[j] = p.relu ? fmaxf(a, 0.f) : a;
+                        }
+                        *reinterpret_cast<v8*>(&r) = __builtin_convertvector(o, v8);
+                    }
+                }
+                *reinterpret_cast<uint4*>(sIn + (dst[u] & 0x3fffffff)) = r;
+            }
+        }
+        __syncthreads();
+        // ---- K loop
+        for (int s0 = 0; s0 < ks; s0 += PF) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int s = s0 + u;
+                if (s < ks) {
+                    const int koff = sK[4 * s + kg];
+                    v8 a[NT];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) a[nt] = ring[u][nt];
+                    if (s + PF < ks) {
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            const int tile = min(nt0 + nt, n16 - 1);
+                            ring[u][nt] = *reinterpret_cast<const v8*>(wp + ((size_t)((kbase + s + PF) * n16 + tile) * 64 + lane) * 8);
+                        }
+                    }
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) {
+                        const v8 b = *reinterpret_cast<const v8*>(sIn + hb[ct] + koff);
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) acc[ct][nt] = Mfma<T>::run(a[nt], b, acc[ct][nt]);
+                    }
+                }
+            }
+        }
+    }
+    // ---- epilogue: lane holds out channels 4 kg .. 4 kg + 3 of tile nt for its voxel of column tile ct
+    T* out = reinterpret_cast<T*>(p.out);
+    float s1[NT][4], s2[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s1[nt][r] = 0.f; s2[nt][r] = 0.f; }
+    const int gd = d0 + wave, gw = w0 + ltw;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int cb = (nt0 + nt) * 16 + 4 * kg;
+        if (cb >= p.nout_p) continue;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias) {
+            bv.x = cb + 0 < p.nbias ? p.bias[cb + 0] : 0.f; bv.y = cb + 1 < p.nbias ? p.bias[cb + 1] : 0.f;
+            bv.z = cb + 2 < p.nbias ? p.bias[cb + 2] : 0.f; bv.w = cb + 3 < p.nbias ? p.bias[cb + 3] : 0.f;
+        }
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            const int gh = h0 + lth[ct];
+            if (gd < p.D && gh < p.H && gw < p.W) {
+                const float4 o = rnd4<T>(make_float4(acc[ct][nt][0] + bv.x, acc[ct][nt][1] + bv.y, acc[ct][nt][2] + bv.z,
+                                                     acc[ct][nt][3] + bv.w));
+                st4<T>(out + ((((size_t)n * p.D + gd) * p.H + gh) * p.W + gw) * p.out_cs + cb, o);
+                s1[nt][0] += o.x; s1[nt][1] += o.y; s1[nt][2] += o.z; s1[nt][3] += o.w;
+                s2[nt][0] += o.x * o.x; s2[nt][1] += o.y * o.y; s2[nt][2] += o.z * o.z; s2[nt][3] += o.w * o.w;
+            }
+        }
+    }
+    if (p.stats) {                                                  // one BatchNorm partial row [2][nout_p] per spatial block
+        __syncthreads();
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float a1 = s1[nt][r], a2 = s2[nt][r];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { a1 += __shfl_xor(a1, o); a2 += __shfl_xor(a2, o); }
+                if (m == 0) {
+                    sRed[((wave * NT + nt) * 2 + 0) * 16 + 4 * kg + r] = a1;
+                    sRed[((wave * NT + nt) * 2 + 1) * 16 + 4 * kg + r] = a2;
+                }
+            }
+        __syncthreads();
+        if (tid < NT * 32) {
+            const int nt = tid >> 5, which = (tid >> 4) & 1, c = tid & 15;
+            const int ch = (nt0 + nt) * 16 + c;
+            if (ch < p.nout_p) {
+                float s = 0.f;
+#pragma unroll
+                for (int wv = 0; wv < 4; ++wv) s += sRed[((wv * NT + nt) * 2 + which) * 16 + c];
+                p.stats[(size_t)blockIdx.x * 2 * p.nout_p + which * p.nout_p + ch] = s;
+            }
+        }
+    }
+}
+
+int lp_box_w(int W) { return W >= 16 ? 16 : 8; }
+
+int lp_fill(LpConvP& p, int N, int D, int H, int W) {
+    const int bw = lp_box_w(W), th = 64 / bw;
+    p.N = N; p.D = D; p.H = H; p.W = W;
+    p.tiles_d = ceil_div(D, 4); p.tiles_h = ceil_div(H, th); p.tiles_w = ceil_div(W, bw);
+    return N * p.tiles_d * p.tiles_h * p.tiles_w;
+}
+
+int lp_voxel_stride(int rin_p) { return rin_p >= 16 ? (rin_p >= LP_SC ? LP_SC : rin_p) * 2 + 16 : 16; }
+
+template <class T, int KS, int NT>
+int lp_conv_launch(LpConvP& p, int ntiles, hipStream_t st) {
+    constexpr int PK = (KS - 1) / 2;
+    const int bw = lp_box_w(p.W), th = 64 / bw;
+    const int hv = (4 + 2 * PK) * (th + 2 * PK) * (bw + 2 * PK);
+    const size_t lds = 2048 + 256 + 4 * NT * 32 * 4 + (size_t)hv * p.S;
+    CTU_REQUIRE(lds <= 160 * 1024, "lp_conv3d_fwd: LDS box of %zu bytes", lds);
+    const int n16 = (p.nout_p + 15) >> 4;
+    const dim3 grid(ntiles, ceil_div(n16, NT));
+    if (bw == 16) {
+        static bool raised = false;
+        if (!raised) {
+            CTU_REQUIRE(hipFuncSetAttribute((const void*)lp_conv_fwd_kernel<T, KS, NT, 16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            160 * 1024) == hipSuccess, "lp_conv3d_fwd: cannot raise the dynamic LDS limit");
+            raised = true;
+        }
+        lp_conv_fwd_kernel<T, KS, NT, 16><<<grid, 256, lds, st>>>(p);
+    } else {
+        static bool raised = false;
+        if (!raised) {
+            CTU_REQUIRE(hipFuncSetAttribute((const void*)lp_conv_fwd_kernel<T, KS, NT, 8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            160 * 1024) == hipSuccess, "lp_conv3d_fwd: cannot raise the dynamic LDS limit");
+            raised = true;
+        }
+        lp_conv_fwd_kernel<T, KS, NT, 8><<<grid, 256, lds, st>>>(p);
+    }
+    CTU_CHECK_LAUNCH("lp_conv3d_fwd");
+    return CTU_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+struct LpWgP {
+    const void* x;
+    const void* g;
+    const float* scale;
+    const float* shift;
+    float* ws;
+    int x_cs, cin_p, relu, g_cs, cout_p;
+    int N, D, H, W, tiles_d, tiles_h, tiles_w, ntiles;
+};
+
+constexpr int WG_SX = 32;      // LDS bytes per voxel of the 16-channel images
+
+// Block (x, y = (ci tile, co tile), z = kd plane for k = 5): accumulates dW[tap][16 ci][16 co] over a contiguous range of
+// boxes (4 x TH x BW voxels, 16 K-steps of 32 voxels, 4 per wave) and writes ONE slab.
+template <class T, int KS, int BW>
+__global__ __launch_bounds__(256) void lp_conv_wgrad_kernel(LpWgP p, int tiles_per_block) {
+    typedef typename Vec<T>::v8 v8;
+    constexpr int PK = (KS - 1) / 2;
+    constexpr int NTAP = (KS == 3) ? 27 : KS * KS;                  // taps per block (k = 5: one kd plane)
+    constexpr int RPK = 32 / BW, TD = 4, TH = 4 * RPK;
+    constexpr int HD = (KS == 3) ? TD + 2 : TD, HH = TH + 2 * PK, HW = BW + 2 * PK, HV = HD * HH * HW, NV = TD * TH * BW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* sXf = reinterpret_cast<float*>(smem);                    // [2][16]
+    unsigned char* sX = smem + 128;                                 // haloed input image, 16 channels
+    unsigned char* sG = sX + (size_t)HV * WG_SX;                    // gradient image, 16 channels
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15, q = i >> 2, pc = i & 3;
+    const int nco = (p.cout_p + 15) >> 4;
+    const int cit = blockIdx.y / nco, cot = blockIdx.y % nco;
+    const int kd = (KS == 3) ? 0 : blockIdx.z;                      // k = 5: this block's kd plane (halo rows d0 + td + kd - PK)
+    const T* x = reinterpret_cast<const T*>(p.x);
+    const T* gr = reinterpret_cast<const T*>(p.g);
+    const bool xf = p.scale != nullptr;
+    if (tid < 32) {
+        const int c = cit * 16 + (tid & 15);
+        float v = (tid < 16) ? 1.f : 0.f;
+        if (xf) v = (c < p.cin_p) ? ((tid < 16) ? p.scale[c] : p.shift[c]) : 0.f;
+        sXf[tid] = v;
+    }
+    // transposed-read addresses: K-step voxel kk = 8 g + 4 r + q (r = 0, 1), columns 4 pc .. 4 pc + 3
+    int xa[2], ga[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int kk = 8 * g + 4 * r + q, rr = kk / BW, tw = kk % BW;
+        xa[r] = ((wave * HH + rr) * HW + tw) * WG_SX + 8 * pc;      // + K-step row offset + tap offset
+        ga[r] = ((wave * TH + rr) * BW + tw) * WG_SX + 8 * pc;
+    }
+    f32x4 acc[NTAP];
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nchx = min(2, (p.cin_p - cit * 16) >> 3), nchg = min(2, (p.cout_p - cot * 16) >> 3);
+    int tile = blockIdx.x * tiles_per_block;
+    const int tile_end = min(p.ntiles, tile + tiles_per_block);
+    for (; tile < tile_end; ++tile) {
+        int t = tile;
+        const int tx = t % p.tiles_w; t /= p.tiles_w;
+        const int ty = t % p.tiles_h; t /= p.tiles_h;
+        const int tz = t % p.tiles_d;
+        const int n = t / p.tiles_d;
+        const int d0 = tz * TD, h0 = ty * TH, w0 = tx * BW;
+        __syncthreads();
+        // ---- stage X (haloed, lazy BatchNorm + ReLU, zero outside the volume) and G: 16-byte items
+        for (int i0 = tid; i0 < HV * 2; i0 += 256 * 4) {
+            uint4 raw[4];
+            int dst[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int it = i0 + u * 256, v = it >> 1, c = it & 1;
+                const int pw = v % HW, t2 = v / HW, ph = t2 % HH, pd = t2 / HH;
+                const int gd = d0 + pd + ((KS == 3) ? -1 : kd - PK), gh = h0 + ph - PK, gw = w0 + pw - PK;
+                const bool in_img = it < HV * 2;
+                const bool ok = in_img && c < nchx && (unsigned)gd < (unsigned)p.D && (unsigned)gh < (unsigned)p.H &&
+                                (unsigned)gw < (unsigned)p.W;
+                dst[u] = in_img ? ((v * WG_SX + c * 16) | (ok ? 0 : 0x40000000)) : -1;
+                raw[u] = make_uint4(0u, 0u, 0u, 0u);
+                if (ok) raw[u] = *reinterpret_cast<const uint4*>(x + ((((size_t)n * p.D + gd) * p.H + gh) * p.W + gw) * p.x_cs +
+                                                                 cit * 16 + c * 8);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (dst[u] < 0) continue;
+                uint4 r = raw[u];
+                if (xf && !(dst[u] & 0x40000000)) {
+                    const int c8 = (dst[u] & 16) >> 1;
+                    const f32x8 f = __builtin_convertvector(*reinterpret_cast<v8*>(&r), f32x8);
+                    f32x8 o;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float a = fmaf(f[j], sXf[c8 + j], sXf[16 + c8 + j]);
+                        o[j] = p.relu ? fmaxf(a, 0.f) : a;
+                    }
+                    *reinterpret_cast<v8*>(&r) = __builtin_convertvector(o, v8);
+                }
+                *reinterpret_cast<uint4*>(sX + (dst[u] & 0x3fffffff)) = r;
+            }
+        }
+        for (int i0 = tid; i0 < NV * 2; i0 += 256 * 4) {
+            uint4 raw[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int it = i0 + u * 256, v = it >> 1, c = it & 1;
+                const int tw = v % BW, t2 = v / BW, th = t2 % TH, td = t2 / TH;
+                const int gd = d0 + td, gh = h0 + th, gw = w0 + tw;
+                raw[u] = make_uint4(0u, 0u, 0u, 0u);
+                if (it < NV * 2 && c < nchg && gd < p.D && gh < p.H && gw < p.W)
+                    raw[u] = *reinterpret_cast<const uint4*>(gr + ((((size_t)n * p.D + gd) * p.H + gh) * p.W + gw) * p.g_cs +
+                                                             cot * 16 + c * 8);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int it = i0 + u * 256;
+                if (it < NV * 2) *reinterpret_cast<uint4*>(sG + (it >> 1) * WG_SX + (it & 1) * 16) = raw[u];
+            }
+        }
+        __syncthreads();
+        // ---- 4 K-steps per wave (td = wave; rows ks * RPK .. of the box)
+#pragma unroll 1
+        for (int ks = 0; ks < 4; ++ks) {
+            const int xo = ks * RPK * HW * WG_SX, go = ks * RPK * BW * WG_SX;
+            v8 b;
+            {
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sG + ga[0] + go));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sG + ga[1] + go));
+                typedef short s16x8 __attribute__((ext_vector_type(8)));
+                const s16x8 bb = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                b = *reinterpret_cast<const v8*>(&bb);
+            }
+#pragma unroll
+            for (int t = 0; t < NTAP; ++t) {
+                const int kdd = (KS == 3) ? t / 9 : 0, kh = (KS == 3) ? (t / 3) % 3 : t / KS, kw = (KS == 3) ? t % 3 : t % KS;
+                const int to = ((kdd * HH + kh) * HW + kw) * WG_SX;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sX + xa[0] + xo + to));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sX + xa[1] + xo + to));
+                typedef short s16x8 __attribute__((ext_vector_type(8)));
+                const s16x8 aa = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                acc[t] = Mfma<T>::run(*reinterpret_cast<const v8*>(&aa), b, acc[t]);
+            }
+        }
+    }
+    // ---- cross-wave sum in LDS (one wave after the other: the slab is 27 KB, the images' space is reused), one slab per block
+    float* sS = reinterpret_cast<float*>(smem + 128);
+    for (int wv = 0; wv < 4; ++wv) {
+        __syncthreads();
+        if (wave == wv) {
+#pragma unroll
+            for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float* e = &sS[t * 256 + (4 * g + r) * 16 + i];        // row = ci 4 g + r, col = co i
+                    *e = (wv == 0) ? acc[t][r] : (*e + acc[t][r]);
+                }
+        }
+    }
+    __syncthreads();
+    float* dst = p.ws + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (NTAP * 256);
+    for (int e = tid; e < NTAP * 256; e += 256) dst[e] = sS[e];
+}
+
+// dw[co][ci][tap] (torch layout) = sum over the gx slabs of (pair, plane); 16 slab groups x 64 elements per block
+template <int KS>
+__global__ __launch_bounds__(1024) void lp_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Co, int Ci,
+                                                              const int32_t* __restrict__ cinv, int cin_p, int cout_p, int gx) {
+    constexpr int TAPS = KS * KS * KS, NTAP = (KS == 3) ? 27 : KS * KS, NPL = TAPS / NTAP;
+    __shared__ float red[16][64];
+    const int e = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int nco = (cout_p + 15) >> 4, nci = (cin_p + 15) >> 4;
+    const int per_pair = NTAP * 256;
+    const int el = blockIdx.x * 64 + e;                             // over [plane][pair][tap][ci 16][co 16]
+    const int total = NPL * nci * nco * per_pair;
+    float s = 0.f;
+    if (el < total) {
+        const int grp = el / per_pair, within = el % per_pair;      // grp = plane * (nci * nco) + pair
+        const float* base = ws + (size_t)grp * gx * per_pair + within;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int k = part;
+        for (; k + 48 < gx; k += 64) {
+            s0 += base[(size_t)k * per_pair];
+            s1 += base[(size_t)(k + 16) * per_pair];
+            s2 += base[(size_t)(k + 32) * per_pair];
+            s3 += base[(size_t)(k + 48) * per_pair];
+        }
+        for (; k < gx; k += 16) s0 += base[(size_t)k * per_pair];
+        s = (s0 + s1) + (s2 + s3);
+    }
+    red[part][e] = s;
+    __syncthreads();
+    if (part != 0 || el >= total) return;
+    float tot = 0.f;
+#pragma unroll
+    for (int qd = 0; qd < 16; ++qd) tot += red[qd][e];
+    const int grp = el / per_pair, within = el % per_pair;
+    const int plane = grp / (nci * nco), pair = grp % (nci * nco);
+    const int t = within >> 8, row = (within >> 4) & 15, col = within & 15;
+    const int cpos = (pair / nco) * 16 + row, co = (pair % nco) * 16 + col;
+    const int ci = (cpos < cin_p) ? (cinv ? cinv[cpos] : (cpos < Ci ? cpos : -1)) : -1;
+    if (ci >= 0 && co < Co) dw[((size_t)co * Ci + ci) * TAPS + plane * NTAP + t] = tot;
+}
+
+int lp_wg_box_w(int W) { return W >= 32 ? 32 : (W >= 16 ? 16 : 8); }
+
+int lp_wg_fill(LpWgP& p, int N, int D, int H, int W) {
+    const int bw = lp_wg_box_w(W), th = 4 * (32 / bw);
+    p.N = N; p.D = D; p.H = H; p.W = W;
+    p.tiles_d = ceil_div(D, 4); p.tiles_h = ceil_div(H, th); p.tiles_w = ceil_div(W, bw);
+    p.ntiles = N * p.tiles_d * p.tiles_h * p.tiles_w;
+    return p.ntiles;
+}
+
+// persistent blocks per (pair, plane): about 768 blocks in all (3 per CU), at least 1 box each
+void lp_wg_grid(int ntiles, int groups, int* gx, int* tpb) {
+    int g = 768 / groups;
+    if (g < 16) g = 16;
+    if (g > ntiles) g = ntiles;
+    *tpb = ceil_div(ntiles, g);
+    *gx = ceil_div(ntiles, *tpb);
+}
+
+template <class T, int KS, int BW>
+int lp_wgrad_launch(LpWgP& p, int gx, int tpb, int pairs, hipStream_t st) {
+    constexpr int PK = (KS - 1) / 2, RPK = 32 / BW, TH = 4 * RPK;
+    constexpr int HD = (KS == 3) ? 6 : 4, HV = HD * (TH + 2 * PK) * (BW + 2 * PK), NV = 4 * TH * BW;
+    constexpr int NTAP = (KS == 3) ? 27 : KS * KS;
+    size_t lds = 128 + (size_t)(HV + NV) * WG_SX;
+    if (lds < 128 + (size_t)NTAP * 1024) lds = 128 + (size_t)NTAP * 1024;
+    static bool raised = false;
+    if (!raised) {
+        CTU_REQUIRE(hipFuncSetAttribute((const void*)lp_conv_wgrad_kernel<T, KS, BW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        160 * 1024) == hipSuccess, "lp_conv3d_wgrad: cannot raise the dynamic LDS limit");
+        raised = true;
+    }
+    lp_conv_wgrad_kernel<T, KS, BW><<<dim3(gx, pairs, KS == 3 ? 1 : KS), 256, lds, st>>>(p, tpb);
+    CTU_CHECK_LAUNCH("lp_conv3d_wgrad");
+    return CTU_OK;
+}
+
+template <class T, int KS>
+int lp_wgrad_dispatch(LpWgP& p, int gx, int tpb, int pairs, hipStream_t st) {
+    const int bw = lp_wg_box_w(p.W);
+    if (bw == 32) return lp_wgrad_launch<T, KS, 32>(p, gx, tpb, pairs, st);
+    if (bw == 16) return lp_wgrad_launch<T, KS, 16>(p, gx, tpb, pairs, st);
+    return lp_wgrad_launch<T, KS, 8>(p, gx, tpb, pairs, st);
+}
+
+}  // namespace
+
+// =================================================================== C ABI
+extern "C" size_t ctu_lp_conv3d_packed_elems(int k, int rin_p, int nout_p) {
+    if ((k != 3 && k != 5) || rin_p <= 0 || rin_p % 8 || nout_p <= 0 || nout_p % 8) return 0;
+    return (size_t)lp_total_ksteps(k * k * k, rin_p) * ((nout_p + 15) >> 4) * 512;
+}
+
+extern "C" int ctu_lp_conv3d_num_blocks(int N, int D, int H, int W, int k) {
+    (void)k;
+    LpConvP p;
+    return lp_fill(p, N, D, H, W);
+}
+
+extern "C" int ctu_lp_pack_conv3d_weight(int dtype, const float* w, void* wp, int Co, int Ci, int k, const int32_t* cinv,
+                                         int rin_p, int nout_p, int mode, void* stream) {
+    CTU_REQUIRE(w && wp, "lp_pack_conv3d_weight: null pointer");
+    CTU_REQUIRE((k == 3 || k == 5) && rin_p > 0 && rin_p % 8 == 0 && nout_p > 0 && nout_p % 8 == 0 && (mode == 0 || mode == 1),
+                "lp_pack_conv3d_weight: k=%d rin_p=%d nout_p=%d mode=%d", k, rin_p, nout_p, mode);
+    const size_t total = ctu_lp_conv3d_packed_elems(k, rin_p, nout_p);
+    const unsigned grid = (unsigned)ceil_div64((int64_t)total, 256);
+    hipStream_t st = (hipStream_t)stream;
+    CTU_DISPATCH_LP(dtype, {
+        if (k == 3) lp_pack_conv_w_kernel<T, 3><<<grid, 256, 0, st>>>(w, (T*)wp, Co, Ci, cinv, rin_p, nout_p, mode);
+        else lp_pack_conv_w_kernel<T, 5><<<grid, 256, 0, st>>>(w, (T*)wp, Co, Ci, cinv, rin_p, nout_p, mode);
+    });
+    CTU_CHECK_LAUNCH("lp_pack_conv3d_weight");
+    return CTU_OK;
+}
+
+extern "C" int ctu_lp_conv3d_fwd(int dtype, const void* in, int in_cs, int rin_p, const float* in_scale, const float* in_shift,
+                                 int in_relu, const void* wp, const float* bias, int nbias, void* out, int out_cs, int nout_p,
+                                 float* stats, int N, int D, int H, int W, int k, void* stream) {
+    CTU_REQUIRE(in && wp && out, "lp_conv3d_fwd: null pointer");
+    CTU_REQUIRE((k == 3 || k == 5) && rin_p > 0 && rin_p % 8 == 0 && nout_p > 0 && nout_p % 8 == 0,
+                "lp_conv3d_fwd: k=%d rin_p=%d nout_p=%d", k, rin_p, nout_p);
+    CTU_REQUIRE(in_cs >= rin_p && in_cs % 8 == 0 && out_cs >= nout_p && out_cs % 4 == 0 && ((uintptr_t)in & 15) == 0 &&
+                ((uintptr_t)out & 7) == 0 && ((uintptr_t)wp & 15) == 0, "lp_conv3d_fwd: strides / alignment (in_cs=%d out_cs=%d)", in_cs, out_cs);
+    CTU_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "lp_conv3d_fwd: scale/shift come in pairs");
+    CTU_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0, "lp_conv3d_fwd: empty volume");
+    LpConvP p{};
+    p.in = in; p.wp = wp; p.out = out; p.scale = in_scale; p.shift = in_shift; p.bias = bias; p.stats = stats;
+    p.in_cs = in_cs; p.rin_p = rin_p; p.relu = in_relu; p.out_cs = out_cs; p.nout_p = nout_p; p.nbias = bias ? nbias : 0;
+    p.S = lp_voxel_stride(rin_p);
+    const int ntiles = lp_fill(p, N, D, H, W);
+    hipStream_t st = (hipStream_t)stream;
+    const bool two = nout_p > 16;
+    int rc = CTU_OK;
+    CTU_DISPATCH_LP(dtype, {
+        if (k == 3) rc = two ? lp_conv_launch<T, 3, 2>(p, ntiles, st) : lp_conv_launch<T, 3, 1>(p, ntiles, st);
+        else rc = two ? lp_conv_launch<T, 5, 2>(p, ntiles, st) : lp_conv_launch<T, 5, 1>(p, ntiles, st);
+    });
+    return rc;
+}
+
+extern "C" size_t ctu_lp_conv3d_wgrad_ws_floats(int N, int D, int H, int W, int k, int cin_p, int cout_p) {
+    if ((k != 3 && k != 5) || cin_p <= 0 || cout_p <= 0) return 0;
+    LpWgP p;
+    const int ntiles = lp_wg_fill(p, N, D, H, W);
+    const int pairs = ((cin_p + 15) >> 4) * ((cout_p + 15) >> 4), planes = k == 3 ? 1 : k;
+    int gx, tpb;
+    lp_wg_grid(ntiles, pairs * planes, &gx, &tpb);
+    return (size_t)gx * pairs * planes * (k == 3 ? 27 : k * k) * 256;
+}
+
+extern "C" int ctu_lp_conv3d_wgrad(int dtype, const void* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
+                                   int in_relu, const void* gout, int g_cs, int cout_p, float* dw, int Co, int Ci,
+                                   const int32_t* cinv, float* ws, int N, int D, int H, int W, int k, void* stream) {
+    CTU_REQUIRE(in && gout && dw && ws, "lp_conv3d_wgrad: null pointer");
+    CTU_REQUIRE((k == 3 || k == 5) && cin_p > 0 && cin_p % 8 == 0 && cout_p > 0 && cout_p % 8 == 0,
+                "lp_conv3d_wgrad: k=%d cin_p=%d cout_p=%d", k, cin_p, cout_p);
+    CTU_REQUIRE(in_cs >= cin_p && in_cs % 8 == 0 && g_cs >= cout_p && g_cs % 8 == 0 && ((uintptr_t)in & 15) == 0 &&
+                ((uintptr_t)gout & 15) == 0, "lp_conv3d_wgrad: strides / alignment (in_cs=%d g_cs=%d)", in_cs, g_cs);
+    CTU_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "lp_conv3d_wgrad: scale/shift come in pairs");
+    LpWgP p{};
+    p.x = in; p.g = gout; p.scale = in_scale; p.shift = in_shift; p.ws = ws;
+    p.x_cs = in_cs; p.cin_p = cin_p; p.relu = in_relu; p.g_cs = g_cs; p.cout_p = cout_p;
+    const int ntiles = lp_wg_fill(p, N, D, H, W);
+    const int nci = (cin_p + 15) >> 4, nco = (cout_p + 15) >> 4, pairs = nci * nco, planes = k == 3 ? 1 : k;
+    int gx, tpb;
+    lp_wg_grid(ntiles, pairs * planes, &gx, &tpb);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = CTU_OK;
+    CTU_DISPATCH_LP(dtype, {
+        if (k == 3) rc = lp_wgrad_dispatch<T, 3>(p, gx, tpb, pairs, st);
+        else rc = lp_wgrad_dispatch<T, 5>(p, gx, tpb, pairs, st);
+    });
+    if (rc != CTU_OK) return rc;
+    const int total = planes * pairs * (k == 3 ? 27 : k * k) * 256;
+    if (k == 3) lp_wgrad_reduce_kernel<3><<<ceil_div(total, 64), 1024, 0, st>>>(ws, dw, Co, Ci, cinv, cin_p, cout_p, gx);
+    else lp_wgrad_reduce_kernel<5><<<ceil_div(total, 64), 1024, 0, st>>>(ws, dw, Co, Ci, cinv, cin_p, cout_p, gx);
+    CTU_CHECK_LAUNCH("lp_conv3d_wgrad reduce");
+    return CTU_OK;
+}

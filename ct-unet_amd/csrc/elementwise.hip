@@ -26,7 +26,8 @@ constexpr int MAX_RED_BLOCKS = 1024;
 
 // ------------------------------------------------------------------ layout
 // NCDHW -> NDHWC: one thread per (voxel, channel-quad); reads are coalesced along w per channel.
-__global__ void ncdhw_to_ndhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int64_t V,
+template <class T>
+__global__ void ncdhw_to_ndhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int C, int64_t V,
                                       int64_t total_vox, int cp, int cs) {
     const int nq = cp >> 2;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -42,17 +43,18 @@ __global__ void ncdhw_to_ndhwc_kernel(const float* __restrict__ src, float* __re
         const int c = qd * 4 + j;
         op[j] = (c < C) ? src[(n * C + c) * V + v] : 0.f;
     }
-    *reinterpret_cast<float4*>(dst + vox * cs + qd * 4) = o;
+    st4<T>(dst + vox * cs + qd * 4, o);
 }
 
-__global__ void ndhwc_to_ncdhw_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int64_t V,
+template <class T>
+__global__ void ndhwc_to_ncdhw_kernel(const T* __restrict__ src, float* __restrict__ dst, int C, int64_t V,
                                       int64_t total_vox, int cs) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total_vox * C) return;
     const int64_t vox = idx % total_vox;
     const int c = (int)(idx / total_vox);
     const int64_t n = vox / V, v = vox % V;
-    dst[(n * C + c) * V + v] = src[vox * cs + c];
+    dst[(n * C + c) * V + v] = (float)src[vox * cs + c];
 }
 
 // Sum of (a, b) over the NT threads of a block, in every thread: wave butterflies, one LDS exchange, a fixed-order sum
@@ -128,7 +130,8 @@ __global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, con
 
 // ------------------------------------------------------------------ BN+ReLU backward
 // thread = (voxel stripe, channel quad); channel quad fixed per thread so its constants sit in registers.
-__global__ void bn_relu_bwd_reduce_kernel(const float* __restrict__ y, int y_cs, const float* __restrict__ ga,
+template <class T>
+__global__ void bn_relu_bwd_reduce_kernel(const T* __restrict__ y, int y_cs, const T* __restrict__ ga,
                                           int g_cs, int cp, const float* __restrict__ scale,
                                           const float* __restrict__ shift, const float* __restrict__ mean,
                                           const float* __restrict__ invstd, int64_t nvox,
@@ -144,8 +147,8 @@ __global__ void bn_relu_bwd_reduce_kernel(const float* __restrict__ y, int y_cs,
         const float4 mu = *reinterpret_cast<const float4*>(mean + qd * 4);
         const float4 is = *reinterpret_cast<const float4*>(invstd + qd * 4);
         for (int64_t v = (int64_t)blockIdx.x * tpv + vl; v < nvox; v += (int64_t)gridDim.x * tpv) {
-            const float4 yy = *reinterpret_cast<const float4*>(y + v * y_cs + qd * 4);
-            const float4 gg = *reinterpret_cast<const float4*>(ga + v * g_cs + qd * 4);
+            const float4 yy = ld4<T>(y + v * y_cs + qd * 4);
+            const float4 gg = ld4<T>(ga + v * g_cs + qd * 4);
             float gz;
             gz = (fmaf(yy.x, sc.x, sh.x) > 0.f) ? gg.x : 0.f; a1.x += gz; a2.x += gz * (yy.x - mu.x) * is.x;
             gz = (fmaf(yy.y, sc.y, sh.y) > 0.f) ? gg.y : 0.f; a1.y += gz; a2.y += gz * (yy.y - mu.y) * is.y;
@@ -210,7 +213,8 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int n
     }
 }
 
-__global__ void bn_relu_bwd_apply_kernel(const float* __restrict__ y, int y_cs, float* __restrict__ ga, int g_cs,
+template <class T>
+__global__ void bn_relu_bwd_apply_kernel(const T* __restrict__ y, int y_cs, T* __restrict__ ga, int g_cs,
                                          int cp, const float* __restrict__ scale, const float* __restrict__ shift,
                                          const float* __restrict__ mean, const float* __restrict__ invstd,
                                          const float* __restrict__ coef, int64_t nvox) {
@@ -226,19 +230,20 @@ __global__ void bn_relu_bwd_apply_kernel(const float* __restrict__ y, int y_cs, 
     const float4 k0 = *reinterpret_cast<const float4*>(coef + qd * 4);
     const float4 k1 = *reinterpret_cast<const float4*>(coef + cp + qd * 4);
     const float4 k2 = *reinterpret_cast<const float4*>(coef + 2 * cp + qd * 4);
-    const float4 yy = *reinterpret_cast<const float4*>(y + v * y_cs + qd * 4);
-    float4 gg = *reinterpret_cast<const float4*>(ga + v * g_cs + qd * 4);
+    const float4 yy = ld4<T>(y + v * y_cs + qd * 4);
+    float4 gg = ld4<T>(ga + v * g_cs + qd * 4);
     float gz;
     gz = (fmaf(yy.x, sc.x, sh.x) > 0.f) ? gg.x : 0.f; gg.x = k0.x * (gz - k1.x - (yy.x - mu.x) * is.x * k2.x);
     gz = (fmaf(yy.y, sc.y, sh.y) > 0.f) ? gg.y : 0.f; gg.y = k0.y * (gz - k1.y - (yy.y - mu.y) * is.y * k2.y);
     gz = (fmaf(yy.z, sc.z, sh.z) > 0.f) ? gg.z : 0.f; gg.z = k0.z * (gz - k1.z - (yy.z - mu.z) * is.z * k2.z);
     gz = (fmaf(yy.w, sc.w, sh.w) > 0.f) ? gg.w : 0.f; gg.w = k0.w * (gz - k1.w - (yy.w - mu.w) * is.w * k2.w);
-    *reinterpret_cast<float4*>(ga + v * g_cs + qd * 4) = gg;
+    st4<T>(ga + v * g_cs + qd * 4, gg);
 }
 
 // ------------------------------------------------------------------ MaxPool3d(2,2)
-__global__ void maxpool2_fwd_kernel(const float* __restrict__ in, int in_cs, int cp, const float* __restrict__ scale,
-                                    const float* __restrict__ shift, int relu, float* __restrict__ out, int out_cs,
+template <class T>
+__global__ void maxpool2_fwd_kernel(const T* __restrict__ in, int in_cs, int cp, const float* __restrict__ scale,
+                                    const float* __restrict__ shift, int relu, T* __restrict__ out, int out_cs,
                                     int N, int D, int H, int W) {
     const int nq = cp >> 2;
     const int Do = D >> 1, Ho = H >> 1, Wo = W >> 1;
@@ -262,44 +267,45 @@ __global__ void maxpool2_fwd_kernel(const float* __restrict__ in, int in_cs, int
     for (int t = 0; t < 8; ++t) {
         const int d = dd * 2 + (t >> 2), h = ho * 2 + ((t >> 1) & 1), w = wo * 2 + (t & 1);
         const size_t vox = (((size_t)n * D + d) * H + h) * W + w;
-        float4 v = *reinterpret_cast<const float4*>(in + vox * in_cs + qd * 4);
+        float4 v = ld4<T>(in + vox * in_cs + qd * 4);
         if (xf) v = xform4(v, sc, sh, relu);
         best.x = fmaxf(best.x, v.x); best.y = fmaxf(best.y, v.y);
         best.z = fmaxf(best.z, v.z); best.w = fmaxf(best.w, v.w);
     }
     const size_t ovox = (((size_t)n * Do + dd) * Ho + ho) * Wo + wo;
-    *reinterpret_cast<float4*>(out + ovox * out_cs + qd * 4) = best;
+    st4<T>(out + ovox * out_cs + qd * 4, best);
 }
 
 // ---- additive skip connections (UNet(cat=False), models.py:250-251): out = act(a) + act(b), act = lazy BN + ReLU
-__global__ void skip_add_kernel(const float* __restrict__ a, int a_cs, const float* __restrict__ a_scale,
-                                const float* __restrict__ a_shift, int a_relu, const float* __restrict__ b, int b_cs,
+template <class T>
+__global__ void skip_add_kernel(const T* __restrict__ a, int a_cs, const float* __restrict__ a_scale,
+                                const float* __restrict__ a_shift, int a_relu, const T* __restrict__ b, int b_cs,
                                 const float* __restrict__ b_scale, const float* __restrict__ b_shift, int b_relu,
-                                float* __restrict__ out, int out_cs, int cp, int64_t nvox) {
+                                T* __restrict__ out, int out_cs, int cp, int64_t nvox) {
     const int nq = cp >> 2;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= nvox * nq) return;
     const int qd = (int)(idx % nq);
     const int64_t v = idx / nq;
-    float4 x = *reinterpret_cast<const float4*>(a + v * a_cs + qd * 4);
+    float4 x = ld4<T>(a + v * a_cs + qd * 4);
     if (a_scale)
         x = xform4(x, *reinterpret_cast<const float4*>(a_scale + qd * 4), *reinterpret_cast<const float4*>(a_shift + qd * 4), a_relu);
     if (b) {
-        float4 y = *reinterpret_cast<const float4*>(b + v * b_cs + qd * 4);
+        float4 y = ld4<T>(b + v * b_cs + qd * 4);
         if (b_scale)
             y = xform4(y, *reinterpret_cast<const float4*>(b_scale + qd * 4), *reinterpret_cast<const float4*>(b_shift + qd * 4), b_relu);
         x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
     }
-    *reinterpret_cast<float4*>(out + v * out_cs + qd * 4) = x;
+    st4<T>(out + v * out_cs + qd * 4, x);
 }
 
 // RED: the pooled tensor is relu(BN(raw conv output)) and gin is the gradient w.r.t. that activated tensor, complete once
 // this kernel has added its share -- so the BatchNorm-backward reduction of that layer (sum gz, sum gz * xhat per channel,
 // gz = gradient masked by the ReLU) rides along: one block-partial row per block, same layout as bn_relu_bwd_reduce.
-template <bool RED>
-__global__ void maxpool2_bwd_kernel(const float* __restrict__ in, int in_cs, int cp, const float* __restrict__ scale,
-                                    const float* __restrict__ shift, int relu, const float* __restrict__ gout,
-                                    int gout_cs, float* __restrict__ gin, int gin_cs, int accumulate, int N, int D,
+template <bool RED, class T>
+__global__ void maxpool2_bwd_kernel(const T* __restrict__ in, int in_cs, int cp, const float* __restrict__ scale,
+                                    const float* __restrict__ shift, int relu, const T* __restrict__ gout,
+                                    int gout_cs, T* __restrict__ gin, int gin_cs, int accumulate, int N, int D,
                                     int H, int W, const float* __restrict__ mean, const float* __restrict__ invstd,
                                     float* __restrict__ partials) {
     const int nq = cp >> 2;
@@ -332,7 +338,7 @@ __global__ void maxpool2_bwd_kernel(const float* __restrict__ in, int in_cs, int
     for (int t = 0; t < 8; ++t) {
         const int d = dd * 2 + (t >> 2), h = ho * 2 + ((t >> 1) & 1), w = wo * 2 + (t & 1);
         const size_t vox = (((size_t)n * D + d) * H + h) * W + w;
-        float4 v = *reinterpret_cast<const float4*>(in + vox * in_cs + qd * 4);
+        float4 v = ld4<T>(in + vox * in_cs + qd * 4);
         raw[t] = v;
         if (xf) v = xform4(v, sc, sh, relu);
         // first maximum in (d,h,w) scan order wins, as ATen's max_pool3d does (strict >)
@@ -342,18 +348,19 @@ __global__ void maxpool2_bwd_kernel(const float* __restrict__ in, int in_cs, int
         if (v.w > best.w) { best.w = v.w; bi[3] = t; }
     }
     const size_t ovox = (((size_t)n * Do + dd) * Ho + ho) * Wo + wo;
-    const float4 g = *reinterpret_cast<const float4*>(gout + ovox * gout_cs + qd * 4);
+    const float4 g = ld4<T>(gout + ovox * gout_cs + qd * 4);
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
         const int d = dd * 2 + (t >> 2), h = ho * 2 + ((t >> 1) & 1), w = wo * 2 + (t & 1);
         const size_t vox = (((size_t)n * D + d) * H + h) * W + w;
-        float4* gp = reinterpret_cast<float4*>(gin + vox * gin_cs + qd * 4);
-        float4 r = accumulate ? *gp : make_float4(0.f, 0.f, 0.f, 0.f);
+        T* gp = gin + vox * gin_cs + qd * 4;
+        float4 r = accumulate ? ld4<T>(gp) : make_float4(0.f, 0.f, 0.f, 0.f);
         if (bi[0] == t) r.x += g.x;
         if (bi[1] == t) r.y += g.y;
         if (bi[2] == t) r.z += g.z;
         if (bi[3] == t) r.w += g.w;
-        *gp = r;
+        r = rnd4<T>(r);                      // the reduction sees what the BatchNorm-backward apply pass will read back
+        st4<T>(gp, r);
         if constexpr (RED) {
             const float4 y = raw[t];
             float gz;
@@ -384,7 +391,8 @@ __global__ void maxpool2_bwd_kernel(const float* __restrict__ in, int in_cs, int
 }
 
 // ------------------------------------------------------------------ channel sums
-__global__ void channel_sum_partial_kernel(const float* __restrict__ x, int cs, int cp, int64_t nvox,
+template <class T>
+__global__ void channel_sum_partial_kernel(const T* __restrict__ x, int cs, int cp, int64_t nvox,
                                            float* __restrict__ partials) {
     const int nq = cp >> 2;
     const int tpv = EW_BLOCK / nq;
@@ -393,7 +401,7 @@ __global__ void channel_sum_partial_kernel(const float* __restrict__ x, int cs, 
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     if (vl < tpv)
         for (int64_t v = (int64_t)blockIdx.x * tpv + vl; v < nvox; v += (int64_t)gridDim.x * tpv) {
-            const float4 t = *reinterpret_cast<const float4*>(x + v * cs + qd * 4);
+            const float4 t = ld4<T>(x + v * cs + qd * 4);
             a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
         }
     float* r = &red[threadIdx.x * 4];
@@ -470,29 +478,150 @@ __global__ void adam_amsgrad_kernel(AdamTable tb, const float* __restrict__ step
     }
 }
 
+struct ScaleTable {
+    float* p[ADAM_MAXT];
+    int64_t n[ADAM_MAXT];
+};
+
+__global__ void scale_tensors_kernel(ScaleTable tb, float s) {
+    const int t = blockIdx.y;
+    float* __restrict__ p = tb.p[t];
+    const int64_t n = tb.n[t];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] *= s;
+}
+
 }  // namespace
 
 // =================================================================== C ABI
-extern "C" int ctu_ncdhw_to_ndhwc(const float* src, float* dst, int N, int C, int D, int H, int W, int cp, int cs,
-                                  void* stream) {
+// The activation-touching entry points exist twice: the fp32 ones (float*) and ctu_lp_* (dtype code + void*, 16-bit
+// storage); both are thin wrappers over one template per operation.
+namespace {
+
+template <class T>
+int ncdhw_to_ndhwc_impl(const float* src, T* dst, int N, int C, int D, int H, int W, int cp, int cs, void* stream) {
     CTU_REQUIRE(src && dst && N > 0 && C > 0, "ncdhw_to_ndhwc: null/empty");
     CTU_REQUIRE(cp % 8 == 0 && cp >= C && cs >= cp && cs % 4 == 0, "ncdhw_to_ndhwc: cp=%d cs=%d C=%d", cp, cs, C);
     const int64_t V = (int64_t)D * H * W, tv = V * N;
     const int64_t total = tv * (cp >> 2);
-    ncdhw_to_ndhwc_kernel<<<(unsigned)ceil_div64(total, EW_BLOCK), EW_BLOCK, 0, (hipStream_t)stream>>>(src, dst, C, V,
-                                                                                                     tv, cp, cs);
+    ncdhw_to_ndhwc_kernel<T><<<(unsigned)ceil_div64(total, EW_BLOCK), EW_BLOCK, 0, (hipStream_t)stream>>>(src, dst, C, V, tv, cp, cs);
     CTU_CHECK_LAUNCH("ncdhw_to_ndhwc");
     return CTU_OK;
 }
 
-extern "C" int ctu_ndhwc_to_ncdhw(const float* src, float* dst, int N, int C, int D, int H, int W, int cs,
-                                  void* stream) {
+template <class T>
+int ndhwc_to_ncdhw_impl(const T* src, float* dst, int N, int C, int D, int H, int W, int cs, void* stream) {
     CTU_REQUIRE(src && dst && N > 0 && C > 0 && cs >= C, "ndhwc_to_ncdhw: bad argument");
     const int64_t V = (int64_t)D * H * W, tv = V * N;
-    ndhwc_to_ncdhw_kernel<<<(unsigned)ceil_div64(tv * C, EW_BLOCK), EW_BLOCK, 0, (hipStream_t)stream>>>(src, dst, C, V,
-                                                                                                      tv, cs);
+    ndhwc_to_ncdhw_kernel<T><<<(unsigned)ceil_div64(tv * C, EW_BLOCK), EW_BLOCK, 0, (hipStream_t)stream>>>(src, dst, C, V, tv, cs);
     CTU_CHECK_LAUNCH("ndhwc_to_ncdhw");
     return CTU_OK;
+}
+
+template <class T>
+int bn_relu_bwd_reduce_impl(const T* y, int y_cs, const T* ga, int g_cs, int cp, const float* scale, const float* shift,
+                            const float* mean, const float* invstd, int64_t nvox, float* partials, void* stream) {
+    CTU_REQUIRE(y && ga && scale && shift && mean && invstd && partials, "bn_relu_bwd_reduce: null pointer");
+    CTU_REQUIRE(cp % 8 == 0 && cp > 0 && cp <= 256 && y_cs % 4 == 0 && g_cs % 4 == 0, "bn_relu_bwd_reduce: cp=%d", cp);
+    bn_relu_bwd_reduce_kernel<T><<<ctu_bn_bwd_num_blocks(nvox), EW_BLOCK, 0, (hipStream_t)stream>>>(
+        y, y_cs, ga, g_cs, cp, scale, shift, mean, invstd, nvox, partials);
+    CTU_CHECK_LAUNCH("bn_relu_bwd_reduce");
+    return CTU_OK;
+}
+
+template <class T>
+int bn_relu_bwd_apply_impl(const T* y, int y_cs, T* ga, int g_cs, int cp, const float* scale, const float* shift,
+                           const float* mean, const float* invstd, const float* coef, int64_t nvox, void* stream) {
+    CTU_REQUIRE(y && ga && scale && shift && mean && invstd && coef, "bn_relu_bwd_apply: null pointer");
+    CTU_REQUIRE(cp % 8 == 0 && cp > 0, "bn_relu_bwd_apply: cp=%d", cp);
+    const int64_t total = nvox * (cp >> 2);
+    bn_relu_bwd_apply_kernel<T><<<(unsigned)ceil_div64(total, EW_BLOCK), EW_BLOCK, 0, (hipStream_t)stream>>>(
+        y, y_cs, ga, g_cs, cp, scale, shift, mean, invstd, coef, nvox);
+    CTU_CHECK_LAUNCH("bn_relu_bwd_apply");
+    return CTU_OK;
+}
+
+template <class T>
+int maxpool2_fwd_impl(const T* in, int in_cs, int cp, const float* in_scale, const float* in_shift, int in_relu, T* out,
+                      int out_cs, int N, int D, int H, int W, void* stream) {
+    CTU_REQUIRE(in && out, "maxpool2_fwd: null pointer");
+    CTU_REQUIRE(cp % 8 == 0 && cp > 0 && D % 2 == 0 && H % 2 == 0 && W % 2 == 0, "maxpool2_fwd: D,H,W must be even");
+    const int64_t total = (int64_t)N * (D / 2) * (H / 2) * (W / 2) * (cp >> 2);
+    maxpool2_fwd_kernel<T><<<(unsigned)ceil_div64(total, EW_BLOCK), EW_BLOCK, 0, (hipStream_t)stream>>>(
+        in, in_cs, cp, in_scale, in_shift, in_relu, out, out_cs, N, D, H, W);
+    CTU_CHECK_LAUNCH("maxpool2_fwd");
+    return CTU_OK;
+}
+
+template <class T>
+int maxpool2_bwd_impl(const T* in, int in_cs, int cp, const float* in_scale, const float* in_shift, int in_relu, const T* gout,
+                      int gout_cs, T* gin, int gin_cs, int accumulate, int N, int D, int H, int W, void* stream) {
+    CTU_REQUIRE(in && gout && gin, "maxpool2_bwd: null pointer");
+    CTU_REQUIRE(cp % 8 == 0 && cp > 0 && D % 2 == 0 && H % 2 == 0 && W % 2 == 0, "maxpool2_bwd: D,H,W must be even");
+    const int64_t total = (int64_t)N * (D / 2) * (H / 2) * (W / 2) * (cp >> 2);
+    maxpool2_bwd_kernel<false, T><<<(unsigned)ceil_div64(total, EW_BLOCK), EW_BLOCK, 0, (hipStream_t)stream>>>(
+        in, in_cs, cp, in_scale, in_shift, in_relu, gout, gout_cs, gin, gin_cs, accumulate, N, D, H, W, nullptr, nullptr, nullptr);
+    CTU_CHECK_LAUNCH("maxpool2_bwd");
+    return CTU_OK;
+}
+
+template <class T>
+int maxpool2_bwd_bn_impl(const T* in, int in_cs, int cp, const float* in_scale, const float* in_shift, const float* mean,
+                         const float* invstd, const T* gout, int gout_cs, T* gin, int gin_cs, int accumulate, int N, int D,
+                         int H, int W, float* partials, void* stream) {
+    CTU_REQUIRE(in && gout && gin && in_scale && in_shift && mean && invstd && partials, "maxpool2_bwd_bn: null pointer");
+    CTU_REQUIRE(cp % 8 == 0 && cp > 0 && cp <= EW_BLOCK && EW_BLOCK % (cp >> 2) == 0 && D % 2 == 0 && H % 2 == 0 && W % 2 == 0,
+                "maxpool2_bwd_bn: cp=%d must be a multiple of 8 whose quads divide the block; D,H,W even", cp);
+    const int nb = ctu_maxpool2_bwd_bn_num_blocks(N, D, H, W, cp);
+    maxpool2_bwd_kernel<true, T><<<nb, EW_BLOCK, 0, (hipStream_t)stream>>>(
+        in, in_cs, cp, in_scale, in_shift, 1, gout, gout_cs, gin, gin_cs, accumulate, N, D, H, W, mean, invstd, partials);
+    CTU_CHECK_LAUNCH("maxpool2_bwd_bn");
+    return CTU_OK;
+}
+
+template <class T>
+int skip_add_impl(const T* a, int a_cs, const float* a_scale, const float* a_shift, int a_relu, const T* b, int b_cs,
+                  const float* b_scale, const float* b_shift, int b_relu, T* out, int out_cs, int cp, int64_t nvox, void* stream) {
+    CTU_REQUIRE(a && out, "skip_add: null pointer");
+    CTU_REQUIRE(cp % 4 == 0 && cp > 0 && a_cs % 4 == 0 && out_cs % 4 == 0 && (!b || b_cs % 4 == 0), "skip_add: channel counts / strides must be multiples of 4");
+    CTU_REQUIRE((a_scale == nullptr) == (a_shift == nullptr) && (b_scale == nullptr) == (b_shift == nullptr), "skip_add: scale/shift come in pairs");
+    if (nvox <= 0) return CTU_OK;
+    const int64_t total = nvox * (cp >> 2);
+    skip_add_kernel<T><<<(unsigned)ceil_div64(total, EW_BLOCK), EW_BLOCK, 0, (hipStream_t)stream>>>(
+        a, a_cs, a_scale, a_shift, a_relu, b, b_cs, b_scale, b_shift, b_relu, out, out_cs, cp, nvox);
+    CTU_CHECK_LAUNCH("skip_add");
+    return CTU_OK;
+}
+
+template <class T>
+int channel_sum_impl(const T* x, int cs, int cp, int64_t nvox, float* partials, float* out, int C, void* stream) {
+    CTU_REQUIRE(x && partials && out, "channel_sum: null pointer");
+    CTU_REQUIRE(cp % 8 == 0 && cp > 0 && cp <= 256 && C <= cp && cs % 4 == 0, "channel_sum: cp=%d", cp);
+    const int nb = ctu_channel_sum_num_blocks(nvox);
+    channel_sum_partial_kernel<T><<<nb, EW_BLOCK, 0, (hipStream_t)stream>>>(x, cs, cp, nvox, partials);
+    CTU_CHECK_LAUNCH("channel_sum_partial");
+    channel_sum_final_kernel<<<C, EW_BLOCK, 0, (hipStream_t)stream>>>(partials, nb, cp, out, C);
+    CTU_CHECK_LAUNCH("channel_sum_final");
+    return CTU_OK;
+}
+
+}  // namespace
+
+extern "C" int ctu_ncdhw_to_ndhwc(const float* src, float* dst, int N, int C, int D, int H, int W, int cp, int cs,
+                                  void* stream) {
+    return ncdhw_to_ndhwc_impl<float>(src, dst, N, C, D, H, W, cp, cs, stream);
+}
+extern "C" int ctu_lp_ncdhw_to_ndhwc(int dtype, const float* src, void* dst, int N, int C, int D, int H, int W, int cp, int cs,
+                                     void* stream) {
+    CTU_DISPATCH_LP(dtype, return ncdhw_to_ndhwc_impl<T>(src, (T*)dst, N, C, D, H, W, cp, cs, stream));
+}
+
+extern "C" int ctu_ndhwc_to_ncdhw(const float* src, float* dst, int N, int C, int D, int H, int W, int cs,
+                                  void* stream) {
+    return ndhwc_to_ncdhw_impl<float>(src, dst, N, C, D, H, W, cs, stream);
+}
+extern "C" int ctu_lp_ndhwc_to_ncdhw(int dtype, const void* src, float* dst, int N, int C, int D, int H, int W, int cs,
+                                     void* stream) {
+    CTU_DISPATCH_LP(dtype, return ndhwc_to_ncdhw_impl<T>((const T*)src, dst, N, C, D, H, W, cs, stream));
 }
 
 extern "C" int ctu_bn_finalize(const float* stats, int nblocks, int C, int cp, double count, const float* gamma,
@@ -529,12 +658,13 @@ extern "C" int ctu_bn_bwd_num_blocks(int64_t nvox) {
 extern "C" int ctu_bn_relu_bwd_reduce(const float* y, int y_cs, const float* ga, int g_cs, int cp, const float* scale,
                                       const float* shift, const float* mean, const float* invstd, int64_t nvox,
                                       float* partials, void* stream) {
-    CTU_REQUIRE(y && ga && scale && shift && mean && invstd && partials, "bn_relu_bwd_reduce: null pointer");
-    CTU_REQUIRE(cp % 8 == 0 && cp > 0 && cp <= 256 && y_cs % 4 == 0 && g_cs % 4 == 0, "bn_relu_bwd_reduce: cp=%d", cp);
-    bn_relu_bwd_reduce_kernel<<<ctu_bn_bwd_num_blocks(nvox), EW_BLOCK, 0, (hipStream_t)stream>>>(
-        y, y_cs, ga, g_cs, cp, scale, shift, mean, invstd, nvox, partials);
-    CTU_CHECK_LAUNCH("bn_relu_bwd_reduce");
-    return CTU_OK;
+    return bn_relu_bwd_reduce_impl<float>(y, y_cs, ga, g_cs, cp, scale, shift, mean, invstd, nvox, partials, stream);
+}
+extern "C" int ctu_lp_bn_relu_bwd_reduce(int dtype, const void* y, int y_cs, const void* ga, int g_cs, int cp, const float* scale,
+                                         const float* shift, const float* mean, const float* invstd, int64_t nvox,
+                                         float* partials, void* stream) {
+    CTU_DISPATCH_LP(dtype, return bn_relu_bwd_reduce_impl<T>((const T*)y, y_cs, (const T*)ga, g_cs, cp, scale, shift, mean, invstd,
+                                                             nvox, partials, stream));
 }
 
 extern "C" int ctu_bn_bwd_finalize(const float* partials, int nb, int C, int cp, double count, const float* gamma,
@@ -554,36 +684,36 @@ extern "C" int ctu_bn_bwd_finalize(const float* partials, int nb, int C, int cp,
 extern "C" int ctu_bn_relu_bwd_apply(const float* y, int y_cs, float* ga, int g_cs, int cp, const float* scale,
                                      const float* shift, const float* mean, const float* invstd, const float* coef,
                                      int64_t nvox, void* stream) {
-    CTU_REQUIRE(y && ga && scale && shift && mean && invstd && coef, "bn_relu_bwd_apply: null pointer");
-    CTU_REQUIRE(cp % 8 == 0 && cp > 0, "bn_relu_bwd_apply: cp=%d", cp);
-    const int64_t total = nvox * (cp >> 2);
-    bn_relu_bwd_apply_kernel<<<(unsigned)ceil_div64(total, EW_BLOCK), EW_BLOCK, 0, (hipStream_t)stream>>>(
-        y, y_cs, ga, g_cs, cp, scale, shift, mean, invstd, coef, nvox);
-    CTU_CHECK_LAUNCH("bn_relu_bwd_apply");
-    return CTU_OK;
+    return bn_relu_bwd_apply_impl<float>(y, y_cs, ga, g_cs, cp, scale, shift, mean, invstd, coef, nvox, stream);
+}
+extern "C" int ctu_lp_bn_relu_bwd_apply(int dtype, const void* y, int y_cs, void* ga, int g_cs, int cp, const float* scale,
+                                        const float* shift, const float* mean, const float* invstd, const float* coef,
+                                        int64_t nvox, void* stream) {
+    CTU_DISPATCH_LP(dtype, return bn_relu_bwd_apply_impl<T>((const T*)y, y_cs, (T*)ga, g_cs, cp, scale, shift, mean, invstd, coef,
+                                                            nvox, stream));
 }
 
 extern "C" int ctu_maxpool2_fwd(const float* in, int in_cs, int cp, const float* in_scale, const float* in_shift,
                                 int in_relu, float* out, int out_cs, int N, int D, int H, int W, void* stream) {
-    CTU_REQUIRE(in && out, "maxpool2_fwd: null pointer");
-    CTU_REQUIRE(cp % 8 == 0 && cp > 0 && D % 2 == 0 && H % 2 == 0 && W % 2 == 0, "maxpool2_fwd: D,H,W must be even");
-    const int64_t total = (int64_t)N * (D / 2) * (H / 2) * (W / 2) * (cp >> 2);
-    maxpool2_fwd_kernel<<<(unsigned)ceil_div64(total, EW_BLOCK), EW_BLOCK, 0, (hipStream_t)stream>>>(
-        in, in_cs, cp, in_scale, in_shift, in_relu, out, out_cs, N, D, H, W);
-    CTU_CHECK_LAUNCH("maxpool2_fwd");
-    return CTU_OK;
+    return maxpool2_fwd_impl<float>(in, in_cs, cp, in_scale, in_shift, in_relu, out, out_cs, N, D, H, W, stream);
+}
+extern "C" int ctu_lp_maxpool2_fwd(int dtype, const void* in, int in_cs, int cp, const float* in_scale, const float* in_shift,
+                                   int in_relu, void* out, int out_cs, int N, int D, int H, int W, void* stream) {
+    CTU_DISPATCH_LP(dtype, return maxpool2_fwd_impl<T>((const T*)in, in_cs, cp, in_scale, in_shift, in_relu, (T*)out, out_cs, N, D,
+                                                       H, W, stream));
 }
 
 extern "C" int ctu_maxpool2_bwd(const float* in, int in_cs, int cp, const float* in_scale, const float* in_shift,
                                 int in_relu, const float* gout, int gout_cs, float* gin, int gin_cs, int accumulate,
                                 int N, int D, int H, int W, void* stream) {
-    CTU_REQUIRE(in && gout && gin, "maxpool2_bwd: null pointer");
-    CTU_REQUIRE(cp % 8 == 0 && cp > 0 && D % 2 == 0 && H % 2 == 0 && W % 2 == 0, "maxpool2_bwd: D,H,W must be even");
-    const int64_t total = (int64_t)N * (D / 2) * (H / 2) * (W / 2) * (cp >> 2);
-    maxpool2_bwd_kernel<false><<<(unsigned)ceil_div64(total, EW_BLOCK), EW_BLOCK, 0, (hipStream_t)stream>>>(
-        in, in_cs, cp, in_scale, in_shift, in_relu, gout, gout_cs, gin, gin_cs, accumulate, N, D, H, W, nullptr, nullptr, nullptr);
-    CTU_CHECK_LAUNCH("maxpool2_bwd");
-    return CTU_OK;
+    return maxpool2_bwd_impl<float>(in, in_cs, cp, in_scale, in_shift, in_relu, gout, gout_cs, gin, gin_cs, accumulate, N, D, H, W,
+                                    stream);
+}
+extern "C" int ctu_lp_maxpool2_bwd(int dtype, const void* in, int in_cs, int cp, const float* in_scale, const float* in_shift,
+                                   int in_relu, const void* gout, int gout_cs, void* gin, int gin_cs, int accumulate,
+                                   int N, int D, int H, int W, void* stream) {
+    CTU_DISPATCH_LP(dtype, return maxpool2_bwd_impl<T>((const T*)in, in_cs, cp, in_scale, in_shift, in_relu, (const T*)gout, gout_cs,
+                                                       (T*)gin, gin_cs, accumulate, N, D, H, W, stream));
 }
 
 extern "C" int ctu_maxpool2_bwd_bn_num_blocks(int N, int D, int H, int W, int cp) {
@@ -595,28 +725,26 @@ extern "C" int ctu_maxpool2_bwd_bn_num_blocks(int N, int D, int H, int W, int cp
 extern "C" int ctu_maxpool2_bwd_bn(const float* in, int in_cs, int cp, const float* in_scale, const float* in_shift,
                                    const float* mean, const float* invstd, const float* gout, int gout_cs, float* gin,
                                    int gin_cs, int accumulate, int N, int D, int H, int W, float* partials, void* stream) {
-    CTU_REQUIRE(in && gout && gin && in_scale && in_shift && mean && invstd && partials, "maxpool2_bwd_bn: null pointer");
-    CTU_REQUIRE(cp % 8 == 0 && cp > 0 && cp <= EW_BLOCK && EW_BLOCK % (cp >> 2) == 0 && D % 2 == 0 && H % 2 == 0 && W % 2 == 0,
-                "maxpool2_bwd_bn: cp=%d must be a multiple of 8 whose quads divide the block; D,H,W even", cp);
-    const int nb = ctu_maxpool2_bwd_bn_num_blocks(N, D, H, W, cp);
-    maxpool2_bwd_kernel<true><<<nb, EW_BLOCK, 0, (hipStream_t)stream>>>(
-        in, in_cs, cp, in_scale, in_shift, 1, gout, gout_cs, gin, gin_cs, accumulate, N, D, H, W, mean, invstd, partials);
-    CTU_CHECK_LAUNCH("maxpool2_bwd_bn");
-    return CTU_OK;
+    return maxpool2_bwd_bn_impl<float>(in, in_cs, cp, in_scale, in_shift, mean, invstd, gout, gout_cs, gin, gin_cs, accumulate, N, D,
+                                       H, W, partials, stream);
+}
+extern "C" int ctu_lp_maxpool2_bwd_bn(int dtype, const void* in, int in_cs, int cp, const float* in_scale, const float* in_shift,
+                                      const float* mean, const float* invstd, const void* gout, int gout_cs, void* gin,
+                                      int gin_cs, int accumulate, int N, int D, int H, int W, float* partials, void* stream) {
+    CTU_DISPATCH_LP(dtype, return maxpool2_bwd_bn_impl<T>((const T*)in, in_cs, cp, in_scale, in_shift, mean, invstd, (const T*)gout,
+                                                          gout_cs, (T*)gin, gin_cs, accumulate, N, D, H, W, partials, stream));
 }
 
 extern "C" int ctu_skip_add(const float* a, int a_cs, const float* a_scale, const float* a_shift, int a_relu,
                             const float* b, int b_cs, const float* b_scale, const float* b_shift, int b_relu,
                             float* out, int out_cs, int cp, int64_t nvox, void* stream) {
-    CTU_REQUIRE(a && out, "skip_add: null pointer");
-    CTU_REQUIRE(cp % 4 == 0 && cp > 0 && a_cs % 4 == 0 && out_cs % 4 == 0 && (!b || b_cs % 4 == 0), "skip_add: channel counts / strides must be multiples of 4");
-    CTU_REQUIRE((a_scale == nullptr) == (a_shift == nullptr) && (b_scale == nullptr) == (b_shift == nullptr), "skip_add: scale/shift come in pairs");
-    if (nvox <= 0) return CTU_OK;
-    const int64_t total = nvox * (cp >> 2);
-    skip_add_kernel<<<(unsigned)ceil_div64(total, EW_BLOCK), EW_BLOCK, 0, (hipStream_t)stream>>>(
-        a, a_cs, a_scale, a_shift, a_relu, b, b_cs, b_scale, b_shift, b_relu, out, out_cs, cp, nvox);
-    CTU_CHECK_LAUNCH("skip_add");
-    return CTU_OK;
+    return skip_add_impl<float>(a, a_cs, a_scale, a_shift, a_relu, b, b_cs, b_scale, b_shift, b_relu, out, out_cs, cp, nvox, stream);
+}
+extern "C" int ctu_lp_skip_add(int dtype, const void* a, int a_cs, const float* a_scale, const float* a_shift, int a_relu,
+                               const void* b, int b_cs, const float* b_scale, const float* b_shift, int b_relu,
+                               void* out, int out_cs, int cp, int64_t nvox, void* stream) {
+    CTU_DISPATCH_LP(dtype, return skip_add_impl<T>((const T*)a, a_cs, a_scale, a_shift, a_relu, (const T*)b, b_cs, b_scale, b_shift,
+                                                   b_relu, (T*)out, out_cs, cp, nvox, stream));
 }
 
 extern "C" int ctu_channel_sum_num_blocks(int64_t nvox) {
@@ -628,14 +756,11 @@ extern "C" int ctu_channel_sum_num_blocks(int64_t nvox) {
 
 extern "C" int ctu_channel_sum(const float* x, int cs, int cp, int64_t nvox, float* partials, float* out, int C,
                                void* stream) {
-    CTU_REQUIRE(x && partials && out, "channel_sum: null pointer");
-    CTU_REQUIRE(cp % 8 == 0 && cp > 0 && cp <= 256 && C <= cp && cs % 4 == 0, "channel_sum: cp=%d", cp);
-    const int nb = ctu_channel_sum_num_blocks(nvox);
-    channel_sum_partial_kernel<<<nb, EW_BLOCK, 0, (hipStream_t)stream>>>(x, cs, cp, nvox, partials);
-    CTU_CHECK_LAUNCH("channel_sum_partial");
-    channel_sum_final_kernel<<<C, EW_BLOCK, 0, (hipStream_t)stream>>>(partials, nb, cp, out, C);
-    CTU_CHECK_LAUNCH("channel_sum_final");
-    return CTU_OK;
+    return channel_sum_impl<float>(x, cs, cp, nvox, partials, out, C, stream);
+}
+extern "C" int ctu_lp_channel_sum(int dtype, const void* x, int cs, int cp, int64_t nvox, float* partials, float* out, int C,
+                                  void* stream) {
+    CTU_DISPATCH_LP(dtype, return channel_sum_impl<T>((const T*)x, cs, cp, nvox, partials, out, C, stream));
 }
 
 extern "C" int ctu_adam_amsgrad(void* const* ptrs, const int64_t* sizes, int n, float* step, double lr, double beta1,
@@ -662,6 +787,27 @@ extern "C" int ctu_adam_amsgrad(void* const* ptrs, const int64_t* sizes, int n, 
                                                               (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps,
                                                               (float)weight_decay, decoupled);
         CTU_CHECK_LAUNCH("adam_amsgrad");
+    }
+    return CTU_OK;
+}
+
+extern "C" int ctu_scale_tensors(void* const* ptrs, const int64_t* sizes, int n, float sc, void* stream) {
+    CTU_REQUIRE(ptrs && sizes && n > 0, "scale_tensors: bad argument");
+    for (int t0 = 0; t0 < n; t0 += ADAM_MAXT) {
+        const int nt = (n - t0) < ADAM_MAXT ? (n - t0) : ADAM_MAXT;
+        ScaleTable tb;
+        int64_t mx = 1;
+        for (int t = 0; t < nt; ++t) {
+            CTU_REQUIRE(ptrs[t0 + t], "scale_tensors: null tensor pointer at %d", t0 + t);
+            tb.p[t] = (float*)ptrs[t0 + t];
+            tb.n[t] = sizes[t0 + t];
+            if (tb.n[t] > mx) mx = tb.n[t];
+        }
+        int gx = (int)ceil_div64(mx, EW_BLOCK * 4);
+        if (gx > 128) gx = 128;
+        if (gx < 1) gx = 1;
+        scale_tensors_kernel<<<dim3(gx, nt), EW_BLOCK, 0, (hipStream_t)stream>>>(tb, sc);
+        CTU_CHECK_LAUNCH("scale_tensors");
     }
     return CTU_OK;
 }

@@ -14,7 +14,7 @@ constexpr int HB = 256;
 constexpr int MAXCO = 4;
 
 struct HeadP {
-    const float* in;
+    const void* in;          // channels-last activations, element type T of the kernel template
     const float* in_scale;
     const float* in_shift;
     const float* w;
@@ -25,14 +25,14 @@ struct HeadP {
 };
 
 // activated input channels of one voxel -> logits -> y (post softmax/sigmoid)
-template <int CP>
+template <int CP, class T>
 __device__ __forceinline__ void head_point(const HeadP& p, const float* sWp, const float* sB, int64_t gv,
                                            float (&a)[CP], float (&lg)[MAXCO], float (&u)[MAXCO],
                                            float (&y)[MAXCO]) {
-    const float* src = p.in + (size_t)gv * p.in_cs;
+    const T* src = reinterpret_cast<const T*>(p.in) + (size_t)gv * p.in_cs;
 #pragma unroll
     for (int qd = 0; qd < CP / 4; ++qd) {
-        float4 v = *reinterpret_cast<const float4*>(src + qd * 4);
+        float4 v = ld4<T>(src + qd * 4);
         if (p.in_scale) {
             const float4 sc = *reinterpret_cast<const float4*>(p.in_scale + qd * 4);
             const float4 sh = *reinterpret_cast<const float4*>(p.in_shift + qd * 4);
@@ -86,7 +86,7 @@ __device__ __forceinline__ void softmax2(float a, float b, float& sa, float& sb)
     sa = ea / (ea + eb); sb = eb / (ea + eb);
 }
 
-template <int CP>
+template <int CP, class T>
 __global__ __launch_bounds__(HB) void head_fwd_kernel(HeadP p, float* __restrict__ out0, float* __restrict__ out1) {
     __shared__ float sWp[MAXCO * CP];
     __shared__ float sB[MAXCO];
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(HB) void head_fwd_kernel(HeadP p, float* __restrict
     const int64_t total = (int64_t)p.N * p.V;
     for (int64_t gv = (int64_t)blockIdx.x * HB + threadIdx.x; gv < total; gv += (int64_t)gridDim.x * HB) {
         float a[CP], lg[MAXCO], u[MAXCO], y[MAXCO];
-        head_point<CP>(p, sWp, sB, gv, a, lg, u, y);
+        head_point<CP, T>(p, sWp, sB, gv, a, lg, u, y);
         const int64_t n = gv / p.V, v = gv % p.V;
         if (p.head_mode == 0) {
 #pragma unroll
@@ -116,12 +116,12 @@ __global__ __launch_bounds__(HB) void head_fwd_kernel(HeadP p, float* __restrict
 // Backward with CP/4 lanes per voxel: every lane owns one channel quad (16-byte coalesced loads/stores, ~50 VGPRs so
 // the streaming loop is hidden by occupancy instead of being latency-bound at one voxel per 64-accumulator thread).
 // Logits are quad partial sums reduced across the voxel's lanes; block partials keep the layout above.
-template <int CP>
+template <int CP, class T>
 // bn_partials != NULL: the first bn_cp input channels are relu(BN(raw conv output)) of ONE layer whose activated-output
 // gradient is complete with this kernel's gin (the decoder's last conv feeding the head): the kernel also emits that
 // BatchNorm's backward reduction rows {sum gz, sum gz * xhat} per block (layout of bn_relu_bwd_reduce).
 __global__ __launch_bounds__(HB) void head_bwd_q_kernel(HeadP p, const float* __restrict__ g0,
-                                                        const float* __restrict__ g1, float* __restrict__ gin,
+                                                        const float* __restrict__ g1, T* __restrict__ gin,
                                                         int gin_cs, float* __restrict__ partials,
                                                         const float* __restrict__ bn_mean, const float* __restrict__ bn_invstd,
                                                         int bn_cp, float* __restrict__ bn_partials) {
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(HB) void head_bwd_q_kernel(HeadP p, const float* __
     const int64_t total = (int64_t)p.N * p.V;
     constexpr int VPB = HB / Q;                       // voxels per block and iteration
     for (int64_t gv = (int64_t)blockIdx.x * VPB + threadIdx.x / Q; gv < total; gv += (int64_t)gridDim.x * VPB) {
-        const float4 raw = *reinterpret_cast<const float4*>(p.in + (size_t)gv * p.in_cs + qd * 4);
+        const float4 raw = ld4<T>(reinterpret_cast<const T*>(p.in) + (size_t)gv * p.in_cs + qd * 4);
         const float4 a = xform4(raw, sc, sh, xrelu);
         float lg[MAXCO], u[MAXCO], y[MAXCO], gy[MAXCO];
 #pragma unroll
@@ -222,7 +222,8 @@ __global__ __launch_bounds__(HB) void head_bwd_q_kernel(HeadP p, const float* __
 #pragma unroll
             for (int j = 0; j < 4; ++j) dw[co][j] = fmaf(gl[co], av[j], dw[co][j]);
         }
-        *reinterpret_cast<float4*>(gin + (size_t)gv * gin_cs + qd * 4) = o;
+        o = rnd4<T>(o);                      // the reduction sees what the BatchNorm-backward apply pass will read back
+        st4<T>(gin + (size_t)gv * gin_cs + qd * 4, o);
         if (bnq) {
             float gz;
             gz = (fmaf(raw.x, sc.x, sh.x) > 0.f) ? o.x : 0.f; r1.x += gz; r2.x += gz * (raw.x - mu.x) * is.x;
@@ -414,7 +415,7 @@ __global__ __launch_bounds__(HB) void loss_bwd_kernel(const float* __restrict__ 
 }  // namespace
 
 // =================================================================== C ABI
-static int fill_head(HeadP& p, const float* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
+static int fill_head(HeadP& p, const void* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
                      int in_relu, const float* w, const float* bias, const int32_t* imap, int Ci, int Co, int act,
                      int head_mode, int N, int64_t V, const char* name) {
     CTU_REQUIRE(in && w, "%s: null pointer", name);
@@ -429,9 +430,12 @@ static int fill_head(HeadP& p, const float* in, int in_cs, int cin_p, const floa
     return CTU_OK;
 }
 
-extern "C" int ctu_head_fwd(const float* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
-                            int in_relu, const float* w, const float* bias, const int32_t* imap, int Ci, int Co, int act,
-                            int head_mode, float* out0, float* out1, int N, int64_t nvox_per_item, void* stream) {
+namespace {
+
+template <class T>
+int head_fwd_impl(const T* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift, int in_relu, const float* w,
+                  const float* bias, const int32_t* imap, int Ci, int Co, int act, int head_mode, float* out0, float* out1, int N,
+                  int64_t nvox_per_item, void* stream) {
     HeadP p;
     int rc = fill_head(p, in, in_cs, cin_p, in_scale, in_shift, in_relu, w, bias, imap, Ci, Co, act, head_mode, N,
                        nvox_per_item, "head_fwd");
@@ -439,11 +443,56 @@ extern "C" int ctu_head_fwd(const float* in, int in_cs, int cin_p, const float* 
     CTU_REQUIRE(out0 && (head_mode == 0 || out1), "head_fwd: null output");
     const int nb = head_blocks((int64_t)N * nvox_per_item);
     hipStream_t st = (hipStream_t)stream;
-    if (cin_p == 8) head_fwd_kernel<8><<<nb, HB, 0, st>>>(p, out0, out1);
-    else if (cin_p == 16) head_fwd_kernel<16><<<nb, HB, 0, st>>>(p, out0, out1);
-    else head_fwd_kernel<32><<<nb, HB, 0, st>>>(p, out0, out1);
+    if (cin_p == 8) head_fwd_kernel<8, T><<<nb, HB, 0, st>>>(p, out0, out1);
+    else if (cin_p == 16) head_fwd_kernel<16, T><<<nb, HB, 0, st>>>(p, out0, out1);
+    else head_fwd_kernel<32, T><<<nb, HB, 0, st>>>(p, out0, out1);
     CTU_CHECK_LAUNCH("head_fwd");
     return CTU_OK;
+}
+
+template <class T>
+int head_bwd_impl(const T* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift, int in_relu, const float* w,
+                  const float* bias, const int32_t* imap, int Ci, int Co, int act, int head_mode, const float* g0, const float* g1,
+                  T* gin, int gin_cs, float* dw, float* db, float* ws, int N, int64_t nvox_per_item, const float* bn_mean,
+                  const float* bn_invstd, int bn_cp, float* bn_partials, void* stream) {
+    HeadP p;
+    int rc = fill_head(p, in, in_cs, cin_p, in_scale, in_shift, in_relu, w, bias, imap, Ci, Co, act, head_mode, N,
+                       nvox_per_item, "head_bwd");
+    if (rc != CTU_OK) return rc;
+    CTU_REQUIRE(g0 && (head_mode == 0 || g1) && gin && dw && db && ws, "head_bwd: null pointer");
+    CTU_REQUIRE(gin_cs >= cin_p && gin_cs % 4 == 0, "head_bwd: bad gin stride");
+    CTU_REQUIRE(!bn_partials || (bn_mean && bn_invstd && in_scale && in_relu && bn_cp > 0 && bn_cp % 4 == 0 && bn_cp <= cin_p),
+                "head_bwd: the BatchNorm reduction needs mean/invstd, a BN+ReLU input transform and bn_cp <= cin_p (bn_cp=%d)", bn_cp);
+    const int nb = head_blocks((int64_t)N * nvox_per_item);
+    hipStream_t st = (hipStream_t)stream;
+    const int nfin = Co * Ci + Co;
+    if (cin_p == 8) {
+        head_bwd_q_kernel<8, T><<<nb, HB, 0, st>>>(p, g0, g1, gin, gin_cs, ws, bn_mean, bn_invstd, bn_cp, bn_partials);
+        head_bwd_final_kernel<8><<<nfin, HB, 0, st>>>(ws, nb, Ci, Co, imap, dw, db);
+    } else if (cin_p == 16) {
+        head_bwd_q_kernel<16, T><<<nb, HB, 0, st>>>(p, g0, g1, gin, gin_cs, ws, bn_mean, bn_invstd, bn_cp, bn_partials);
+        head_bwd_final_kernel<16><<<nfin, HB, 0, st>>>(ws, nb, Ci, Co, imap, dw, db);
+    } else {
+        head_bwd_q_kernel<32, T><<<nb, HB, 0, st>>>(p, g0, g1, gin, gin_cs, ws, bn_mean, bn_invstd, bn_cp, bn_partials);
+        head_bwd_final_kernel<32><<<nfin, HB, 0, st>>>(ws, nb, Ci, Co, imap, dw, db);
+    }
+    CTU_CHECK_LAUNCH("head_bwd");
+    return CTU_OK;
+}
+
+}  // namespace
+
+extern "C" int ctu_head_fwd(const float* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
+                            int in_relu, const float* w, const float* bias, const int32_t* imap, int Ci, int Co, int act,
+                            int head_mode, float* out0, float* out1, int N, int64_t nvox_per_item, void* stream) {
+    return head_fwd_impl<float>(in, in_cs, cin_p, in_scale, in_shift, in_relu, w, bias, imap, Ci, Co, act, head_mode, out0, out1, N,
+                                nvox_per_item, stream);
+}
+extern "C" int ctu_lp_head_fwd(int dtype, const void* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
+                               int in_relu, const float* w, const float* bias, const int32_t* imap, int Ci, int Co, int act,
+                               int head_mode, float* out0, float* out1, int N, int64_t nvox_per_item, void* stream) {
+    CTU_DISPATCH_LP(dtype, return head_fwd_impl<T>((const T*)in, in_cs, cin_p, in_scale, in_shift, in_relu, w, bias, imap, Ci, Co, act,
+                                                   head_mode, out0, out1, N, nvox_per_item, stream));
 }
 
 extern "C" size_t ctu_head_bwd_ws_floats(int N, int64_t nvox_per_item, int cin_p, int Co) {
@@ -457,8 +506,8 @@ extern "C" int ctu_head_bwd(const float* in, int in_cs, int cin_p, const float* 
                             int in_relu, const float* w, const float* bias, const int32_t* imap, int Ci, int Co, int act,
                             int head_mode, const float* g0, const float* g1, float* gin, int gin_cs, float* dw,
                             float* db, float* ws, int N, int64_t nvox_per_item, void* stream) {
-    return ctu_head_bwd_bn(in, in_cs, cin_p, in_scale, in_shift, in_relu, w, bias, imap, Ci, Co, act, head_mode, g0, g1, gin,
-                           gin_cs, dw, db, ws, N, nvox_per_item, nullptr, nullptr, 0, nullptr, stream);
+    return head_bwd_impl<float>(in, in_cs, cin_p, in_scale, in_shift, in_relu, w, bias, imap, Ci, Co, act, head_mode, g0, g1, gin,
+                                gin_cs, dw, db, ws, N, nvox_per_item, nullptr, nullptr, 0, nullptr, stream);
 }
 
 extern "C" int ctu_head_bwd_bn(const float* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
@@ -466,29 +515,18 @@ extern "C" int ctu_head_bwd_bn(const float* in, int in_cs, int cin_p, const floa
                                int head_mode, const float* g0, const float* g1, float* gin, int gin_cs, float* dw,
                                float* db, float* ws, int N, int64_t nvox_per_item, const float* bn_mean,
                                const float* bn_invstd, int bn_cp, float* bn_partials, void* stream) {
-    HeadP p;
-    int rc = fill_head(p, in, in_cs, cin_p, in_scale, in_shift, in_relu, w, bias, imap, Ci, Co, act, head_mode, N,
-                       nvox_per_item, "head_bwd");
-    if (rc != CTU_OK) return rc;
-    CTU_REQUIRE(g0 && (head_mode == 0 || g1) && gin && dw && db && ws, "head_bwd: null pointer");
-    CTU_REQUIRE(gin_cs >= cin_p && gin_cs % 4 == 0, "head_bwd: bad gin stride");
-    CTU_REQUIRE(!bn_partials || (bn_mean && bn_invstd && in_scale && in_relu && bn_cp > 0 && bn_cp % 4 == 0 && bn_cp <= cin_p),
-                "head_bwd: the BatchNorm reduction needs mean/invstd, a BN+ReLU input transform and bn_cp <= cin_p (bn_cp=%d)", bn_cp);
-    const int nb = head_blocks((int64_t)N * nvox_per_item);
-    hipStream_t st = (hipStream_t)stream;
-    const int nfin = Co * Ci + Co;
-    if (cin_p == 8) {
-        head_bwd_q_kernel<8><<<nb, HB, 0, st>>>(p, g0, g1, gin, gin_cs, ws, bn_mean, bn_invstd, bn_cp, bn_partials);
-        head_bwd_final_kernel<8><<<nfin, HB, 0, st>>>(ws, nb, Ci, Co, imap, dw, db);
-    } else if (cin_p == 16) {
-        head_bwd_q_kernel<16><<<nb, HB, 0, st>>>(p, g0, g1, gin, gin_cs, ws, bn_mean, bn_invstd, bn_cp, bn_partials);
-        head_bwd_final_kernel<16><<<nfin, HB, 0, st>>>(ws, nb, Ci, Co, imap, dw, db);
-    } else {
-        head_bwd_q_kernel<32><<<nb, HB, 0, st>>>(p, g0, g1, gin, gin_cs, ws, bn_mean, bn_invstd, bn_cp, bn_partials);
-        head_bwd_final_kernel<32><<<nfin, HB, 0, st>>>(ws, nb, Ci, Co, imap, dw, db);
-    }
-    CTU_CHECK_LAUNCH("head_bwd");
-    return CTU_OK;
+    return head_bwd_impl<float>(in, in_cs, cin_p, in_scale, in_shift, in_relu, w, bias, imap, Ci, Co, act, head_mode, g0, g1, gin,
+                                gin_cs, dw, db, ws, N, nvox_per_item, bn_mean, bn_invstd, bn_cp, bn_partials, stream);
+}
+/* bn_partials NULL: plain head backward */
+extern "C" int ctu_lp_head_bwd_bn(int dtype, const void* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
+                                  int in_relu, const float* w, const float* bias, const int32_t* imap, int Ci, int Co, int act,
+                                  int head_mode, const float* g0, const float* g1, void* gin, int gin_cs, float* dw,
+                                  float* db, float* ws, int N, int64_t nvox_per_item, const float* bn_mean,
+                                  const float* bn_invstd, int bn_cp, float* bn_partials, void* stream) {
+    CTU_DISPATCH_LP(dtype, return head_bwd_impl<T>((const T*)in, in_cs, cin_p, in_scale, in_shift, in_relu, w, bias, imap, Ci, Co, act,
+                                                   head_mode, g0, g1, (T*)gin, gin_cs, dw, db, ws, N, nvox_per_item, bn_mean,
+                                                   bn_invstd, bn_cp, bn_partials, stream));
 }
 
 extern "C" size_t ctu_loss_ws_floats(int N, int64_t V) {

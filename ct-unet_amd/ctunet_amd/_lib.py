@@ -96,13 +96,45 @@ SIGNATURES = {
     "ctu_hausdorff": (I, [P, P, I, I, I, I, I, P, P, P]),
     "ctu_extract_patches": (I, [P, P, I, I, I, I, I, I, I, I, P, P]),
     "ctu_stitch_patches": (I, [P, P, I, I, I, I, I, I, I, I, P, P]),
+    "ctu_lp_conv3d_packed_elems": (Z, [I, I, I]),
+    "ctu_lp_conv3d_num_blocks": (I, [I, I, I, I, I]),
+    "ctu_lp_pack_conv3d_weight": (I, [I, P, P, I, I, I, P, I, I, I, P]),
+    "ctu_lp_conv3d_fwd": (I, [I, P, I, I, P, P, I, P, P, I, P, I, I, P, I, I, I, I, I, P]),
+    "ctu_lp_conv3d_wgrad_ws_floats": (Z, [I, I, I, I, I, I, I]),
+    "ctu_lp_conv3d_wgrad": (I, [I, P, I, I, P, P, I, P, I, I, P, I, I, P, P, I, I, I, I, I, P]),
+    "ctu_lp_conv3d_first_fwd": (I, [I, P, I, P, P, I, P, I, I, P, I, I, I, I, P]),
+    "ctu_lp_conv3d_first_bwd_data": (I, [I, P, I, P, I, I, P, I, I, I, I, P]),
+    "ctu_lp_conv3d_first_wgrad": (I, [I, P, I, P, I, P, I, P, I, I, I, I, P]),
+    "ctu_lp_convt_packed_elems": (Z, [I, I, I]),
+    "ctu_lp_pack_convt_weight": (I, [I, P, P, I, I, P, I, I, I, P]),
+    "ctu_lp_convt2_fwd": (I, [I, P, I, I, P, P, I, P, P, I, P, I, I, I, I, I, I, P]),
+    "ctu_lp_convt2_bwd_data": (I, [I, P, I, I, P, P, I, I, I, I, I, I, P]),
+    "ctu_lp_convt2_wgrad_ws_floats": (Z, [I, I, I, I, I, I]),
+    "ctu_lp_convt2_wgrad": (I, [I, P, I, I, P, P, I, P, I, I, P, I, I, P, P, I, I, I, I, P]),
+    "ctu_lp_ncdhw_to_ndhwc": (I, [I, P, P, I, I, I, I, I, I, I, P]),
+    "ctu_lp_ndhwc_to_ncdhw": (I, [I, P, P, I, I, I, I, I, I, P]),
+    "ctu_lp_bn_relu_bwd_reduce": (I, [I, P, I, P, I, I, P, P, P, P, L, P, P]),
+    "ctu_lp_bn_relu_bwd_apply": (I, [I, P, I, P, I, I, P, P, P, P, P, L, P]),
+    "ctu_lp_maxpool2_fwd": (I, [I, P, I, I, P, P, I, P, I, I, I, I, I, P]),
+    "ctu_lp_maxpool2_bwd": (I, [I, P, I, I, P, P, I, P, I, P, I, I, I, I, I, I, P]),
+    "ctu_lp_maxpool2_bwd_bn": (I, [I, P, I, I, P, P, P, P, P, I, P, I, I, I, I, I, I, P, P]),
+    "ctu_lp_skip_add": (I, [I, P, I, P, P, I, P, I, P, P, I, P, I, I, L, P]),
+    "ctu_lp_channel_sum": (I, [I, P, I, I, L, P, P, I, P]),
+    "ctu_lp_head_fwd": (I, [I, P, I, I, P, P, I, P, P, P, I, I, I, I, P, P, I, L, P]),
+    "ctu_lp_head_bwd_bn": (I, [I, P, I, I, P, P, I, P, P, P, I, I, I, I, P, P, P, I, P, P, P, I, L, P, P, I, P, P]),
+    "ctu_scale_tensors": (I, [P, P, I, F, P]),
+    "ctu_comm_available": (I, []),
+    "ctu_comm_unique_id": (I, [P]),
+    "ctu_comm_init": (I, [C.POINTER(C.c_void_p), I, I, P]),
+    "ctu_comm_allreduce_f32": (I, [P, P, P, Z, I, P]),
+    "ctu_comm_destroy": (I, [P]),
     "ctu_channel_sum_num_blocks": (I, [L]),
     "ctu_channel_sum": (I, [P, I, I, L, P, P, I, P]),
     "ctu_adam_amsgrad": (I, [P, P, I, P, D, D, D, D, D, I, P]),
 }
 
 _lib = None
-ABI_VERSION = 3          # CTU_ABI_VERSION of the csrc/ this file mirrors (bumped on any signature change)
+ABI_VERSION = 4          # CTU_ABI_VERSION of the csrc/ this file mirrors (bumped on any signature change)
 
 
 class CtuError(RuntimeError):

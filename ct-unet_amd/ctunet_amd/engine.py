@@ -66,8 +66,18 @@ class _ConvRec:
 
 
 class UNetEngine:
-    def __init__(self, plan: NetPlan):
+    def __init__(self, plan: NetPlan, dtype: torch.dtype = torch.float32, loss_scale: Optional[float] = None):
+        """dtype: storage type of every activation / activation-gradient tensor (float32, or bfloat16 / float16 for the
+        reduced-precision path of BASELINE configs 4 / 5: 16-bit tensors in HBM, fp32 MFMA accumulation, fp32 BatchNorm
+        statistics, fp32 master weights and weight gradients).  loss_scale: float16 only -- the factor the incoming output
+        gradients are multiplied by before they enter the 16-bit backward (and every parameter gradient divided by at
+        the end); None = a power of two near voxels / 16, which puts the per-voxel loss gradient of a mean-reduced loss
+        (1 / voxels: 6e-8 for a 256^3 patch, below fp16's smallest normal 6e-5) at about 1/16."""
+        if dtype not in ops.ACT_DTYPES:
+            raise ValueError(f"ctunet_amd: activation dtype {dtype} not supported (float32, bfloat16, float16)")
         self.plan = plan
+        self.dtype = dtype
+        self.loss_scale = loss_scale
         self._pack_cache: Dict[Tuple, Tuple[int, torch.Tensor]] = {}
         self._replay_stats = False
         self._up_cache: Dict[str, Tuple] = {}
@@ -97,17 +107,25 @@ class UNetEngine:
         """MFMA-ordered copy of a weight tensor, cached by (tensor version, address).  The first request of a key
         packs it on the spot and records the job; refresh_packs() then re-packs every recorded job whose weight
         changed in ONE launch at the start of the next forward (into the same buffers: stable pointers)."""
-        key = (name, kind, mode, rin_p, nout_p, layout)
+        key = (name, kind, mode, rin_p, nout_p, layout, self.dtype)
         hit = self._pack_cache.get(key)
         ver = (w._version, w.data_ptr())
         if hit is not None and hit[0] == ver:
             return hit[1]
         wd = w.detach()
-        wp = hit[1] if hit is not None else torch.empty(ops.packed_floats(kind, w.shape[2], rin_p, nout_p, layout),
-                                                        dtype=torch.float32, device=w.device)
-        ops.pack_batch([(kind, wd.contiguous(), wp, imap, rin_p, nout_p, mode, layout)])
+        if self.dtype != torch.float32:                # 16-bit fragment-ordered copies of the fp32 masters
+            wp = self._pack_lp(kind, wd, imap, rin_p, nout_p, mode, hit[1] if hit is not None else None)
+        else:
+            wp = hit[1] if hit is not None else torch.empty(ops.packed_floats(kind, w.shape[2], rin_p, nout_p, layout),
+                                                            dtype=torch.float32, device=w.device)
+            ops.pack_batch([(kind, wd.contiguous(), wp, imap, rin_p, nout_p, mode, layout)])
         self._pack_cache[key] = (ver, wp, imap)
         return wp
+
+    def _pack_lp(self, kind, wd, imap, rin_p, nout_p, mode, into):
+        if kind == "conv":
+            return ops.pack_conv_w_lp(wd, imap, rin_p, nout_p, mode, self.dtype, into)
+        return ops.pack_convt_w_lp(wd, imap, rin_p, nout_p, mode, self.dtype, into)
 
     def refresh_packs(self, P: Dict[str, torch.Tensor]) -> None:
         # under graph capture every copy is re-packed unconditionally: the replayed graph must refresh them after each
@@ -115,13 +133,16 @@ class UNetEngine:
         force = P and next(iter(P.values())).is_cuda and torch.cuda.is_current_stream_capturing()
         jobs = []
         for key, ent in self._pack_cache.items():
-            name, kind, mode, rin_p, nout_p, layout = key
+            name, kind, mode, rin_p, nout_p, layout, dt = key
             w = P.get(name + ".weight")
-            if w is None or w.device != ent[1].device:
+            if w is None or w.device != ent[1].device or dt != self.dtype:
                 continue
             ver = (w._version, w.data_ptr())
             if force or ent[0] != ver:
-                jobs.append((kind, w.detach().contiguous(), ent[1], ent[2], rin_p, nout_p, mode, layout))
+                if dt != torch.float32:
+                    self._pack_lp(kind, w.detach(), ent[2], rin_p, nout_p, mode, ent[1])
+                else:
+                    jobs.append((kind, w.detach().contiguous(), ent[1], ent[2], rin_p, nout_p, mode, layout))
                 self._pack_cache[key] = (ver, ent[1], ent[2])
         ops.pack_batch(jobs)
 
@@ -130,14 +151,14 @@ class UNetEngine:
                  training: bool, n_upd: int, save: bool) -> Tuple[CL, Optional[_ConvRec]]:
         k = self.plan.k
         w = P[conv + ".weight"]
-        lay = ops.conv_layout(k, out.cp, x.dims[3])
+        lay = ops.conv_layout(k, out.cp, x.dims[3]) if self.dtype == torch.float32 else 0
         wp = self._packed(conv, w, "conv", imap, x.cp, out.cp, 0, lay)
         bias = P.get(conv + ".bias")
         bias_p = None if bias is None else bias.detach()
         dims = x.dims
         c = cout
         if training:
-            nblk = ops.conv_num_blocks(dims, out.cp, lay, k)
+            nblk = ops.conv_num_blocks(dims, out.cp, lay, k, self.dtype)
             stats = torch.empty((nblk, 2, out.cp), dtype=torch.float32, device=x.buf.device)
             ops.conv3d_fwd(x, wp, bias_p, out, k, stats, (cin, cout), lay)
             ops.bn_finalize_into(stats, nblk, c, out.cp, x.nvox, P[bn + ".weight"], P[bn + ".bias"],
@@ -160,8 +181,8 @@ class UNetEngine:
     def _fuse_up(self, x: CL, nout_p: int) -> bool:
         """Run ConvTranspose3d -> Conv3d of a decoder block as one coarse-grid kernel (ops.upconv_fused_fwd)?
         Levels whose first conv has at most 16 (padded) output channels: they hold the FLOPs and have enough boxes."""
-        return (self.plan.k == 3 and not self.plan.conv_bias and nout_p <= FUSE_UP_MAX_CO and FUSE_UP
-                and ops.upconv_fused_supported(x.dims, 3, x.cp, nout_p))
+        return (self.dtype == torch.float32 and self.plan.k == 3 and not self.plan.conv_bias and nout_p <= FUSE_UP_MAX_CO
+                and FUSE_UP and ops.upconv_fused_supported(x.dims, 3, x.cp, nout_p))
 
     def _upconv_bn(self, P, x: CL, prefix: str, ct: int, cout: int, cinv, out: CL, vec4: torch.Tensor, training: bool,
                    n_upd: int, save: bool) -> Tuple[CL, Optional[_ConvRec]]:
@@ -249,7 +270,8 @@ class UNetEngine:
         x = x.contiguous()
         e0 = plan.enc[0]
         first_direct = plan.conv_bias is False and ops.conv_first_supported(plan.k, cin, pad8(e0.cout), w)
-        cur = None if first_direct else ops.ncdhw_to_cl(x)
+        adt = self.dtype
+        cur = None if first_direct else ops.ncdhw_to_cl(x, dtype=adt)
         x_cl = cur
         cat: List[torch.Tensor] = []     # concat buffer per level
         xf: List[torch.Tensor] = []      # [4, 2Cp] scale/shift/mean/invstd of the concat buffer
@@ -263,10 +285,10 @@ class UNetEngine:
         xf_off = 0
         for i, blk in enumerate(plan.enc):
             cp = pad8(blk.cout)
-            cat.append(torch.empty((n, dd, hh, ww, 2 * cp), dtype=torch.float32, device=dev))
+            cat.append(torch.empty((n, dd, hh, ww, 2 * cp), dtype=adt, device=dev))
             xf.append(xf_all[xf_off:xf_off + 8 * cp].view(4, 2 * cp))
             xf_off += 8 * cp
-            t1 = CL(torch.empty((n, dd, hh, ww, cp), dtype=torch.float32, device=dev), 0, cp)
+            t1 = CL(torch.empty((n, dd, hh, ww, cp), dtype=adt, device=dev), 0, cp)
             v1 = torch.empty((4, cp), dtype=torch.float32, device=dev)
             imap = None
             if i == 0 and first_direct:
@@ -282,7 +304,7 @@ class UNetEngine:
                                                       training, n_upd, save)
             dskip.append(a2)
             dd, hh, ww = dd // 2, hh // 2, ww // 2
-            pl = CL(torch.empty((n, dd, hh, ww, cp), dtype=torch.float32, device=dev), 0, cp)
+            pl = CL(torch.empty((n, dd, hh, ww, cp), dtype=adt, device=dev), 0, cp)
             ops.maxpool_fwd(a2, pl)
             pooled.append(pl)
             cur = pl
@@ -292,8 +314,8 @@ class UNetEngine:
         center_out = None
         if plan.center_live or training:
             live = plan.center_live
-            c1 = CL(torch.empty((n, dd, hh, ww, cpc), dtype=torch.float32, device=dev), 0, cpc)
-            c2 = CL(torch.empty((n, dd, hh, ww, cpc), dtype=torch.float32, device=dev), 0, cpc)
+            c1 = CL(torch.empty((n, dd, hh, ww, cpc), dtype=adt, device=dev), 0, cpc)
+            c2 = CL(torch.empty((n, dd, hh, ww, cpc), dtype=adt, device=dev), 0, cpc)
             v1 = torch.empty((4, cpc), dtype=torch.float32, device=dev)
             v2 = torch.empty((4, cpc), dtype=torch.float32, device=dev)
             a1, r1 = self._conv_bn(P, cur, f"{cb.prefix}.{cb.first}", f"{cb.prefix}.{cb.first + 1}", cb.cin, cb.cout,
@@ -317,14 +339,14 @@ class UNetEngine:
             imap_t, cinv_t = self._maps(cur_segs, cur.cp, dev)
             wt = P[f"{blk.prefix}.0.weight"]
             dec_in.append(cur)
-            t1 = CL(torch.empty((n, dd, hh, ww, cp), dtype=torch.float32, device=dev), 0, cp)
+            t1 = CL(torch.empty((n, dd, hh, ww, cp), dtype=adt, device=dev), 0, cp)
             v1 = torch.empty((4, cp), dtype=torch.float32, device=dev)
             if self._fuse_up(cur, cp):
                 ups.append(None)                      # never materialised in forward; backward recomputes it
                 a1, recs[(blk.prefix, 1)] = self._upconv_bn(P, cur, blk.prefix, ct, blk.cout, cinv_t, t1, v1, training,
                                                             n_upd, save)
             else:
-                up = CL(torch.empty((n, dd, hh, ww, ctp), dtype=torch.float32, device=dev), 0, ctp)
+                up = CL(torch.empty((n, dd, hh, ww, ctp), dtype=adt, device=dev), 0, ctp)
                 wpt = self._packed(f"{blk.prefix}.0", wt, "convt", cinv_t, cur.cp, ctp, 0)
                 ops.convt_fwd(cur, wpt, P[f"{blk.prefix}.0.bias"].detach(), up)
                 ups.append(up)
@@ -339,7 +361,7 @@ class UNetEngine:
                 cur = CL(cat[i], 0, cp, xf[i][0][:cp], xf[i][1][:cp], True)
                 cur_segs = ((blk.cout, 0),)
             else:                                # "add": the sum of two differently normalised tensors is materialised
-                cur = CL(torch.empty((n, dd, hh, ww, cp), dtype=torch.float32, device=dev), 0, cp)
+                cur = CL(torch.empty((n, dd, hh, ww, cp), dtype=adt, device=dev), 0, cp)
                 ops.skip_add(CL(cat[i], 0, cp, xf[i][0][:cp], xf[i][1][:cp], True),
                              CL(cat[i], cp, cp, xf[i][0][cp:], xf[i][1][cp:], True), cur)
                 cur_segs = ((blk.cout, 0),)
@@ -374,7 +396,7 @@ class UNetEngine:
             if rec.bias:
                 grads[rec.conv + ".bias"] = dbias
         if gin is not None:
-            lay = ops.conv_layout(k, gin.cp, ga.dims[3])
+            lay = ops.conv_layout(k, gin.cp, ga.dims[3]) if self.dtype == torch.float32 else 0
             wpd = self._packed(rec.conv, P[rec.conv + ".weight"], "conv", rec.imap, ga.cp, gin.cp, 1, lay)
             ops.conv3d_fwd(ga, wpd, None, gin, k, None, (rec.cout, rec.cin), lay)
 
@@ -387,6 +409,14 @@ class UNetEngine:
         n, d, h, w = ctx["dims"]
         dev = g0.device
         nlev = len(plan.enc)
+        # float16 gradients: scale what comes in (the per-voxel gradient of a mean-reduced loss underflows fp16), un-scale
+        # every parameter gradient and dx on the way out; bf16 / fp32 need none
+        gs = 1.0
+        if self.dtype == torch.float16:
+            gs = self.loss_scale if self.loss_scale else float(2 ** max(0, (n * d * h * w).bit_length() - 5))
+            g0 = g0.contiguous().clone()
+            g1 = None if g1 is None else g1.contiguous().clone()
+            ops.scale_tensors([g0, g1], gs)
         grads: Dict[str, torch.Tensor] = {}
         emitted: set = set()
 
@@ -405,10 +435,10 @@ class UNetEngine:
                 ws_n = max(ws_n, ops.conv_first_wgrad_ws(r.y.dims, r.cin))
                 part_n = max(part_n, ops.bn_bwd_partials_floats(r.y.nvox, r.y.cp))
                 continue
-            ws_n = max(ws_n, ops.conv3d_wgrad_ws(r.y.dims, k, r.x.cp if r.x is not None else pad8(r.cin), r.y.cp))
+            ws_n = max(ws_n, ops.conv3d_wgrad_ws(r.y.dims, k, r.x.cp if r.x is not None else pad8(r.cin), r.y.cp, self.dtype))
             part_n = max(part_n, ops.bn_bwd_partials_floats(r.y.nvox, r.y.cp))
         for x_in, blk in zip(ctx["dec_in"], plan.dec):
-            ws_n = max(ws_n, ops.convt_wgrad_ws(x_in.dims, x_in.cp, pad8(blk.cin)))
+            ws_n = max(ws_n, ops.convt_wgrad_ws(x_in.dims, x_in.cp, pad8(blk.cin), self.dtype))
         for dsk in ctx["dskip"]:
             part_n = max(part_n, ops.maxpool_bwd_bn_blocks(dsk.dims, dsk.cp) * 2 * dsk.cp)
         part_n = max(part_n, ops.head_bwd_blocks(ctx["head_in"].dims) * 2 * pad8(plan.dec[-1].cout))
@@ -530,6 +560,8 @@ class UNetEngine:
             else:
                 self._conv_bn_bwd(P, r1, g_d1, None, grads, ws, part)
             emit()
+        if gs != 1.0:
+            ops.scale_tensors([g for g in grads.values() if g is not None] + ([dx] if dx is not None else []), 1.0 / gs)
         if sync is not None:
             grads.update(sync.finish())
         return grads, dx

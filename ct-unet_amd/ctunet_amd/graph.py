@@ -6,8 +6,8 @@ The step is the reference's ``Model.forward_pass`` train branch (ctunet/pytorch/
 host round trips: the per-term ``float(loss)`` syncs become ONE device->host copy after the replay.
 With ``distributed`` set (one process per GPU) the step is TWO graphs around one eagerly launched collective:
 graph 1 = forward + loss + backward + flattening of the live gradients into one static buffer; then the gradient
-sum over ranks (one flat RCCL all-reduce, 3.3 MB for UNet()) -- no collective is ever captured --; graph 2 = scale
-by 1/world + the fused optimizer step reading the gradients straight from the flat buffer.  The bucketed,
+sum over ranks (one flat RCCL all-reduce, 3.3 MB for UNet()) -- no collective is ever captured --; graph 2 = the fused
+optimizer step reading the gradients straight from the flat buffer.  The bucketed,
 backward-overlapped ``parallel.GradSync`` path remains the eager alternative.
 """
 from __future__ import annotations
@@ -119,15 +119,18 @@ class GraphedTrainStep:
         return torch.stack([t.detach() for t in terms] + [loss.detach()])
 
     def _scale_and_step(self) -> None:
-        self.flat.mul_(1.0 / self.world)
-        self.opt.step()
+        self.opt.step()                 # the collective already averaged (ncclAvg)
+
+    def _allreduce(self) -> None:
+        """Mean over ranks of the flat gradient buffer: RCCL through the C ABI on the current stream (never captured)."""
+        from .parallel import get_communicator
+        get_communicator(self.group).allreduce_(self.flat, average=True)
 
     def _eager_reduce_step(self) -> None:
         """One eagerly launched all-reduce + optimizer step on the flat buffer the last _step() produced."""
-        import torch.distributed as dist
         for p, v in zip(self._live, self.flat.split([p.numel() for p in self._live])):
             p.grad = v.view_as(p)
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        self._allreduce()
         self._scale_and_step()
         for p in self._live:
             p.grad = None
@@ -142,8 +145,7 @@ class GraphedTrainStep:
                 dst.copy_(src)
         self.graph.replay()
         if self.distributed:
-            import torch.distributed as dist
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            self._allreduce()
             self.graph2.replay()
         # the replayed optimizer kernel wrote the parameters through raw pointers: bump their version counters, so that
         # an eagerly launched forward after this replay (the reference's train-then-validate epoch loop,

@@ -118,10 +118,26 @@ class _HipNet(nn.Module):
 
     def _engine(self) -> UNetEngine:
         eng = self.__dict__.get("_eng")
-        if eng is None:
-            eng = UNetEngine(self._plan)
+        dt = self.__dict__.get("_act_dtype", torch.float32)
+        if eng is None or eng.dtype != dt:
+            eng = UNetEngine(self._plan, dt, self.__dict__.get("_loss_scale"))
             self.__dict__["_eng"] = eng       # not a submodule / not in state_dict
         return eng
+
+    def set_precision(self, dtype=torch.float32, loss_scale=None):
+        """Storage type of the activations between the kernels: ``torch.float32`` (default: the reference's arithmetic,
+        1e-4 parity), ``torch.bfloat16`` or ``torch.float16`` (BASELINE configs 4 / 5: 16-bit tensors in HBM,
+        v_mfma_f32_16x16x32 with fp32 accumulation, fp32 BatchNorm statistics, fp32 master weights / gradients /
+        optimizer -- what ``torch.autocast`` would give the reference).  Inputs, outputs, parameters and their gradients
+        stay float32 either way.  ``loss_scale`` (float16 only): see ``UNetEngine``.  Accepts the strings
+        "fp32" / "bf16" / "fp16" too.  Returns self."""
+        names = {"fp32": torch.float32, "f32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16, "f16": torch.float16}
+        dt = names.get(dtype, dtype) if isinstance(dtype, str) else dtype
+        if dt not in (torch.float32, torch.bfloat16, torch.float16):
+            raise ValueError(f"ctunet_amd: unsupported precision {dtype}")
+        self.__dict__["_act_dtype"] = dt
+        self.__dict__["_loss_scale"] = loss_scale
+        return self
 
     def _run(self, x):
         return run_network(self, self._engine(), x)

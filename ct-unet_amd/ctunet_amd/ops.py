@@ -22,6 +22,10 @@ def pad8(c: int) -> int:
     return (c + 7) // 8 * 8
 
 
+LP_CODE = {torch.bfloat16: 1, torch.float16: 2}          # CTU_BF16 / CTU_F16 of include/ctunet_hip.h
+ACT_DTYPES = (torch.float32, torch.bfloat16, torch.float16)
+
+
 def _need_cuda(t: torch.Tensor, name: str) -> None:
     if not t.is_cuda:
         raise RuntimeError(f"ctunet_amd: {name} must live on the GPU (MI355X); this path has no CPU fallback")
@@ -29,10 +33,25 @@ def _need_cuda(t: torch.Tensor, name: str) -> None:
         raise RuntimeError(f"ctunet_amd: {name} must be float32, got {t.dtype}")
 
 
-def _ptr(t: Optional[torch.Tensor], off_floats: int = 0):
+def _ptr(t: Optional[torch.Tensor], off_elems: int = 0):
     if t is None:
         return None
-    return t.data_ptr() + 4 * off_floats
+    return t.data_ptr() + t.element_size() * off_elems
+
+
+def _dual(code: int, name: str, *args) -> None:
+    """ctu_<name>(args) for fp32 tensors, ctu_lp_<name>(dtype code, args) for 16-bit ones (same argument lists)."""
+    lib = _lib.load()
+    if code:
+        _lib.check(getattr(lib, "ctu_lp_" + name)(code, *args), "lp_" + name)
+    else:
+        _lib.check(getattr(lib, "ctu_" + name)(*args), name)
+
+
+def lp(t_or_dtype) -> int:
+    """dtype code of the ctu_lp_* entry points for a 16-bit activation tensor / dtype; 0 for float32."""
+    dt = t_or_dtype if isinstance(t_or_dtype, torch.dtype) else t_or_dtype.dtype
+    return LP_CODE.get(dt, 0)
 
 
 def _stream():
@@ -109,8 +128,18 @@ class CL:
     def __post_init__(self):
         if self.cp == 0:
             self.cp = self.buf.shape[-1] - self.c0
-        assert self.buf.dim() == 5 and self.buf.is_contiguous()
+        assert self.buf.dim() == 5 and self.buf.is_contiguous() and self.buf.dtype in ACT_DTYPES
         assert self.cp % 8 == 0 and self.c0 % 4 == 0 and self.c0 + self.cp <= self.buf.shape[-1]
+        # 16-bit tensors: slices start on 16-byte boundaries and the voxel stride keeps them there
+        assert self.buf.dtype == torch.float32 or (self.c0 % 8 == 0 and self.buf.shape[-1] % 8 == 0)
+
+    @property
+    def dtype(self) -> torch.dtype:
+        return self.buf.dtype
+
+    @property
+    def lp(self) -> int:
+        return LP_CODE.get(self.buf.dtype, 0)
 
     @property
     def cs(self) -> int:
@@ -142,28 +171,26 @@ class CL:
         return CL(self.buf, self.c0, self.cp, scale, shift, relu)
 
 
-def new_cl(n, d, h, w, cs, device, zero=False) -> torch.Tensor:
+def new_cl(n, d, h, w, cs, device, zero=False, dtype=torch.float32) -> torch.Tensor:
     f = torch.zeros if zero else torch.empty
-    return f((n, d, h, w, cs), dtype=torch.float32, device=device)
+    return f((n, d, h, w, cs), dtype=dtype, device=device)
 
 
 # ---------------------------------------------------------------------------- layout
-def ncdhw_to_cl(x: torch.Tensor, cp: Optional[int] = None) -> CL:
+def ncdhw_to_cl(x: torch.Tensor, cp: Optional[int] = None, dtype=torch.float32) -> CL:
     _need_cuda(x, "input")
     x = x.contiguous()
     n, c, d, h, w = x.shape
     cp = cp or pad8(c)
-    out = new_cl(n, d, h, w, cp, x.device)
-    lib = _lib.load()
-    _lib.check(lib.ctu_ncdhw_to_ndhwc(x.data_ptr(), out.data_ptr(), n, c, d, h, w, cp, cp, _stream()), "ncdhw_to_ndhwc")
+    out = new_cl(n, d, h, w, cp, x.device, dtype=dtype)
+    _dual(lp(dtype), "ncdhw_to_ndhwc", x.data_ptr(), out.data_ptr(), n, c, d, h, w, cp, cp, _stream())
     return CL(out, 0, cp)
 
 
 def cl_to_ncdhw(a: CL, c: int) -> torch.Tensor:
     n, d, h, w = a.dims
     out = torch.empty((n, c, d, h, w), dtype=torch.float32, device=a.buf.device)
-    lib = _lib.load()
-    _lib.check(lib.ctu_ndhwc_to_ncdhw(a.ptr, out.data_ptr(), n, c, d, h, w, a.cs, _stream()), "ndhwc_to_ncdhw")
+    _dual(a.lp, "ndhwc_to_ncdhw", a.ptr, out.data_ptr(), n, c, d, h, w, a.cs, _stream())
     return out
 
 
@@ -209,9 +236,11 @@ def pack_batch(jobs) -> None:
     _lib.check(_lib.load().ctu_pack_batch(arr, len(jobs), _stream()), "pack_batch")
 
 
-def conv_num_blocks(dims, nout_p: int, layout: int = 0, k: int = 3) -> int:
+def conv_num_blocks(dims, nout_p: int, layout: int = 0, k: int = 3, dtype=torch.float32) -> int:
     """Rows of the BN partial-sum buffer a conv3d_fwd call with this geometry writes."""
     n, d, h, w = dims
+    if lp(dtype):
+        return _lib.load().ctu_lp_conv3d_num_blocks(n, d, h, w, k)
     return _lib.load().ctu_conv3d_num_blocks(n, d, h, w, k, nout_p, layout)
 
 
@@ -221,6 +250,18 @@ def conv3d_fwd(x: CL, wp: torch.Tensor, bias: Optional[torch.Tensor], out: CL, k
     n, d, h, w = x.dims
     assert out.dims == x.dims
     lib = _lib.load()
+    if x.lp:
+        assert out.dtype == x.dtype and wp.dtype == x.dtype, (x.dtype, out.dtype, wp.dtype)
+        t0 = TIMER.begin() if TIMER is not None else None
+        _lib.check(lib.ctu_lp_conv3d_fwd(x.lp, x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), wp.data_ptr(),
+                                         _ptr(bias), 0 if bias is None else bias.numel(), out.ptr, out.cs, out.cp,
+                                         _ptr(stats), n, d, h, w, k, _stream()), "lp_conv3d_fwd")
+        if t0 is not None:
+            ci, co = algo_ch if algo_ch is not None else (x.cp, out.cp)
+            vox = n * d * h * w
+            TIMER.end(f"lp_conv_fwd_kernel<{'bf16' if x.lp == 1 else 'f16'}, {k}>", 2.0 * ci * co * k ** 3 * vox,
+                      2.0 * vox * (ci + co), t0, (w, x.cp, out.cp))
+        return
     t0 = TIMER.begin() if TIMER is not None else None
     _lib.check(lib.ctu_conv3d_fwd(x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), wp.data_ptr(),
                                   _ptr(bias), 0 if bias is None else bias.numel(), out.ptr, out.cs, out.cp, _ptr(stats),
@@ -236,6 +277,20 @@ def conv3d_wgrad(x: CL, g: CL, co: int, ci: int, k: int, cinv: Optional[torch.Te
                  want_bias: bool) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     n, d, h, w = x.dims
     lib = _lib.load()
+    if x.lp:
+        assert g.dtype == x.dtype
+        need = lib.ctu_lp_conv3d_wgrad_ws_floats(n, d, h, w, k, x.cp, g.cp)
+        assert ws.numel() >= need, (ws.numel(), need)
+        dw = torch.empty((co, ci, k, k, k), dtype=torch.float32, device=x.buf.device)
+        t0 = TIMER.begin() if TIMER is not None else None
+        _lib.check(lib.ctu_lp_conv3d_wgrad(x.lp, x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), g.ptr, g.cs,
+                                           g.cp, dw.data_ptr(), co, ci, _ptr(cinv), ws.data_ptr(), n, d, h, w, k, _stream()),
+                   "lp_conv3d_wgrad")
+        if t0 is not None:
+            vox = n * d * h * w
+            TIMER.end(f"lp_conv_wgrad_kernel<{'bf16' if x.lp == 1 else 'f16'}, {k}> (+slab reduce)",
+                      2.0 * ci * co * k ** 3 * vox, 2.0 * vox * (ci + co), t0, (w, x.cp, g.cp))
+        return dw, (channel_sum(g, co) if want_bias else None)
     need = lib.ctu_conv3d_wgrad_ws_floats(n, d, h, w, k, x.cp, g.cp)
     assert ws.numel() >= need, (ws.numel(), need)
     dw = torch.empty((co, ci, k, k, k), dtype=torch.float32, device=x.buf.device)
@@ -251,9 +306,25 @@ def conv3d_wgrad(x: CL, g: CL, co: int, ci: int, k: int, cinv: Optional[torch.Te
     return dw, db
 
 
-def conv3d_wgrad_ws(dims, k, cin_p, cout_p) -> int:
+def conv3d_wgrad_ws(dims, k, cin_p, cout_p, dtype=torch.float32) -> int:
     n, d, h, w = dims
+    if lp(dtype):
+        return _lib.load().ctu_lp_conv3d_wgrad_ws_floats(n, d, h, w, k, cin_p, cout_p)
     return _lib.load().ctu_conv3d_wgrad_ws_floats(n, d, h, w, k, cin_p, cout_p)
+
+
+def pack_conv_w_lp(w: torch.Tensor, cinv: Optional[torch.Tensor], rin_p: int, nout_p: int, mode: int, dtype: torch.dtype,
+                   into: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """16-bit MFMA-fragment-ordered copy of an fp32 master Conv3d weight (mode 0 forward, 1 data gradient)."""
+    _need_cuda(w, "conv weight")
+    co, ci, k = w.shape[0], w.shape[1], w.shape[2]
+    lib = _lib.load()
+    n = lib.ctu_lp_conv3d_packed_elems(k, rin_p, nout_p)
+    wp = into if into is not None else torch.empty(n, dtype=dtype, device=w.device)
+    assert wp.numel() == n and wp.dtype == dtype
+    _lib.check(lib.ctu_lp_pack_conv3d_weight(LP_CODE[dtype], w.contiguous().data_ptr(), wp.data_ptr(), co, ci, k, _ptr(cinv),
+                                             rin_p, nout_p, mode, _stream()), "lp_pack_conv3d_weight")
+    return wp
 
 
 # ---------------------------------------------------------------------------- first layer (C_in <= 2)
@@ -273,9 +344,8 @@ def conv_first_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor
     n, cin, d, h, w_ = x.shape
     lib = _lib.load()
     t0 = TIMER.begin() if TIMER is not None else None
-    _lib.check(lib.ctu_conv3d_first_fwd(x.data_ptr(), cin, w.data_ptr(), _ptr(bias), 0 if bias is None else bias.numel(),
-                                        out.ptr, out.cs, w.shape[0], _ptr(stats), n, d, h, w_, _stream()),
-               "conv3d_first_fwd")
+    _dual(out.lp, "conv3d_first_fwd", x.data_ptr(), cin, w.data_ptr(), _ptr(bias), 0 if bias is None else bias.numel(),
+          out.ptr, out.cs, w.shape[0], _ptr(stats), n, d, h, w_, _stream())
     if t0 is not None:
         vox = n * d * h * w_
         TIMER.end(f"first_fwd_kernel<{cin}>", 2.0 * cin * w.shape[0] * 27 * vox, 4.0 * vox * (cin + w.shape[0]), t0)
@@ -286,8 +356,7 @@ def conv_first_bwd_data(g: CL, w: torch.Tensor, cin: int) -> torch.Tensor:
     dx = torch.empty((n, cin, d, h, w_), dtype=torch.float32, device=g.buf.device)
     lib = _lib.load()
     t0 = TIMER.begin() if TIMER is not None else None
-    _lib.check(lib.ctu_conv3d_first_bwd_data(g.ptr, g.cs, w.data_ptr(), cin, w.shape[0], dx.data_ptr(), n, d, h, w_,
-                                             _stream()), "conv3d_first_bwd_data")
+    _dual(g.lp, "conv3d_first_bwd_data", g.ptr, g.cs, w.data_ptr(), cin, w.shape[0], dx.data_ptr(), n, d, h, w_, _stream())
     if t0 is not None:
         vox = n * d * h * w_
         TIMER.end(f"first_bwd_data_kernel<{cin}>", 2.0 * cin * w.shape[0] * 27 * vox, 4.0 * vox * (cin + w.shape[0]), t0)
@@ -300,8 +369,7 @@ def conv_first_wgrad(x: torch.Tensor, g: CL, co: int, ws: torch.Tensor) -> torch
     assert ws.numel() >= lib.ctu_conv3d_first_wgrad_ws_floats(n, d, h, w_, cin)
     dw = torch.empty((co, cin, 3, 3, 3), dtype=torch.float32, device=x.device)
     t0 = TIMER.begin() if TIMER is not None else None
-    _lib.check(lib.ctu_conv3d_first_wgrad(x.data_ptr(), cin, g.ptr, g.cs, dw.data_ptr(), co, ws.data_ptr(), n, d, h, w_,
-                                          _stream()), "conv3d_first_wgrad")
+    _dual(g.lp, "conv3d_first_wgrad", x.data_ptr(), cin, g.ptr, g.cs, dw.data_ptr(), co, ws.data_ptr(), n, d, h, w_, _stream())
     if t0 is not None:
         vox = n * d * h * w_
         TIMER.end(f"first_wgrad_kernel<{cin}> (+slab reduce)", 2.0 * cin * co * 27 * vox, 4.0 * vox * (cin + co), t0)
@@ -356,8 +424,8 @@ def bn_relu_bwd(y: CL, ga: CL, vec: torch.Tensor, gamma: torch.Tensor, c: int, p
     sc, sh, mu, istd = (vec[i].data_ptr() for i in range(4))
     st = _stream()
     if pre_reduced is None:       # (else: the kernel that produced ga wrote the nb reduction rows, maxpool_bwd(bn=...))
-        _lib.check(lib.ctu_bn_relu_bwd_reduce(y.ptr, y.cs, ga.ptr, ga.cs, cp, sc, sh, mu, istd, nvox, partials.data_ptr(),
-                                              st), "bn_relu_bwd_reduce")
+        assert ga.dtype == y.dtype
+        _dual(y.lp, "bn_relu_bwd_reduce", y.ptr, y.cs, ga.ptr, ga.cs, cp, sc, sh, mu, istd, nvox, partials.data_ptr(), st)
     dgb = torch.empty((2, c), dtype=torch.float32, device=y.buf.device)
     coef = torch.empty((3, cp), dtype=torch.float32, device=y.buf.device)
     rm, rv, mom, eps, nbt = (tuple(replay) + (None,))[:5] if replay is not None else (None, None, 0.0, 0.0, None)
@@ -365,8 +433,7 @@ def bn_relu_bwd(y: CL, ga: CL, vec: torch.Tensor, gamma: torch.Tensor, c: int, p
     _lib.check(lib.ctu_bn_bwd_finalize(partials.data_ptr(), nb, c, cp, float(nvox), gamma.data_ptr(), istd,
                                        dgb[0].data_ptr(), dgb[1].data_ptr(), coef.data_ptr(), mu, _ptr(rm), _ptr(rv),
                                        mom, eps, None if nbt is None else nbt.data_ptr(), st), "bn_bwd_finalize")
-    _lib.check(lib.ctu_bn_relu_bwd_apply(y.ptr, y.cs, ga.ptr, ga.cs, cp, sc, sh, mu, istd, coef.data_ptr(), nvox, st),
-               "bn_relu_bwd_apply")
+    _dual(y.lp, "bn_relu_bwd_apply", y.ptr, y.cs, ga.ptr, ga.cs, cp, sc, sh, mu, istd, coef.data_ptr(), nvox, st)
     return dgb[0], dgb[1]
 
 
@@ -378,8 +445,9 @@ def bn_bwd_partials_floats(nvox: int, cp: int) -> int:
 def maxpool_fwd(x: CL, out: CL) -> None:
     n, d, h, w = x.dims
     lib = _lib.load()
-    _lib.check(lib.ctu_maxpool2_fwd(x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), out.ptr, out.cs,
-                                    n, d, h, w, _stream()), "maxpool2_fwd")
+    assert out.dtype == x.dtype
+    _dual(x.lp, "maxpool2_fwd", x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), out.ptr, out.cs, n, d, h, w,
+          _stream())
 
 
 def maxpool_bwd_bn_blocks(dims, cp: int) -> int:
@@ -397,12 +465,11 @@ def maxpool_bwd(x: CL, gout: CL, gin: CL, accumulate: bool, bn=None) -> Optional
         nb = lib.ctu_maxpool2_bwd_bn_num_blocks(n, d, h, w, x.cp)
         assert x.scale is not None and x.relu and partials.numel() >= nb * 2 * x.cp
         assert vec[0].data_ptr() == x.scale.data_ptr() and vec[1].data_ptr() == x.shift.data_ptr()
-        _lib.check(lib.ctu_maxpool2_bwd_bn(x.ptr, x.cs, x.cp, vec[0].data_ptr(), vec[1].data_ptr(), vec[2].data_ptr(),
-                                           vec[3].data_ptr(), gout.ptr, gout.cs, gin.ptr, gin.cs, int(accumulate), n, d, h, w,
-                                           partials.data_ptr(), _stream()), "maxpool2_bwd_bn")
+        _dual(x.lp, "maxpool2_bwd_bn", x.ptr, x.cs, x.cp, vec[0].data_ptr(), vec[1].data_ptr(), vec[2].data_ptr(),
+              vec[3].data_ptr(), gout.ptr, gout.cs, gin.ptr, gin.cs, int(accumulate), n, d, h, w, partials.data_ptr(), _stream())
         return nb
-    _lib.check(lib.ctu_maxpool2_bwd(x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), gout.ptr, gout.cs,
-                                    gin.ptr, gin.cs, int(accumulate), n, d, h, w, _stream()), "maxpool2_bwd")
+    _dual(x.lp, "maxpool2_bwd", x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), gout.ptr, gout.cs, gin.ptr,
+          gin.cs, int(accumulate), n, d, h, w, _stream())
 
 
 # ---------------------------------------------------------------------------- conv transpose
@@ -416,9 +483,29 @@ def pack_convt_w(w: torch.Tensor, cinv, rin_p: int, nout_p: int, mode: int) -> t
     return wp
 
 
+def pack_convt_w_lp(w: torch.Tensor, cinv, rin_p: int, nout_p: int, mode: int, dtype: torch.dtype,
+                    into: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """16-bit fragment-ordered copy of an fp32 master ConvTranspose3d weight [Ci,Co,2,2,2] (mode 0 forward, 1 data gradient)."""
+    _need_cuda(w, "convT weight")
+    ci, co = w.shape[0], w.shape[1]
+    lib = _lib.load()
+    n = lib.ctu_lp_convt_packed_elems(rin_p, nout_p, mode)
+    wp = into if into is not None else torch.empty(n, dtype=dtype, device=w.device)
+    assert wp.numel() == n and wp.dtype == dtype
+    _lib.check(lib.ctu_lp_pack_convt_weight(LP_CODE[dtype], w.contiguous().data_ptr(), wp.data_ptr(), ci, co, _ptr(cinv), rin_p,
+                                            nout_p, mode, _stream()), "lp_pack_convt_weight")
+    return wp
+
+
 def convt_fwd(x: CL, wp: torch.Tensor, bias: Optional[torch.Tensor], out: CL) -> None:
     n, d, h, w = x.dims
     lib = _lib.load()
+    if x.lp:
+        assert out.dtype == x.dtype and wp.dtype == x.dtype
+        _lib.check(lib.ctu_lp_convt2_fwd(x.lp, x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), wp.data_ptr(),
+                                         _ptr(bias), 0 if bias is None else bias.numel(), out.ptr, out.cs, out.cp, n, d, h, w,
+                                         _stream()), "lp_convt2_fwd")
+        return
     _lib.check(lib.ctu_convt2_fwd(x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), wp.data_ptr(),
                                   _ptr(bias), 0 if bias is None else bias.numel(), out.ptr, out.cs, out.cp, n, d, h, w,
                                   _stream()), "convt2_fwd")
@@ -427,6 +514,11 @@ def convt_fwd(x: CL, wp: torch.Tensor, bias: Optional[torch.Tensor], out: CL) ->
 def convt_bwd_data(gout: CL, wp: torch.Tensor, gin: CL) -> None:
     n, d, h, w = gin.dims
     lib = _lib.load()
+    if gout.lp:
+        assert gin.dtype == gout.dtype and wp.dtype == gout.dtype
+        _lib.check(lib.ctu_lp_convt2_bwd_data(gout.lp, gout.ptr, gout.cs, gout.cp, wp.data_ptr(), gin.ptr, gin.cs, gin.cp, n, d,
+                                              h, w, _stream()), "lp_convt2_bwd_data")
+        return
     _lib.check(lib.ctu_convt2_bwd_data(gout.ptr, gout.cs, gout.cp, wp.data_ptr(), gin.ptr, gin.cs, gin.cp, n, d, h, w,
                                        _stream()), "convt2_bwd_data")
 
@@ -434,6 +526,14 @@ def convt_bwd_data(gout: CL, wp: torch.Tensor, gin: CL) -> None:
 def convt_wgrad(x: CL, g: CL, ci: int, co: int, imap, ws: torch.Tensor):
     n, d, h, w = x.dims
     lib = _lib.load()
+    if x.lp:
+        assert g.dtype == x.dtype
+        assert ws.numel() >= lib.ctu_lp_convt2_wgrad_ws_floats(n, d, h, w, x.cp, g.cp)
+        dw = torch.empty((ci, co, 2, 2, 2), dtype=torch.float32, device=x.buf.device)
+        _lib.check(lib.ctu_lp_convt2_wgrad(x.lp, x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), g.ptr, g.cs,
+                                           g.cp, dw.data_ptr(), ci, co, _ptr(imap), ws.data_ptr(), n, d, h, w, _stream()),
+                   "lp_convt2_wgrad")
+        return dw, channel_sum(g, co)
     assert ws.numel() >= lib.ctu_convt2_wgrad_ws_floats(n, d, h, w, x.cp, g.cp)
     dw = torch.empty((ci, co, 2, 2, 2), dtype=torch.float32, device=x.buf.device)
     db = torch.empty(co, dtype=torch.float32, device=x.buf.device)
@@ -443,8 +543,10 @@ def convt_wgrad(x: CL, g: CL, ci: int, co: int, imap, ws: torch.Tensor):
     return dw, db
 
 
-def convt_wgrad_ws(dims, cin_p, cout_p) -> int:
+def convt_wgrad_ws(dims, cin_p, cout_p, dtype=torch.float32) -> int:
     n, d, h, w = dims
+    if lp(dtype):
+        return _lib.load().ctu_lp_convt2_wgrad_ws_floats(n, d, h, w, cin_p, cout_p)
     return _lib.load().ctu_convt2_wgrad_ws_floats(n, d, h, w, cin_p, cout_p)
 
 
@@ -461,9 +563,8 @@ def head_fwd(x: CL, w: torch.Tensor, b: torch.Tensor, imap, act: int, head_mode:
     else:
         out0 = torch.empty((n, 2, d, h, w_), dtype=torch.float32, device=dev)
         out1 = torch.empty((n, 2, d, h, w_), dtype=torch.float32, device=dev)
-    _lib.check(lib.ctu_head_fwd(x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), w.data_ptr(),
-                                b.data_ptr(), _ptr(imap), ci, co, act, head_mode, out0.data_ptr(), _ptr(out1), n, v,
-                                _stream()), "head_fwd")
+    _dual(x.lp, "head_fwd", x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), w.data_ptr(), b.data_ptr(),
+          _ptr(imap), ci, co, act, head_mode, out0.data_ptr(), _ptr(out1), n, v, _stream())
     return out0, out1
 
 
@@ -484,14 +585,13 @@ def head_bwd(x: CL, w: torch.Tensor, b: torch.Tensor, imap, act: int, head_mode:
         bn_cp = vec.shape[1]
         rows = lib.ctu_head_bwd_num_blocks(n, v)
         assert x.scale is not None and x.relu and vec[0].data_ptr() == x.scale.data_ptr() and partials.numel() >= rows * 2 * bn_cp
-        _lib.check(lib.ctu_head_bwd_bn(x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), w.data_ptr(),
-                                       b.data_ptr(), _ptr(imap), ci, co, act, head_mode, g0.data_ptr(), _ptr(g1), gin.ptr,
-                                       gin.cs, dw.data_ptr(), db.data_ptr(), ws.data_ptr(), n, v, vec[2].data_ptr(),
-                                       vec[3].data_ptr(), bn_cp, partials.data_ptr(), _stream()), "head_bwd_bn")
+        _dual(x.lp, "head_bwd_bn", x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), w.data_ptr(), b.data_ptr(),
+              _ptr(imap), ci, co, act, head_mode, g0.data_ptr(), _ptr(g1), gin.ptr, gin.cs, dw.data_ptr(), db.data_ptr(),
+              ws.data_ptr(), n, v, vec[2].data_ptr(), vec[3].data_ptr(), bn_cp, partials.data_ptr(), _stream())
         return dw, db, rows
-    _lib.check(lib.ctu_head_bwd(x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), w.data_ptr(),
-                                b.data_ptr(), _ptr(imap), ci, co, act, head_mode, g0.data_ptr(), _ptr(g1), gin.ptr,
-                                gin.cs, dw.data_ptr(), db.data_ptr(), ws.data_ptr(), n, v, _stream()), "head_bwd")
+    _dual(x.lp, "head_bwd_bn", x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), w.data_ptr(), b.data_ptr(),
+          _ptr(imap), ci, co, act, head_mode, g0.data_ptr(), _ptr(g1), gin.ptr, gin.cs, dw.data_ptr(), db.data_ptr(),
+          ws.data_ptr(), n, v, None, None, 0, None, _stream())
     return dw, db
 
 
@@ -537,11 +637,10 @@ def loss_bwd(pred, target, ce_lambda, dice_lambda, dice_softmax, ws, g_ce: Optio
 def skip_add(a: CL, b: Optional[CL], out: CL) -> None:
     """out = act(a) + act(b) (additive skip, UNet(cat=False)); b None: out = act(a) (channel-slice copy)."""
     assert out.dims == a.dims and out.cp == a.cp and (b is None or (b.dims == a.dims and b.cp == a.cp))
-    _lib.check(_lib.load().ctu_skip_add(a.ptr, a.cs, _ptr(a.scale), _ptr(a.shift), int(a.relu),
-                                        0 if b is None else b.ptr, 0 if b is None else b.cs,
-                                        _ptr(b.scale) if b is not None else 0, _ptr(b.shift) if b is not None else 0,
-                                        int(b.relu) if b is not None else 0, out.ptr, out.cs, out.cp, a.nvox, _stream()),
-               "skip_add")
+    assert out.dtype == a.dtype and (b is None or b.dtype == a.dtype)
+    _dual(a.lp, "skip_add", a.ptr, a.cs, _ptr(a.scale), _ptr(a.shift), int(a.relu), 0 if b is None else b.ptr,
+          0 if b is None else b.cs, _ptr(b.scale) if b is not None else 0, _ptr(b.shift) if b is not None else 0,
+          int(b.relu) if b is not None else 0, out.ptr, out.cs, out.cp, a.nvox, _stream())
 
 
 def channel_sum(x: CL, c: int) -> torch.Tensor:
@@ -549,8 +648,7 @@ def channel_sum(x: CL, c: int) -> torch.Tensor:
     nb = lib.ctu_channel_sum_num_blocks(x.nvox)
     part = torch.empty(nb * x.cp, dtype=torch.float32, device=x.buf.device)
     out = torch.empty(c, dtype=torch.float32, device=x.buf.device)
-    _lib.check(lib.ctu_channel_sum(x.ptr, x.cs, x.cp, x.nvox, part.data_ptr(), out.data_ptr(), c, _stream()),
-               "channel_sum")
+    _dual(x.lp, "channel_sum", x.ptr, x.cs, x.cp, x.nvox, part.data_ptr(), out.data_ptr(), c, _stream())
     return out
 
 
@@ -737,3 +835,17 @@ def stitch_patches(patches: torch.Tensor, coords: torch.Tensor, shape: Tuple[int
     _lib.check(_lib.load().ctu_stitch_patches(patches.data_ptr(), coords.data_ptr(), p, c, shape[0], shape[1], shape[2], pd, ph,
                                               pw, out.data_ptr(), _stream()), "stitch_patches")
     return out
+
+
+def scale_tensors(tensors, s: float) -> None:
+    """Every float32 CUDA tensor of the list scaled in place by s, one launch (un-scaling of loss-scaled gradients)."""
+    import ctypes as C
+    ts = [t for t in tensors if t is not None]
+    if not ts:
+        return
+    for t in ts:
+        _need_cuda(t, "tensor")
+        assert t.is_contiguous() and t.dtype == torch.float32
+    pa = (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    sa = (C.c_int64 * len(ts))(*[t.numel() for t in ts])
+    _lib.check(_lib.load().ctu_scale_tensors(pa, sa, len(ts), float(s), _stream()), "scale_tensors")

@@ -7,9 +7,10 @@ its own patch; the only exchange is the mean of the parameter gradients before t
 
 Design for MI355X (8 GPUs, point-to-point xGMI, 7 links x ~153 GB/s): the payload is tiny
 (3.3 MB for UNet(), 27 MB for recAE_v2_fixed) so the collective is latency-bound; gradients are
-flattened into a few large buckets in the order backward produces them (head -> decoder ->
-encoder) and each bucket's ``all_reduce`` is issued on a side stream as soon as its last weight
-gradient kernel has been enqueued, overlapping the remaining backward convolutions.
+flattened into a few buckets in the order backward produces them (head -> decoder ->
+encoder) and each bucket's all-reduce (RCCL through the C ABI, ``ctu_comm_allreduce_f32``) is issued on a
+side stream as soon as its last weight gradient kernel has been enqueued, overlapping the remaining
+backward convolutions.
 Parameters the graph never touches (the dead centre block of the generic UNet, models.py:241) never
 enter a bucket on any rank; their ``.grad`` stays ``None`` as in the reference.
 BatchNorm statistics stay per-rank (no SyncBN), matching batch-1-per-GPU reference semantics.
@@ -24,10 +25,77 @@ import torch
 import torch.distributed as dist
 
 
-class GradSync:
-    """Bucketed, overlapped mean-all-reduce of gradients produced block by block."""
+DEFAULT_BUCKET_BYTES = 512 << 10
 
-    def __init__(self, process_group=None, bucket_bytes: int = 8 << 20):
+
+class Communicator:
+    """One RCCL communicator per rank behind the C ABI (``ctu_comm_*``, include/ctunet_hip.h): ``ncclCommInitRank`` on
+    this process's current GPU, ``ncclAllReduce(avg)`` on a caller-chosen stream.  ``torch.distributed`` is only the side
+    channel that hands rank 0's unique id to the other ranks."""
+
+    def __init__(self, process_group=None):
+        import ctypes as C
+        from . import _lib
+        self._lib = _lib
+        lib = _lib.load()
+        if not lib.ctu_comm_available():
+            raise RuntimeError("ctunet_amd.parallel: librccl could not be bound (ctu_comm_available() == 0)")
+        self.world = dist.get_world_size(process_group)
+        self.rank = dist.get_rank(process_group)
+        buf = (C.c_char * 128)()
+        if self.rank == 0:
+            _lib.check(lib.ctu_comm_unique_id(buf), "comm_unique_id")
+        box = [bytes(buf)]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0,
+                                   group=process_group)
+        ident = (C.c_char * 128).from_buffer_copy(box[0])
+        handle = C.c_void_p()
+        _lib.check(lib.ctu_comm_init(C.byref(handle), self.world, self.rank, ident), "comm_init")
+        self._handle = handle
+
+    def allreduce_(self, t: torch.Tensor, average: bool = True, stream=None) -> None:
+        """In place over ranks; enqueued on ``stream`` (default: torch's current stream), no synchronisation."""
+        if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+            raise RuntimeError("ctunet_amd.parallel.Communicator: contiguous float32 GPU tensors only")
+        st = (stream or torch.cuda.current_stream(t.device)).cuda_stream
+        self._lib.check(self._lib.load().ctu_comm_allreduce_f32(self._handle, t.data_ptr(), t.data_ptr(), t.numel(),
+                                                                int(average), st), "comm_allreduce_f32")
+
+    def close(self) -> None:
+        if self._handle is not None and self._handle.value:
+            self._lib.check(self._lib.load().ctu_comm_destroy(self._handle), "comm_destroy")
+        self._handle = None
+
+
+_COMMS: Dict[object, Communicator] = {}
+
+
+def get_communicator(process_group=None) -> Communicator:
+    """The (cached) RCCL communicator of this rank for ``process_group``; collective on first use."""
+    c = _COMMS.get(process_group)
+    if c is None:
+        c = _COMMS[process_group] = Communicator(process_group)
+    return c
+
+
+def close_communicators() -> None:
+    for c in _COMMS.values():
+        c.close()
+    _COMMS.clear()
+
+
+class GradSync:
+    """Bucketed mean-all-reduce of gradients produced block by block, overlapped with the rest of backward.
+
+    The engine pushes each block's weight gradients as soon as their kernels are enqueued (head, decoder top -> bottom,
+    centre, encoder bottom -> top); whenever ``bucket_bytes`` are pending the bucket is flattened and its all-reduce is
+    launched on a side stream behind an event, so it runs under the backward kernels of the blocks that follow.  With the
+    default 512 KiB, UNet()'s 3.3 MB of live gradients leave in four buckets (head + top three decoder blocks / deepest
+    decoder block / deepest encoder block / the rest at ``finish``): everything but the last, 0.2 MB bucket overlaps the
+    128^3 / 64^3 encoder backward.  GPU tensors go through the C ABI's RCCL communicator (``ctu_comm_allreduce_f32``,
+    ncclAvg); CPU tensors (the gloo tests of this logic) through ``torch.distributed``."""
+
+    def __init__(self, process_group=None, bucket_bytes: int = DEFAULT_BUCKET_BYTES):
         self.group = process_group
         self.bucket_bytes = int(bucket_bytes)
         self._pending: List[Tuple[str, torch.Tensor]] = []
@@ -35,6 +103,7 @@ class GradSync:
         self._inflight: List[Tuple[torch.Tensor, List[Tuple[str, torch.Tensor, int]], object]] = []
         self._comm_stream: Optional[torch.cuda.Stream] = None
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.launched_before_finish = 0          # buckets whose collective was issued from push() (overlap evidence)
 
     # -- called by the engine as soon as a block's gradients have been enqueued
     def push(self, named_grads: Sequence[Tuple[str, torch.Tensor]]) -> None:
@@ -45,30 +114,30 @@ class GradSync:
             self._pending_bytes += g.numel() * g.element_size()
         if self._pending_bytes >= self.bucket_bytes:
             self._launch()
+            self.launched_before_finish += 1
 
     def _launch(self) -> None:
         if not self._pending:
             return
         items = self._pending
         self._pending, self._pending_bytes = [], 0
-        total = sum(g.numel() for _, g in items)
         ref = items[0][1]
-        flat = torch.empty(total, dtype=ref.dtype, device=ref.device)
+        flat = torch.cat([g.reshape(-1) for _, g in items])       # one flattening launch per bucket
         layout, off = [], 0
         for name, g in items:
-            n = g.numel()
-            flat[off:off + n].copy_(g.reshape(-1))
             layout.append((name, g, off))
-            off += n
+            off += g.numel()
         if flat.is_cuda:
             if self._comm_stream is None:
                 self._comm_stream = torch.cuda.Stream(device=flat.device)
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(flat.device))
-            with torch.cuda.stream(self._comm_stream):
-                self._comm_stream.wait_event(ev)
-                work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._comm_stream.wait_event(ev)
+            get_communicator(self.group).allreduce_(flat, average=True, stream=self._comm_stream)
+            done = torch.cuda.Event()
+            done.record(self._comm_stream)
             flat.record_stream(self._comm_stream)
+            work = done
         else:
             work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._inflight.append((flat, layout, work))
@@ -81,15 +150,18 @@ class GradSync:
         out: Dict[str, torch.Tensor] = {}
         inv = 1.0 / self.world
         for flat, layout, work in self._inflight:
-            work.wait()                      # on CUDA: makes the current stream wait for the collective
-            flat.mul_(inv)
+            if flat.is_cuda:
+                torch.cuda.current_stream(flat.device).wait_event(work)      # ncclAvg: already the mean
+            else:
+                work.wait()
+                flat.mul_(inv)
             for name, g, off in layout:
                 out[name] = flat[off:off + g.numel()].view_as(g)
         self._inflight = []
         return out
 
 
-def distribute(module: torch.nn.Module, process_group=None, bucket_bytes: int = 8 << 20,
+def distribute(module: torch.nn.Module, process_group=None, bucket_bytes: int = DEFAULT_BUCKET_BYTES,
                broadcast: bool = True) -> torch.nn.Module:
     """Make ``module`` (a ctunet_amd model) data-parallel across the ranks of ``process_group``.
 
@@ -123,7 +195,7 @@ def make_sync(module) -> Optional[GradSync]:
 
 
 def allreduce_mean_(tensors: Sequence[Optional[torch.Tensor]], process_group=None,
-                    bucket_bytes: int = 8 << 20) -> None:
+                    bucket_bytes: int = DEFAULT_BUCKET_BYTES) -> None:
     """In-place mean over ranks of a list of tensors (``None`` entries are skipped on every rank).
     Stand-alone form of the bucket logic, for optimizers/gradients produced outside the engine."""
     sync = GradSync(process_group, bucket_bytes)

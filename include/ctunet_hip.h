@@ -40,6 +40,13 @@ extern "C" {
 #define CTU_EINVAL (-1)   /* bad argument / unsupported shape */
 #define CTU_ELAUNCH (-2)  /* HIP launch or runtime error       */
 
+/* storage types of activation tensors: the fp32 entry points take float*; the ctu_lp_* (reduced precision) ones take a
+ * dtype code and void* tensors of 16-bit elements (arithmetic stays fp32: MFMA accumulators, BatchNorm statistics,
+ * weight gradients, master weights) */
+#define CTU_F32 0
+#define CTU_BF16 1
+#define CTU_F16 2
+
 const char* ctu_last_error(void);
 /* Library/ABI version (bumped on any signature change). */
 int ctu_abi_version(void);
@@ -362,6 +369,104 @@ int ctu_extract_patches(const float* vol, const int32_t* coords, int P, int C, i
                         int pw, float* out, void* stream);
 int ctu_stitch_patches(const float* patches, const int32_t* coords, int P, int C, int D, int H, int W, int pd, int ph,
                        int pw, float* out, void* stream);
+
+/* ------------------------------------------------ reduced precision (bf16 / fp16 activations) ---- */
+/* BASELINE configs 4 ("bf16, 192^3 patches") and 5 ("fp16 MFMA conv path, 256^3 patches").  Same operations, call sites
+ * and argument meaning as the fp32 entry points above, with
+ *   dtype ............ CTU_BF16 | CTU_F16: element type of every ACTIVATION / activation-gradient tensor (void*), still
+ *                      channels-last with channel counts padded to 8 and channel strides in ELEMENTS (multiples of 8)
+ *   arithmetic ....... fp32: MFMA accumulators (v_mfma_f32_16x16x32_{bf16,f16}), lazy BatchNorm transform, statistics
+ *                      (taken from the ROUNDED outputs), weight / bias / BatchNorm gradients, master weights
+ *   packed weights ... 16-bit copies in MFMA fragment order, re-packed from the fp32 masters (ctu_lp_pack_*)
+ * fp16 gradients need the caller's loss scaling (the per-voxel loss gradient of a 256^3 patch is 6e-8); bf16 does not. */
+size_t ctu_lp_conv3d_packed_elems(int k, int rin_p, int nout_p);
+int ctu_lp_conv3d_num_blocks(int N, int D, int H, int W, int k);
+int ctu_lp_pack_conv3d_weight(int dtype, const float* w, void* wp, int Co, int Ci, int k, const int32_t* cinv,
+                              int rin_p, int nout_p, int mode, void* stream);
+/* nn.Conv3d forward (mode-0 packing) / data gradient (mode-1 packing); stats: [ctu_lp_conv3d_num_blocks()][2][nout_p] */
+int ctu_lp_conv3d_fwd(int dtype, const void* in, int in_cs, int rin_p, const float* in_scale, const float* in_shift,
+                      int in_relu, const void* wp, const float* bias, int nbias, void* out, int out_cs, int nout_p,
+                      float* stats, int N, int D, int H, int W, int k, void* stream);
+/* weight gradient -> dw fp32 [Co,Ci,k,k,k] (torch layout); ws: ctu_lp_conv3d_wgrad_ws_floats() floats */
+size_t ctu_lp_conv3d_wgrad_ws_floats(int N, int D, int H, int W, int k, int cin_p, int cout_p);
+int ctu_lp_conv3d_wgrad(int dtype, const void* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
+                        int in_relu, const void* gout, int g_cs, int cout_p, float* dw, int Co, int Ci,
+                        const int32_t* cinv, float* ws, int N, int D, int H, int W, int k, void* stream);
+
+/* first encoder convolution (C_in <= 2): the input x and dx stay fp32 NCDHW, the 8-channel side tensor is 16-bit */
+int ctu_lp_conv3d_first_fwd(int dtype, const float* x, int cin, const float* w, const float* bias, int nbias, void* out,
+                            int out_cs, int Co, float* stats, int N, int D, int H, int W, void* stream);
+int ctu_lp_conv3d_first_bwd_data(int dtype, const void* g, int g_cs, const float* w, int cin, int Co, float* dx, int N,
+                                 int D, int H, int W, void* stream);
+int ctu_lp_conv3d_first_wgrad(int dtype, const float* x, int cin, const void* g, int g_cs, float* dw, int Co, float* ws,
+                              int N, int D, int H, int W, void* stream);
+/* ConvTranspose3d(C, C, 2, 2) + bias; packing mode 0 forward / 1 data gradient (different sizes: packed_elems(mode)) */
+size_t ctu_lp_convt_packed_elems(int rin_p, int nout_p, int mode);
+int ctu_lp_pack_convt_weight(int dtype, const float* w, void* wp, int Ci, int Co, const int32_t* cinv, int rin_p,
+                             int nout_p, int mode, void* stream);
+int ctu_lp_convt2_fwd(int dtype, const void* in, int in_cs, int rin_p, const float* in_scale, const float* in_shift,
+                      int in_relu, const void* wp, const float* bias, int nbias, void* out, int out_cs, int nout_p,
+                      int N, int D, int H, int W, void* stream);
+int ctu_lp_convt2_bwd_data(int dtype, const void* gout, int g_cs, int rout_p, const void* wp, void* gin, int gin_cs,
+                           int nin_p, int N, int D, int H, int W, void* stream);
+size_t ctu_lp_convt2_wgrad_ws_floats(int N, int D, int H, int W, int cin_p, int cout_p);
+/* dw only (fp32 [Ci,Co,2,2,2]); the bias gradient is ctu_lp_channel_sum of gout */
+int ctu_lp_convt2_wgrad(int dtype, const void* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
+                        int in_relu, const void* gout, int g_cs, int cout_p, float* dw, int Ci, int Co,
+                        const int32_t* imap, float* ws, int N, int D, int H, int W, void* stream);
+/* HBM-bound glue: same kernels as the fp32 entry points, instantiated for 16-bit storage */
+int ctu_lp_ncdhw_to_ndhwc(int dtype, const float* src, void* dst, int N, int C, int D, int H, int W, int cp, int cs,
+                          void* stream);
+int ctu_lp_ndhwc_to_ncdhw(int dtype, const void* src, float* dst, int N, int C, int D, int H, int W, int cs,
+                          void* stream);
+int ctu_lp_bn_relu_bwd_reduce(int dtype, const void* y, int y_cs, const void* ga, int g_cs, int cp, const float* scale,
+                              const float* shift, const float* mean, const float* invstd, int64_t nvox,
+                              float* partials, void* stream);
+int ctu_lp_bn_relu_bwd_apply(int dtype, const void* y, int y_cs, void* ga, int g_cs, int cp, const float* scale,
+                             const float* shift, const float* mean, const float* invstd, const float* coef,
+                             int64_t nvox, void* stream);
+int ctu_lp_maxpool2_fwd(int dtype, const void* in, int in_cs, int cp, const float* in_scale, const float* in_shift,
+                        int in_relu, void* out, int out_cs, int N, int D, int H, int W, void* stream);
+int ctu_lp_maxpool2_bwd(int dtype, const void* in, int in_cs, int cp, const float* in_scale, const float* in_shift,
+                        int in_relu, const void* gout, int gout_cs, void* gin, int gin_cs, int accumulate,
+                        int N, int D, int H, int W, void* stream);
+int ctu_lp_maxpool2_bwd_bn(int dtype, const void* in, int in_cs, int cp, const float* in_scale, const float* in_shift,
+                           const float* mean, const float* invstd, const void* gout, int gout_cs, void* gin,
+                           int gin_cs, int accumulate, int N, int D, int H, int W, float* partials, void* stream);
+int ctu_lp_skip_add(int dtype, const void* a, int a_cs, const float* a_scale, const float* a_shift, int a_relu,
+                    const void* b, int b_cs, const float* b_scale, const float* b_shift, int b_relu,
+                    void* out, int out_cs, int cp, int64_t nvox, void* stream);
+int ctu_lp_channel_sum(int dtype, const void* x, int cs, int cp, int64_t nvox, float* partials, float* out, int C,
+                       void* stream);
+/* head: 16-bit input / input gradient, fp32 NCDHW outputs and output gradients (the loss stays fp32) */
+int ctu_lp_head_fwd(int dtype, const void* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
+                    int in_relu, const float* w, const float* bias, const int32_t* imap, int Ci, int Co, int act,
+                    int head_mode, float* out0, float* out1, int N, int64_t nvox_per_item, void* stream);
+int ctu_lp_head_bwd_bn(int dtype, const void* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
+                       int in_relu, const float* w, const float* bias, const int32_t* imap, int Ci, int Co, int act,
+                       int head_mode, const float* g0, const float* g1, void* gin, int gin_cs, float* dw,
+                       float* db, float* ws, int N, int64_t nvox_per_item, const float* bn_mean,
+                       const float* bn_invstd, int bn_cp, float* bn_partials, void* stream);
+/* Every tensor of a list scaled in place by s (one launch): un-scaling of loss-scaled fp16 gradients.
+ * ptrs: HOST array of n DEVICE float pointers, sizes: HOST int64[n]. */
+int ctu_scale_tensors(void* const* ptrs, const int64_t* sizes, int n, float s, void* stream);
+
+/* --------------------------------------------------------------- gradient exchange (RCCL over xGMI) ---- */
+/* One process per GPU; the only cross-GPU step of the path is the mean of the parameter gradients before the optimizer
+ * step.  Replaces nn.DataParallel's replicate / scatter / gather / reduce-add (ctunet/pytorch/Model.py:481-487).
+ *   ctu_comm_available ... 1 if librccl could be bound (it is dlopen'ed by soname on first use; no link-time dependency)
+ *   ctu_comm_unique_id ... HOST buffer of CTU_COMM_ID_BYTES, filled on ONE rank and handed to the others by the caller
+ *                          (any side channel: a torch.distributed store / broadcast, MPI, a file)
+ *   ctu_comm_init ........ collective over all ranks (ncclCommInitRank) on the calling thread's current HIP device
+ *   ctu_comm_allreduce_f32 ncclAllReduce(sum | avg) of `count` floats on the caller's stream; send == recv allowed;
+ *                          returns without synchronising.  Not capturable: launch it between graph segments.
+ *   ctu_comm_destroy ..... ncclCommDestroy */
+#define CTU_COMM_ID_BYTES 128
+int ctu_comm_available(void);
+int ctu_comm_unique_id(void* id_host);
+int ctu_comm_init(void** comm, int world, int rank, const void* id_host);
+int ctu_comm_allreduce_f32(void* comm, const float* send, float* recv, size_t count, int average, void* stream);
+int ctu_comm_destroy(void* comm);
 
 /* Per-channel sum over voxels of a channels-last tensor: out[c] = sum_v x[v,c] (bias grads). */
 int ctu_channel_sum_num_blocks(int64_t nvox);

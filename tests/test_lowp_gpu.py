@@ -1,0 +1,362 @@
+"""Reduced-precision path (BASELINE configs 4 / 5: bf16 and fp16 activations, fp32 accumulate) through the C ABI's ctu_lp_*
+entry points.
+
+Per-op tests isolate the kernels from the precision question: inputs and weights are rounded to the 16-bit type FIRST, the
+reference is torch's fp32 (fp64 for the long K = voxel reductions) op on those rounded values, so the only differences left
+are fp32 summation order and the final rounding of the stored result (half an ulp of the 16-bit type: 2^-9 relative for
+bf16, 2^-12 for fp16).  Whole-net tests then measure what the 16-bit storage costs against the fp32 oracle: the reference's
+own bf16 / fp16 autocast run deviates 4e-3 / 5e-4 from its fp32 run, which is the yardstick here."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import unet_oracle as O
+from util import CLASS_INPUT, gen, onehot_target, rel_err
+
+pytestmark = pytest.mark.gpu
+
+DT = {"bf16": torch.bfloat16, "fp16": torch.float16}
+ULP = {"bf16": 2.0 ** -8, "fp16": 2.0 ** -11}        # one unit in the last place, relative
+
+
+def _ops():
+    from ctunet_amd import ops
+    return ops
+
+
+def to_cl(x, cp, dtype, cs=None, c0=0):
+    """NCDHW fp32 (CPU) -> CL on the GPU with cp padded channels inside a cs-wide buffer at offset c0 (garbage around)."""
+    ops = _ops()
+    n, c, d, h, w = x.shape
+    cs = cs or cp
+    buf = torch.full((n, d, h, w, cs), 7.0, dtype=dtype).cuda()
+    v = torch.zeros((n, d, h, w, cp), dtype=torch.float32)
+    v[..., :c] = x.permute(0, 2, 3, 4, 1)
+    buf[..., c0:c0 + cp] = v.to(dtype).cuda()
+    return ops.CL(buf, c0, cp)
+
+
+def from_cl(a, c):
+    return a.buf[..., a.c0:a.c0 + c].float().permute(0, 4, 1, 2, 3).contiguous().cpu()
+
+
+def rnd(x, dtype):
+    return x.to(dtype).float()
+
+
+CONV_CASES = [  # (k, ci, co, shape NDHW, transform)
+    (3, 8, 8, (1, 8, 8, 16), True), (3, 16, 16, (2, 5, 9, 17), True), (3, 32, 8, (1, 4, 8, 32), False),
+    (3, 7, 14, (1, 8, 8, 8), True), (3, 56, 28, (1, 6, 8, 8), True), (3, 128, 32, (1, 4, 4, 8), False),
+    (3, 40, 64, (1, 4, 8, 16), True), (5, 8, 16, (1, 6, 7, 16), True), (5, 64, 16, (1, 4, 4, 8), False),
+]
+
+
+@pytest.mark.parametrize("name", ["bf16", "fp16"])
+@pytest.mark.parametrize("k,ci,co,shape,xf", CONV_CASES)
+def test_lp_conv_forward_stats_dgrad_wgrad(name, k, ci, co, shape, xf):
+    ops = _ops()
+    dt = DT[name]
+    g = gen(hash((k, ci, co, shape)) % 1000)
+    n, d, h, w = shape
+    cip, cop = ops.pad8(ci), ops.pad8(co)
+    x = rnd(torch.randn(n, ci, d, h, w, generator=g), dt)
+    wt = rnd(torch.randn(co, ci, k, k, k, generator=g) * (2.0 / (ci * k ** 3)) ** 0.5, dt)
+    bias = torch.randn(co, generator=g) if k == 5 else None
+    sc = torch.rand(cip, generator=g) + 0.5
+    sh = torch.randn(cip, generator=g) * 0.3
+    sc[ci:] = 0
+    sh[ci:] = 0
+    xcl = to_cl(x, cip, dt, cs=cip + 8, c0=8 if cip % 16 == 8 else 0) if ci != 7 else to_cl(x, cip, dt)
+    if xf:
+        xcl = xcl.with_xf(sc.cuda(), sh.cuda(), True)
+        a = rnd(F.relu(x * sc[:ci].view(1, -1, 1, 1, 1) + sh[:ci].view(1, -1, 1, 1, 1)), dt)     # what the kernel stages
+    else:
+        a = x
+    # ---- forward + BatchNorm partial sums
+    wp = ops.pack_conv_w_lp(wt.cuda(), None, cip, cop, 0, dt)
+    out = ops.CL(torch.full((n, d, h, w, cop + 8), 3.0, dtype=dt).cuda(), 8, cop)
+    nblk = ops.conv_num_blocks(shape, cop, 0, k, dt)
+    stats = torch.zeros((nblk, 2, cop), dtype=torch.float32).cuda()
+    ops.conv3d_fwd(xcl, wp, None if bias is None else bias.cuda(), out, k, stats)
+    ref = F.conv3d(a.double(), wt.double(), None if bias is None else bias.double(), 1, (k - 1) // 2).float()
+    got = from_cl(out, co)
+    tol = ULP[name] * ref.abs().max().item()
+    assert (got - ref).abs().max().item() <= tol
+    assert torch.equal(out.buf[..., :8].float().cpu(), torch.full((n, d, h, w, 8), 3.0))            # the slice's neighbours are untouched
+    full = from_cl(out, cop)
+    assert float(full[:, co:].abs().max()) == 0.0 if cop > co else True                               # padded channels hold zeros
+    s = stats.sum(0).cpu()
+    assert torch.allclose(s[0, :co], got.sum((0, 2, 3, 4)), rtol=1e-4, atol=1e-2)                     # sums of the ROUNDED outputs
+    assert torch.allclose(s[1, :co], (got * got).sum((0, 2, 3, 4)), rtol=1e-4, atol=1e-2)
+    assert float(s[:, co:].abs().max()) == 0.0 if cop > co else True
+    # ---- data gradient (mode-1 packing, no transform on the gradient)
+    go = rnd(torch.randn(n, co, d, h, w, generator=g), dt)
+    gcl = to_cl(go, cop, dt)
+    wpd = ops.pack_conv_w_lp(wt.cuda(), None, cop, cip, 1, dt)
+    gin = ops.CL(torch.zeros((n, d, h, w, cip), dtype=dt).cuda(), 0, cip)
+    ops.conv3d_fwd(gcl, wpd, None, gin, k)
+    ref_dx = torch.nn.grad.conv3d_input(a.shape, wt.double(), go.double(), 1, (k - 1) // 2).float()
+    assert (from_cl(gin, ci) - ref_dx).abs().max().item() <= ULP[name] * ref_dx.abs().max().item()
+    # ---- weight gradient (fp32 output; K = voxels)
+    ws = torch.empty(ops.conv3d_wgrad_ws(shape, k, cip, cop, dt), dtype=torch.float32).cuda()
+    dw, db = ops.conv3d_wgrad(xcl, gcl, co, ci, k, None, ws, bias is not None)
+    ref_dw = torch.nn.grad.conv3d_weight(a.double(), wt.shape, go.double(), 1, (k - 1) // 2).float()
+    assert rel_err(dw, ref_dw) < 2e-5
+    if bias is not None:
+        assert rel_err(db, go.sum((0, 2, 3, 4))) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["bf16", "fp16"])
+def test_lp_conv_channel_maps_of_the_concat_layout(name):
+    """The decoder convs read [C real | pad | C real | pad] concat buffers: cinv maps padded positions to logical
+    channels (forward packing) and the weight gradient scatters back through it."""
+    ops = _ops()
+    dt = DT[name]
+    g = gen(5)
+    c, co, shape = 7, 14, (1, 4, 8, 16)
+    x = rnd(torch.randn(1, 2 * c, *shape[1:], generator=g), dt)
+    wt = rnd(torch.randn(co, 2 * c, 3, 3, 3, generator=g) * 0.1, dt)
+    xp = torch.zeros(1, 16, *shape[1:])
+    xp[:, 0:c] = x[:, :c]
+    xp[:, 8:8 + c] = x[:, c:]
+    cinv = torch.full((16,), -1, dtype=torch.int32)
+    cinv[0:c] = torch.arange(c, dtype=torch.int32)
+    cinv[8:8 + c] = torch.arange(c, 2 * c, dtype=torch.int32)
+    xcl = to_cl(xp, 16, dt)
+    wp = ops.pack_conv_w_lp(wt.cuda(), cinv.cuda(), 16, 16, 0, dt)
+    out = ops.CL(torch.zeros((1,) + shape[1:] + (16,), dtype=dt).cuda(), 0, 16)
+    ops.conv3d_fwd(xcl, wp, None, out, 3)
+    ref = F.conv3d(x.double(), wt.double(), None, 1, 1).float()
+    assert (from_cl(out, co) - ref).abs().max().item() <= ULP[name] * ref.abs().max().item()
+    go = rnd(torch.randn(1, co, *shape[1:], generator=g), dt)
+    gcl = to_cl(go, 16, dt)
+    ws = torch.empty(ops.conv3d_wgrad_ws(shape, 3, 16, 16, dt), dtype=torch.float32).cuda()
+    dw, _ = ops.conv3d_wgrad(xcl, gcl, co, 2 * c, 3, cinv.cuda(), ws, False)
+    assert rel_err(dw, torch.nn.grad.conv3d_weight(x.double(), wt.shape, go.double(), 1, 1).float()) < 2e-5
+    wpd = ops.pack_conv_w_lp(wt.cuda(), cinv.cuda(), 16, 16, 1, dt)
+    gin = ops.CL(torch.zeros((1,) + shape[1:] + (16,), dtype=dt).cuda(), 0, 16)
+    ops.conv3d_fwd(gcl, wpd, None, gin, 3)
+    ref_dx = torch.nn.grad.conv3d_input(x.shape, wt.double(), go.double(), 1, 1).float()
+    got = gin.buf.float().cpu()[0].permute(3, 0, 1, 2)
+    assert (torch.cat((got[0:c], got[8:8 + c]))[None] - ref_dx).abs().max().item() <= ULP[name] * ref_dx.abs().max().item()
+    assert float(got[c:8].abs().max()) == 0.0 and float(got[8 + c:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("name", ["bf16", "fp16"])
+@pytest.mark.parametrize("c,shape,xf", [(32, (1, 8, 8, 16), True), (8, (2, 3, 5, 8), False), (56, (1, 4, 4, 8), True),
+                                        (128, (1, 2, 4, 8), False), (7, (1, 4, 8, 8), True)])
+def test_lp_conv_transpose_forward_dgrad_wgrad(name, c, shape, xf):
+    ops = _ops()
+    dt = DT[name]
+    g = gen(c)
+    n, d, h, w = shape
+    cp = ops.pad8(c)
+    x = rnd(torch.randn(n, c, d, h, w, generator=g), dt)
+    wt = rnd(torch.randn(c, c, 2, 2, 2, generator=g) * (1.0 / c) ** 0.5, dt)
+    b = torch.randn(c, generator=g)
+    sc, sh = torch.rand(cp, generator=g) + 0.5, torch.randn(cp, generator=g) * 0.3
+    sc[c:] = 0
+    sh[c:] = 0
+    xcl = to_cl(x, cp, dt)
+    a = x
+    if xf:
+        xcl = xcl.with_xf(sc.cuda(), sh.cuda(), True)
+        a = rnd(F.relu(x * sc[:c].view(1, -1, 1, 1, 1) + sh[:c].view(1, -1, 1, 1, 1)), dt)
+    wp = ops.pack_convt_w_lp(wt.cuda(), None, cp, cp, 0, dt)
+    out = ops.CL(torch.zeros((n, 2 * d, 2 * h, 2 * w, cp), dtype=dt).cuda(), 0, cp)
+    ops.convt_fwd(xcl, wp, b.cuda(), out)
+    ref = F.conv_transpose3d(a.double(), wt.double(), b.double(), stride=2).float()
+    assert (from_cl(out, c) - ref).abs().max().item() <= ULP[name] * ref.abs().max().item()
+    go = rnd(torch.randn(n, c, 2 * d, 2 * h, 2 * w, generator=g), dt)
+    gcl = to_cl(go, cp, dt)
+    wpd = ops.pack_convt_w_lp(wt.cuda(), None, cp, cp, 1, dt)
+    gin = ops.CL(torch.zeros((n, d, h, w, cp), dtype=dt).cuda(), 0, cp)
+    ops.convt_bwd_data(gcl, wpd, gin)
+    ref_dx = F.conv3d(go.double(), wt.double(), None, 2).float()          # adjoint of the stride-2 transposed conv
+    assert (from_cl(gin, c) - ref_dx).abs().max().item() <= ULP[name] * ref_dx.abs().max().item()
+    ws = torch.empty(ops.convt_wgrad_ws(shape, cp, cp, dt), dtype=torch.float32).cuda()
+    dw, db = ops.convt_wgrad(xcl, gcl, c, c, None, ws)
+    aa = a.double().requires_grad_(False)
+    wv = wt.double().clone().requires_grad_(True)
+    (F.conv_transpose3d(aa, wv, None, stride=2) * go.double()).sum().backward()
+    assert rel_err(dw, wv.grad.float()) < 2e-5
+    assert rel_err(db, go.sum((0, 2, 3, 4))) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["bf16", "fp16"])
+def test_lp_glue_kernels_match_fp32_kernels_on_rounded_data(name):
+    """max-pool forward / backward (+ BatchNorm rows), BatchNorm backward reduce / apply, skip add, channel sum, layout:
+    the 16-bit instantiations against the fp32 instantiations of the SAME kernels on the same (rounded) values."""
+    ops = _ops()
+    dt = DT[name]
+    g = gen(3)
+    n, c, d, h, w = 2, 16, 4, 8, 8
+    y = rnd(torch.randn(n, c, d, h, w, generator=g), dt)
+    ga = rnd(torch.randn(n, c, d, h, w, generator=g), dt)
+    vec = torch.stack([torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.2, torch.randn(c, generator=g) * 0.1,
+                       torch.rand(c, generator=g) + 0.5]).cuda()
+
+    def run(dtype):
+        ycl = to_cl(y, c, dtype).with_xf(vec[0], vec[1], True)
+        pooled = ops.CL(torch.zeros((n, d // 2, h // 2, w // 2, c), dtype=dtype).cuda(), 0, c)
+        ops.maxpool_fwd(ycl, pooled)
+        gp = to_cl(rnd(torch.randn(n, c, d // 2, h // 2, w // 2, generator=gen(4)), dt), c, dtype)
+        gin = to_cl(ga, c, dtype)
+        part = torch.zeros(ops.maxpool_bwd_bn_blocks((n, d, h, w), c) * 2 * c + ops.bn_bwd_partials_floats(n * d * h * w, c)).cuda()
+        nb = ops.maxpool_bwd(ycl, gp, gin, True, (vec, part))
+        rows = part[:nb * 2 * c].view(nb, 2, c).sum(0).cpu()
+        g2 = to_cl(ga, c, dtype)
+        dgam, dbet = ops.bn_relu_bwd(ycl.raw(), g2, vec, torch.ones(c).cuda(), c, part)
+        added = ops.CL(torch.zeros((n, d, h, w, c), dtype=dtype).cuda(), 0, c)
+        ops.skip_add(ycl, to_cl(ga, c, dtype), added)
+        return (from_cl(pooled, c), from_cl(gin, c), rows, from_cl(g2, c), dgam.cpu(), dbet.cpu(), from_cl(added, c),
+                ops.channel_sum(to_cl(ga, c, dtype), c).cpu(), from_cl(ops.ncdhw_to_cl(y.cuda(), dtype=dtype), c),
+                ops.cl_to_ncdhw(to_cl(y, c, dtype), c).cpu())
+    lo, hi = run(dt), run(torch.float32)
+    u = ULP[name]
+    assert torch.equal(lo[0], rnd(hi[0], dt))                                  # pooled activations: rounded fp32 result
+    assert (lo[1] - hi[1]).abs().max().item() <= u * hi[1].abs().max().item()   # routed gradient (+ accumulate)
+    assert torch.allclose(lo[2], hi[2], rtol=5e-2, atol=5e-2 * hi[2].abs().max().item())   # rows are taken from rounded sums
+    assert (lo[3] - hi[3]).abs().max().item() <= 2 * u * hi[3].abs().max().item()
+    assert torch.allclose(lo[4], hi[4], rtol=1e-5, atol=1e-4) and torch.allclose(lo[5], hi[5], rtol=1e-5, atol=1e-4)
+    assert (lo[6] - hi[6]).abs().max().item() <= u * hi[6].abs().max().item()
+    assert torch.allclose(lo[7], hi[7], rtol=1e-6, atol=1e-5)
+    assert torch.equal(lo[8], y) and torch.equal(lo[9], y)
+
+
+@pytest.mark.parametrize("name", ["bf16", "fp16"])
+def test_lp_first_conv_and_head_against_fp32_kernels(name):
+    ops = _ops()
+    dt = DT[name]
+    g = gen(8)
+    n, d, h, w = 1, 8, 8, 32
+    x = torch.randn(n, 2, d, h, w, generator=g).cuda()
+    wt = (torch.randn(7, 2, 3, 3, 3, generator=g) * 0.2).cuda()
+
+    def first(dtype):
+        out = ops.CL(torch.zeros((n, d, h, w, 8), dtype=dtype).cuda(), 0, 8)
+        stats = torch.zeros((ops.conv_first_num_blocks((n, d, h, w)), 2, 8)).cuda()
+        ops.conv_first_fwd(x, wt, None, out, stats)
+        return out, stats.sum(0).cpu()
+    (o16, s16), (o32, s32) = first(dt), first(torch.float32)
+    assert torch.equal(from_cl(o16, 7), rnd(from_cl(o32, 7), dt))
+    assert torch.allclose(s16[0, :7], from_cl(o16, 7).sum((0, 2, 3, 4)), rtol=1e-4, atol=1e-3)
+    go = rnd(torch.randn(n, 7, d, h, w, generator=g), dt)
+    ws = torch.empty(ops.conv_first_wgrad_ws((n, d, h, w), 2)).cuda()
+    dw16, dw32 = ops.conv_first_wgrad(x, to_cl(go, 8, dt), 7, ws).cpu(), ops.conv_first_wgrad(x, to_cl(go, 8, torch.float32), 7, ws).cpu()
+    assert torch.allclose(dw16, dw32, rtol=1e-5, atol=1e-5)
+    dx16, dx32 = ops.conv_first_bwd_data(to_cl(go, 8, dt), wt, 2).cpu(), ops.conv_first_bwd_data(to_cl(go, 8, torch.float32), wt, 2).cpu()
+    assert torch.allclose(dx16, dx32, rtol=1e-5, atol=1e-5)
+    # head (SP re-encoding): 16-bit input, fp32 NCDHW outputs; backward writes a 16-bit input gradient
+    hin = rnd(torch.randn(n, 14, d, h, w, generator=g), dt)
+    hw_, hb = (torch.randn(3, 14, generator=g) * 0.3).cuda(), torch.randn(3, generator=g).cuda()
+    g0, g1 = torch.randn(n, 2, d, h, w, generator=g).cuda(), torch.randn(n, 2, d, h, w, generator=g).cuda()
+
+    def head(dtype):
+        a = to_cl(hin, 16, dtype)
+        o0, o1 = ops.head_fwd(a, hw_, hb, None, 2, 1)
+        gin = ops.CL(torch.zeros((n, d, h, w, 16), dtype=dtype).cuda(), 0, 16)
+        dw, db = ops.head_bwd(a, hw_, hb, None, 2, 1, g0, g1, gin)
+        return o0.cpu(), o1.cpu(), from_cl(gin, 14), dw.cpu(), db.cpu()
+    a16, a32 = head(dt), head(torch.float32)
+    assert torch.equal(a16[0], a32[0]) and torch.equal(a16[1], a32[1])
+    assert (a16[2] - a32[2]).abs().max().item() <= ULP[name] * a32[2].abs().max().item()
+    assert torch.allclose(a16[3], a32[3], rtol=1e-5, atol=1e-5) and torch.allclose(a16[4], a32[4], rtol=1e-5, atol=1e-5)
+
+
+# -------------------------------------------------------------------------------------------------------- whole nets
+def _lowp_vs_oracle(cls, size, name, batch=1):
+    """Train-mode step of class `cls` at size^3 in reduced precision against the fp32 ORACLE on the same weights / inputs.
+    Returns the measured deviations (the caller gates them)."""
+    import ctunet_amd
+    from ctunet_amd import ProblemHandler as PH
+    torch.manual_seed(0)
+    net = getattr(ctunet_amd, cls)()
+    net.chk = False
+    sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+    in_ch = CLASS_INPUT[cls][0]
+    x = torch.randn(batch, in_ch, size, size, size, generator=gen(1234))
+    spec = O.SPECS[cls]
+    two = spec.head != "plain"
+    tg = [onehot_target((batch, 2, size, size, size), 4321 + i, 0.2) for i in range(2 if two else 1)]
+    fn = (lambda o: O.loss_double(o, tg, 1.0, 1.0)[0]) if two else (lambda o: O.loss_single(o, tg[0], 1.0, 1.0)[0])
+    ref_out, ref_loss, ref_g, ref_dx = O.grads(spec, sd0, x, fn, training=True)
+    refs = ref_out if isinstance(ref_out, tuple) else (ref_out,)
+
+    class H:
+        verbose = False
+        params = dict(ce_lambda=1.0, dice_lambda=1.0, save_dice_plots=False, save_hd_plots=False)
+
+        def __init__(self):
+            self.losses_and_metrics, self.pt_loss = {}, None
+    net = net.cuda().train().set_precision(name)
+    xi = x.cuda().requires_grad_(True)
+    out = net(xi)
+    hh = H()
+    if two:
+        PH.FlapRecWithShapePriorDoubleOut.comp_losses_metrics(hh, out, [t.cuda() for t in tg], 0, 1)
+    else:
+        PH.ProblemHandler.comp_losses_metrics(hh, out, tg[0].cuda(), 0, 1)
+    hh.pt_loss.backward()
+    outs = out if isinstance(out, tuple) else (out,)
+    res = {"out_err": max(rel_err(o, r) for o, r in zip(outs, refs)),
+           "dice": min(float(O.hard_dice(o.detach().cpu(), F.one_hot(r.argmax(1), r.shape[1]).movedim(-1, 1).float()))
+                       for o, r in zip(outs, refs)),
+           "loss_err": abs(hh.pt_loss.item() - ref_loss.item()), "loss": ref_loss.item()}
+    cos, l2 = [], []
+    for n_, p in net.named_parameters():
+        r = ref_g[n_]
+        assert (p.grad is None) == (r is None), n_
+        if r is None or r.abs().max() == 0:
+            continue
+        a, b = p.grad.detach().cpu().double().flatten(), r.double().flatten()
+        assert torch.isfinite(a).all(), n_
+        if b.abs().max() < 1e-7:           # conv biases in front of a BatchNorm: the true gradient is zero (rounding noise)
+            continue
+        cos.append(float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-300)))
+        l2.append(float((a - b).norm() / b.norm()))
+    res["grad_cos_min"], res["grad_l2_max"] = min(cos), max(l2)
+    a, b = xi.grad.cpu().double().flatten(), ref_dx.double().flatten()
+    res["dx_cos"] = float(torch.dot(a, b) / (a.norm() * b.norm()))
+    return res
+
+
+@pytest.mark.parametrize("name", ["bf16", "fp16"])
+@pytest.mark.parametrize("cls", ["UNet", "UNetSP", "UNetSPSmall", "recAE_v2_fixed"])
+def test_lowp_nets_against_the_fp32_oracle(cls, name):
+    """Small patches, every class family: output error within a few times the reference's own autocast deviation
+    (bf16 4e-3, fp16 5e-4: SURVEY 7), loss close, gradients pointing the same way as the fp32 oracle's."""
+    r = _lowp_vs_oracle(cls, CLASS_INPUT[cls][1], name)
+    print(cls, name, r)
+    out_tol, loss_tol, cos_tol = (2e-2, 5e-3, 0.98) if name == "bf16" else (3e-3, 5e-4, 0.999)
+    assert r["out_err"] < out_tol and r["loss_err"] < loss_tol * max(1.0, r["loss"])
+    assert r["grad_cos_min"] > cos_tol and r["dx_cos"] > cos_tol, r
+
+
+def test_lowp_precision_switch_and_loss_scale():
+    import ctunet_amd
+    torch.manual_seed(0)
+    net = ctunet_amd.UNet(n_blocks=2, use_checkpoint=False).cuda().train()
+    x = torch.randn(1, 1, 32, 32, 32, generator=gen(2)).cuda()
+    y32 = net(x)
+    assert net._engine().dtype == torch.float32
+    y16 = net.set_precision("fp16")(x)
+    assert net._engine().dtype == torch.float16 and y16.dtype == torch.float32 and y16.shape == y32.shape
+    assert 0 < rel_err(y16, y32) < 3e-3
+    # gradients do not depend on the (power-of-two) loss scale, and survive the smallest one only because of it
+    from ctunet_amd import losses as L
+    t = onehot_target((1, 2, 32, 32, 32), 3, 0.3).cuda()
+    gr = []
+    for s in (None, 2.0 ** 8, 2.0 ** 14):
+        net.set_precision(torch.float16, loss_scale=s)
+        for p in net.parameters():
+            p.grad = None
+        ce, dc = L.fused_ce_dice(net(x), t, 1.0, 1.0, False)
+        (ce + dc).backward()
+        gr.append(torch.cat([p.grad.flatten() for p in net.parameters() if p.grad is not None]).clone())
+    assert rel_err(gr[1], gr[0]) < 2e-2 and rel_err(gr[2], gr[0]) < 2e-2
+    with pytest.raises(ValueError):
+        net.set_precision("int8")
+    net.set_precision("fp32")
+    assert torch.equal(net(x), y32)

@@ -178,12 +178,18 @@ def test_shipped_classes_vs_reference_checksums_and_oracle(name):
             assert float(b) == e, n_
 
 
-def oracle_train_check(name, size, batch=1, seed=1234, want_fp64=True):
+def oracle_train_check(name, size, batch=1, seed=1234, want_fp64=True, lowp=None):
     """One train-mode step of class `name` on a size^3 patch through the HIP path AND through the oracle on the same seeded
     weights / input / targets: outputs <= 1e-4 (north star: 1e-3), loss <= 1e-5, hard-segmentation Dice >= 0.999, and every
-    parameter gradient + dx under the fp64 rule (no worse than max(5x the ATen-CPU fp32 error, 2e-3 of the tensor's scale)
-    against an fp64 run of the oracle).  3-channel plain classes (UNet4b2i3o, ...) get an MSE loss against the one-hot
-    target stack, the others the reference's handler loss.  Shared with tests/test_full_size_gpu.py."""
+    parameter gradient + dx
+      want_fp64: under the fp64 rule -- against an fp64 run of the oracle, no worse than max(5x the ATen-CPU fp32 error,
+                 2e-3 of the tensor's scale);
+      else:      against the fp32 oracle in the L2 norm (<= 3e-2 of the tensor's norm; the maximum over ~1e5 entries of an
+                 ill-conditioned quantity is an extreme-value statistic, the norm is not) -- the fp64 oracle of the 192^3 /
+                 256^3 cases costs minutes of host time (fp64 convolutions do not go through oneDNN).
+    3-channel plain classes (UNet4b2i3o, ...) get an MSE loss, the others the reference's handler loss.
+    lowp = "bf16" | "fp16": the same step in reduced precision is compared with the SAME oracle run (returned dict).
+    Shared with tests/test_full_size_gpu.py."""
     A, M, L, PH = _mods()
     torch.manual_seed(0)
     net = getattr(A, name)()
@@ -211,38 +217,72 @@ def oracle_train_check(name, size, batch=1, seed=1234, want_fp64=True):
     o32, l32, g32, dx32 = run(torch.float32)
     if want_fp64:
         _, l64, g64, dx64 = run(torch.float64)
-    net = net.cuda().train()
-    xi = x.cuda().requires_grad_(True)
-    out = net(xi)
-    h = Holder(1.0, 1.0)
-    if two:
-        PH.FlapRecWithShapePriorDoubleOut.comp_losses_metrics(h, out, [t.cuda() for t in tg], 0, 1)
-        loss = h.pt_loss
-    elif handler:
-        PH.ProblemHandler.comp_losses_metrics(h, out, tg[0].cuda(), 0, 1)
-        loss = h.pt_loss
-    else:
-        loss = (out ** 2).mean()
-    loss.backward()
-    outs = out if isinstance(out, tuple) else (out,)
     refs = o32 if isinstance(o32, tuple) else (o32,)
+
+    def hip_step(precision):
+        torch.manual_seed(0)
+        m = getattr(A, name)()
+        m.chk = False
+        m.load_state_dict(sd0)
+        m = m.cuda().train().set_precision(precision)
+        xi = x.cuda().requires_grad_(True)
+        out = m(xi)
+        h = Holder(1.0, 1.0)
+        if two:
+            PH.FlapRecWithShapePriorDoubleOut.comp_losses_metrics(h, out, [t.cuda() for t in tg], 0, 1)
+            loss = h.pt_loss
+        elif handler:
+            PH.ProblemHandler.comp_losses_metrics(h, out, tg[0].cuda(), 0, 1)
+            loss = h.pt_loss
+        else:
+            loss = (out ** 2).mean()
+        loss.backward()
+        outs = out if isinstance(out, tuple) else (out,)
+        return m, [o.detach() for o in outs], loss.item(), xi.grad
+
+    def versus_fp32(m, dx):
+        """(max L2 relative error, min cosine) over dx and every live parameter gradient against the fp32 oracle."""
+        l2, cos = [], []
+        for n_, got, ref in [("dx", dx, dx32)] + [(n_, p.grad, g32[n_]) for n_, p in m.named_parameters()]:
+            assert (got is None) == (ref is None), n_
+            if ref is None or ref.abs().max() < 1e-7:      # conv biases in front of a BatchNorm: true gradient zero
+                continue
+            a, b = got.detach().cpu().double().flatten(), ref.double().flatten()
+            assert torch.isfinite(a).all(), n_
+            l2.append((float((a - b).norm() / b.norm()), n_))
+            cos.append((float(torch.dot(a, b) / (a.norm() * b.norm())), n_))
+        return max(l2), min(cos)
+
+    net, outs, loss, dx = hip_step("fp32")
     for o, r in zip(outs, refs):
         assert rel_err(o, r) < 1e-4
-        assert O.hard_dice(o.detach().cpu(), torch.nn.functional.one_hot(r.argmax(1), r.shape[1]).movedim(-1, 1).float()) >= 0.999
-    assert abs(loss.item() - l32.item()) < 1e-5
-    if not want_fp64:
-        return
-    assert abs(loss.item() - l64.item()) < 1e-5
+        assert O.hard_dice(o.cpu(), torch.nn.functional.one_hot(r.argmax(1), r.shape[1]).movedim(-1, 1).float()) >= 0.999
+    assert abs(loss - l32.item()) < 1e-5
+    worst_l2, worst_cos = versus_fp32(net, dx)
+    print(f"[{name} {size}^3 fp32] grad L2 err max {worst_l2}, cos min {worst_cos}")
+    if want_fp64:
+        assert abs(loss - l64.item()) < 1e-5
 
-    def err(a, b):
-        return (a.detach().cpu().double() - b).abs().max().item()
-    checks = [("dx", xi.grad, dx32, dx64)] + [(n_, p.grad, g32[n_], g64[n_]) for n_, p in net.named_parameters()
-                                              if g64[n_] is not None]
-    for n_, p in net.named_parameters():
-        assert (p.grad is None) == (g64[n_] is None), n_
-    for n_, got, c32, r64 in checks:
-        scale = r64.abs().max().item()
-        assert err(got, r64) <= max(5 * err(c32, r64), 2e-3 * scale) + 1e-7, (n_, err(got, r64), err(c32, r64), scale)
+        def err(a, b):
+            return (a.detach().cpu().double() - b).abs().max().item()
+        checks = [("dx", dx, dx32, dx64)] + [(n_, p.grad, g32[n_], g64[n_]) for n_, p in net.named_parameters()
+                                             if g64[n_] is not None]
+        for n_, got, c32, r64 in checks:
+            scale = r64.abs().max().item()
+            assert err(got, r64) <= max(5 * err(c32, r64), 2e-3 * scale) + 1e-7, (n_, err(got, r64), err(c32, r64), scale)
+    else:
+        assert worst_l2[0] <= 3e-2 and worst_cos[0] >= 0.999, (worst_l2, worst_cos)
+    if lowp is None:
+        return None
+    del net
+    m, outs, loss_lp, dx = hip_step(lowp)
+    l2, cos = versus_fp32(m, dx)
+    res = {"out_err": max(rel_err(o, r) for o, r in zip(outs, refs)),
+           "dice": min(float(O.hard_dice(o.cpu(), torch.nn.functional.one_hot(r.argmax(1), r.shape[1]).movedim(-1, 1).float()))
+                       for o, r in zip(outs, refs)),
+           "loss_err": abs(loss_lp - l32.item()), "loss": l32.item(), "grad_l2_max": l2, "grad_cos_min": cos}
+    print(f"[{name} {size}^3 {lowp}] {res}")
+    return res
 
 
 @pytest.mark.parametrize("name", list(CLASS_INPUT))
@@ -487,6 +527,8 @@ def test_distributed_graphed_step_one_rank_equals_eager():
         for (n_, a), (_, b) in zip(net_e.state_dict().items(), net_g.state_dict().items()):
             assert torch.allclose(a.float(), b.float(), rtol=2e-3, atol=1e-5), n_
     finally:
+        from ctunet_amd import parallel
+        parallel.close_communicators()
         dist.destroy_process_group()
 
 

@@ -38,8 +38,17 @@ def _worker(rank, world, port, tmp):
         live = [(n, t.clone()) for n, t in grads.items() if t is not None]
         for i in range(0, len(live), 3):
             sync.push(live[i:i + 3])
+        assert sync.launched_before_finish >= 3          # collectives were issued from push(), i.e. under "backward"
         red = sync.finish()
         assert set(red) == {n for n, _ in live}
+        # the default bucket size splits UNet()'s 3.3 MB into several buckets, most of them launched before finish()
+        big = ctunet_amd.UNet()
+        order = ["last_conv"] + [f"u_blocks.{j}." for j in (3, 2, 1, 0)] + [f"d_blocks.{i}." for i in (3, 2, 1, 0)]
+        s2 = parallel.GradSync(None)
+        for pre in order:
+            s2.push([(n, torch.zeros_like(p)) for n, p in big.named_parameters() if n.startswith(pre)])
+        assert s2.launched_before_finish >= 3, s2.launched_before_finish
+        assert len(s2.finish()) == 58
         for n, t in live:
             exp = torch.zeros_like(t)
             for r in range(world):
