@@ -25,8 +25,6 @@ import torch.distributed as dist
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense f32-input MFMA peak
 PEAK_HBM_GBS = 8000.0             # spec; ~6300 achievable
 
-# algorithmic work per input voxel, UNet() default, live graph, no recompute
-FLOP_PER_VOXEL_FWD_BWD = 129.6e3
 
 
 class Holder:
@@ -39,14 +37,16 @@ class Holder:
         self.pt_loss = None
 
 
-def synth_batch(size, rank, device):
-    """Synthetic CT-like patch + one-hot target: seeds 1234+rank / 4321+rank."""
+def synth_batch(size, rank, device, batch=1, in_ch=1, n_targets=1):
+    """Synthetic CT-like patch + one-hot target(s): seeds 1234+rank / 4321+rank(+i)."""
     g = torch.Generator().manual_seed(1234 + rank)
-    x = torch.randn(1, 1, size, size, size, generator=g)
-    gt = torch.Generator().manual_seed(4321 + rank)
-    m = (torch.rand(1, size, size, size, generator=gt) < 0.2).long()
-    t = torch.nn.functional.one_hot(m, 2).movedim(4, 1).float().contiguous()
-    return x.to(device), t.to(device)
+    x = torch.randn(batch, in_ch, size, size, size, generator=g)
+    ts = []
+    for i in range(n_targets):
+        gt = torch.Generator().manual_seed(4321 + rank + 1000 * i)
+        m = (torch.rand(batch, size, size, size, generator=gt) < 0.2).long()
+        ts.append(torch.nn.functional.one_hot(m, 2).movedim(4, 1).float().contiguous().to(device))
+    return x.to(device), ts
 
 
 def log(msg):
@@ -82,41 +82,81 @@ def pmc_traffic(kernel):
         return None
 
 
-def cpu_baseline(size, steps=5):
-    """The oracle (same ATen-CPU graph as the reference, no checkpoint recompute) timed on the host
-    cores: 1 warm-up + best of `steps` forward+backward steps of the same 128^3 workload."""
+def cpu_baseline(size, model="UNet", precision="fp32", mode="train", batch=1, steps=3):
+    """The oracle (same ATen-CPU graph as the reference) timed on the host cores, bounded: 1 warm-up + best of `steps`
+    steps of the same workload.  Train mode reports three points: all granted cores without checkpoint
+    recompute (`value`, the algorithmic 3x-forward work), the same with the recompute pass the reference's default
+    use_checkpoint=True adds (every block's forward runs again inside backward, models.py:232-255: emulated as one extra
+    no-grad forward per step), and the 8-thread point the survey container was measured at."""
     from oracle import unet_oracle as O
     import ctunet_amd
     cores = host_cores()
-    torch.set_num_threads(cores)
     torch.manual_seed(0)
-    net = ctunet_amd.UNet()
+    net = getattr(ctunet_amd, model)()
     sd = {k: v.clone() for k, v in net.state_dict().items()}
-    x, t = synth_batch(size, 0, "cpu")
-    spec = O.SPECS["UNet"]
-    best = float("inf")
-    for i in range(steps + 1):
-        t0 = time.perf_counter()
-        O.grads(spec, sd, x, lambda o: O.loss_single(o, t, 1.0, 1.0)[0], training=True)
-        dt = time.perf_counter() - t0
-        log(f"cpu baseline step {i}: {dt:.2f} s on {cores} threads")
-        if i > 0:
-            best = min(best, dt)
-    # "Dice vs CPU ref" (BASELINE metric, SURVEY 8d): hard segmentation argmax(out, 1) of the HIP path against the
-    # oracle's on identical weights and input (train-mode forward, the measured path), plus the raw-output error
+    spec = O.SPECS[model]
+    two = spec.head != "plain"
+    x, tg = synth_batch(size, 0, "cpu", batch, spec.in_ch, 2 if two else 1)
+    fn = (lambda o: O.loss_double(o, tg, 1.0, 1.0)[0]) if two else (lambda o: O.loss_single(o, tg[0], 1.0, 1.0)[0])
+
+    def timed(threads, recompute, n):
+        torch.set_num_threads(threads)
+        best = float("inf")
+        for i in range(n + 1):
+            t0 = time.perf_counter()
+            if mode == "train":
+                O.grads(spec, sd, x, fn, training=True)
+                if recompute:
+                    with torch.no_grad():
+                        O.forward(spec, {k: v.clone() for k, v in sd.items()}, x, training=True, update_stats=False)
+            else:
+                with torch.no_grad():
+                    O.forward(spec, sd, x, training=False)
+            dt = time.perf_counter() - t0
+            log(f"cpu baseline ({threads} threads{', +recompute' if recompute else ''}) step {i}: {dt:.2f} s")
+            if i > 0:
+                best = min(best, dt)
+        return best
+    best = timed(cores, False, steps)
+    vox = batch * size ** 3
+    out = {"value": vox / best, "unit": "voxels/s", "cores": cores, "kind": "port",
+           "sample": f"{steps} {'fwd+bwd' if mode == 'train' else 'eval-forward'} steps (best, after 1 warm-up) of the same "
+                     f"{size}^3 batch-{batch} {model}() {'train step' if mode == 'train' else 'forward'}, oracle = "
+                     f"torch.nn.functional graph on ATen-CPU fp32, no checkpoint recompute, {best:.2f} s/step"}
+    if mode == "train":
+        bc = timed(cores, True, 2)
+        out["checkpoint_default"] = {"value": vox / bc, "s_per_step": round(bc, 2),
+                                     "note": "reference default use_checkpoint=True: + one recompute forward per step (emulated)"}
+        if cores != 8:
+            b8 = timed(min(8, cores), False, 2)
+            out["threads_8"] = {"value": vox / b8, "s_per_step": round(b8, 2)}
+        torch.set_num_threads(cores)
+    # "Dice vs CPU ref" (BASELINE metric, SURVEY 8d): hard segmentation argmax(out, 1) of the measured HIP path (same
+    # precision, same BatchNorm mode) against the oracle's on identical weights and input, plus the raw-output error
     with torch.no_grad():
-        ref = O.forward(spec, {k: v.clone() for k, v in sd.items()}, x, training=True, update_stats=False)
+        ref = O.forward(spec, {k: v.clone() for k, v in sd.items()}, x, training=mode == "train", update_stats=False)
         net.load_state_dict(sd)
-        got = net.cuda().train()(x.cuda()).cpu()
-    a, b = got.argmax(1) == 1, ref.argmax(1) == 1
-    tot = int(a.sum()) + int(b.sum())
-    dice = 2.0 * int((a & b).sum()) / tot if tot else 1.0
-    rel = float((got - ref).abs().max() / ref.abs().max())
-    log(f"dice vs cpu ref {dice:.6f}, max rel output error {rel:.2e}")
-    return {"value": size ** 3 / best, "unit": "voxels/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} fwd+bwd steps (best, after 1 warm-up) of the same {size}^3 batch-1 UNet() train step, "
-                      f"oracle = torch.nn.functional graph on ATen-CPU fp32, no checkpoint recompute, {best:.2f} s/step",
-            "dice_vs_cpu_ref": dice, "max_rel_output_err": rel}
+        net = net.cuda().train(mode == "train").set_precision(precision)
+        got = net(x.cuda())
+    refs = ref if isinstance(ref, tuple) else (ref,)
+    gots = got if isinstance(got, tuple) else (got,)
+    dices, rels = [], []
+    for g_, r_ in zip(gots, refs):
+        g_ = g_.cpu()
+        a_, b_ = g_.argmax(1) == 1, r_.argmax(1) == 1
+        tot = int(a_.sum()) + int(b_.sum())
+        dices.append(2.0 * int((a_ & b_).sum()) / tot if tot else 1.0)
+        rels.append(float((g_ - r_).abs().max() / r_.abs().max()))
+    log(f"dice vs cpu ref {min(dices):.6f}, max rel output error {max(rels):.2e}")
+    out["dice_vs_cpu_ref"], out["max_rel_output_err"] = min(dices), max(rels)
+    return out
+
+
+# SURVEY 2.2: algorithmic forward+backward kFLOP per input voxel (= 3x forward, live graph, no recompute) and the fused-ideal
+# forward HBM bytes per voxel in fp32, per model class
+ALGO = {"UNet": (129.6e3, 694), "UNetSP": (100.6e3, 617), "UNetDO": (99.5e3, 613), "UNetSPSmall": (35.2e3, 363),
+        "recAE_v2_fixed": (570.6e3, 696), "UNet4_2IC": (442.8e3, 614)}     # the classes the example inis name
+PEAK_16BIT_MFMA_TFLOPS = 2500.0    # dense bf16 / fp16 (MI355X_MICROARCH.md)
 
 
 def main():
@@ -132,7 +172,12 @@ def main():
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
-    ap.add_argument("--eager", action="store_true", help="do not replay the step from a HIP graph (N=1 default: graph)")
+    ap.add_argument("--eager", action="store_true", help="do not replay the step from a HIP graph (default: graph)")
+    # secondary legs (the defaults above ARE the headline: UNet(), 128^3, fp32, batch 1, train step)
+    ap.add_argument("--model", default="UNet", choices=sorted(ALGO), help="drop-in class to run")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f16"], help="activation storage type (cfg 4 / 5)")
+    ap.add_argument("--mode", default="train", choices=["train", "infer"], help="infer: eval-mode forward only (cfg 2)")
+    ap.add_argument("--batch", type=int, default=1, help="per-GPU batch")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -153,23 +198,30 @@ def main():
     import ctunet_amd
     from ctunet_amd import ProblemHandler, ops, parallel
 
+    precision = {"f32": "fp32", "bf16": "bf16", "f16": "fp16"}[args.dtype]
+    train = args.mode == "train"
     torch.manual_seed(0)
-    net = ctunet_amd.UNet().to(dev).train()
+    net = getattr(ctunet_amd, args.model)().to(dev).train(train).set_precision(precision)
+    in_ch, two = net._plan.in_ch, net._plan.head_mode != 0   # (bg, flap, full) heads return two 2-channel maps
     use_graph = not args.eager
-    if distributed:
+    if distributed and train:
         if use_graph:
             parallel.broadcast_parameters(net)              # graph(fwd+bwd) -> flat RCCL all-reduce -> optimizer
         else:
             parallel.distribute(net)                        # eager: bucketed all-reduce overlapped with backward
     from ctunet_amd import optim as ctu_optim
     opt = ctu_optim.Adam(net.parameters(), lr=1e-4, weight_decay=0, amsgrad=True)         # Model.py:514-520, fused kernel
-    x, target = synth_batch(args.size, rank, dev)
+    x, targets = synth_batch(args.size, rank, dev, args.batch, in_ch, 2 if two else 1)
     holder = Holder()
+    handler = ProblemHandler.FlapRecWithShapePriorDoubleOut if two else ProblemHandler.ProblemHandler
 
     def eager_step():
+        if not train:
+            with torch.no_grad():
+                return net(x)
         xi = x.detach().requires_grad_(True)                # Model.py:351-352
         out = net(xi)
-        ProblemHandler.ProblemHandler.comp_losses_metrics(holder, out, target, 0, 1)   # one D2H sync for the logged floats
+        handler.comp_losses_metrics(holder, out, targets if two else targets[0], 0, 1)   # one D2H sync for the logged floats
         holder.pt_loss.backward()
         opt.step()
         for p in net.parameters():                          # Model.py:373-374
@@ -177,15 +229,28 @@ def main():
 
     step = eager_step
     mode = "eager"
-    if use_graph:
+    if use_graph and train:
         # a failed capture is fatal (non-zero exit): the headline number is never silently measured on eager launches;
         # eager is the explicit --eager flag, decided identically on every rank before any step runs
         from ctunet_amd.graph import GraphedTrainStep
-        gstep = GraphedTrainStep(net, opt, x, [target], 1.0, 1.0, input_requires_grad=True, distributed=distributed)
+        gstep = GraphedTrainStep(net, opt, x, targets, 1.0, 1.0, input_requires_grad=True, distributed=distributed)
 
         def step():
-            vals = gstep(x, [target])                   # same batch each step (synthetic), copied in like a loader would
+            vals = gstep(x, targets)                    # same batch each step (synthetic), copied in like a loader would
             holder.losses_and_metrics.setdefault("epoch_loss", []).append(vals.tolist()[-1])   # one D2H sync
+        mode = "hipgraph"
+    elif use_graph:
+        with torch.no_grad():
+            for _ in range(2):
+                net(x)
+            torch.cuda.synchronize()
+            g_inf = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_inf):
+                y_static = net(x)
+
+        def step():
+            g_inf.replay()
+            return y_static
         mode = "hipgraph"
 
     def barrier():
@@ -224,11 +289,15 @@ def main():
         tt = torch.tensor([dt], device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
-    vox = world * args.size ** 3 * args.steps
+    vox = world * args.batch * args.size ** 3 * args.steps
     value = vox / dt
     log(f"{dt / args.steps * 1e3:.2f} ms/step, {value / 1e6:.1f} Mvox/s")
 
     if rank == 0:
+        lowp = args.dtype != "f32"
+        flop_vox, bytes_vox = ALGO[args.model]
+        if not train:
+            flop_vox /= 3.0
         roofline = None
         kernels = {}
         if timer is not None:
@@ -237,31 +306,47 @@ def main():
             for tag, d in summ.items():
                 kernels[tag] = {"launches_per_step": d["launches"] / timer_steps, "avg_ms": round(d["avg_ms"], 4),
                                 "ms_per_step": round(d["total_ms"] / timer_steps, 3),
-                                "achieved_tflops": round(d["flops"] / (d["total_ms"] * 1e-3) / 1e12, 2)}
+                                "achieved_tflops": round(d["flops"] / (d["total_ms"] * 1e-3) / 1e12, 2),
+                                "achieved_gbs": round(d["bytes"] / (d["total_ms"] * 1e-3) / 1e9, 1)}
             # dominant kernel for the roofline leg: largest share of the step among the kernels whose algorithmic FLOPs are
             # the FLOPs they execute (the fused up-convolution symbols are credited with the two layers they replace)
             plain = {k: v for k, v in summ.items() if not k.startswith("upconv_fused")}
             dom = max((plain or summ).items(), key=lambda kv: kv[1]["total_ms"])
-            ach = dom[1]["flops"] / (dom[1]["total_ms"] * 1e-3) / 1e12
-            roofline = {"kernel": dom[0], "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
-                        "traffic": pmc_traffic(dom[0]),
-                        "algorithmic_mb_per_launch": round(dom[1]["bytes"] / dom[1]["launches"] / 1e6, 1),
-                        "avg_launch_ms": round(dom[1]["avg_ms"], 4),
-                        "measured": ("HIP events around each launch, " +
-                                     ("inside the timed region" if mode == "eager" else
-                                      f"{timer_steps} eager steps right after the graph-replayed timed region")),
-                        "algorithmic_gflop_per_launch": round(dom[1]["flops"] / dom[1]["launches"] / 1e9, 3)}
+            meas = ("HIP events around each launch, " +
+                    ("inside the timed region" if mode == "eager" else
+                     f"{timer_steps} eager steps right after the graph-replayed timed region"))
+            if lowp:
+                # 16-bit activations: every 128^3 / 64^3 stage is HBM-bound -- bytes, not FLOPs
+                ach = dom[1]["bytes"] / (dom[1]["total_ms"] * 1e-3) / 1e9
+                roofline = {"kernel": dom[0], "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                            "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": pmc_traffic(dom[0]),
+                            "algorithmic_mb_per_launch": round(dom[1]["bytes"] / dom[1]["launches"] / 1e6, 1),
+                            "avg_launch_ms": round(dom[1]["avg_ms"], 4), "measured": meas,
+                            "achieved_tflops": round(dom[1]["flops"] / (dom[1]["total_ms"] * 1e-3) / 1e12, 1)}
+            else:
+                ach = dom[1]["flops"] / (dom[1]["total_ms"] * 1e-3) / 1e12
+                roofline = {"kernel": dom[0], "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+                            "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+                            "traffic": pmc_traffic(dom[0]),
+                            "algorithmic_mb_per_launch": round(dom[1]["bytes"] / dom[1]["launches"] / 1e6, 1),
+                            "avg_launch_ms": round(dom[1]["avg_ms"], 4), "measured": meas,
+                            "algorithmic_gflop_per_launch": round(dom[1]["flops"] / dom[1]["launches"] / 1e9, 3)}
+        what = ("train step = fwd + Dice/CE loss + bwd + grad all-reduce + Adam(amsgrad)" if train else
+                "eval-mode forward (BatchNorm folded into the consumers' loads), no loss")
+        desc = {"UNet": "UNet() default (1 in, 2 out, i_size 8, 4 blocks)"}.get(args.model, args.model + "()")
+        headline = train and args.model == "UNet" and args.dtype == "f32" and args.batch == 1
         line = {
-            "metric": "voxels/sec fwd+bwd, 128^3 fp32 patch", "value": value, "unit": "voxels/s", "n_gpus": world,
+            "metric": "voxels/sec fwd+bwd, 128^3 fp32 patch" if headline else
+                      f"voxels/sec {'fwd+bwd' if train else 'fwd'}, {args.size}^3 {precision} patch",
+            "value": value, "unit": "voxels/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"UNet() default (1 in, 2 out, i_size 8, 4 blocks), {args.size}^3 patch, batch 1 per "
-                                   "GPU, train step = fwd + Dice/CE loss + bwd + grad all-reduce + Adam(amsgrad)",
-                       "patch": args.size, "per_gpu_batch": 1, "parallelism": f"dp{world}", "launch": mode,
-                       "whole_step_tflops_algorithmic": round(FLOP_PER_VOXEL_FWD_BWD * value / 1e12, 2),
-                       "whole_step_frac_of_mfma_peak": round(FLOP_PER_VOXEL_FWD_BWD * value / world / 1e12 /
-                                                             PEAK_FP32_MFMA_TFLOPS, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{desc}, {args.size}^3 patch, batch {args.batch} per GPU, {what}",
+                       "patch": args.size, "per_gpu_batch": args.batch, "parallelism": f"dp{world}", "launch": mode,
+                       "whole_step_tflops_algorithmic": round(flop_vox * value / 1e12, 2),
+                       "whole_step_frac_of_mfma_peak": round(flop_vox * value / world / 1e12 /
+                                                             (PEAK_16BIT_MFMA_TFLOPS if lowp else PEAK_FP32_MFMA_TFLOPS), 4),
+                       "whole_step_algorithmic_gbs": round((3 if train else 1) * bytes_vox * (0.5 if lowp else 1.0) * value / world / 1e9, 1),
                        "flop_accounting": "algorithmic = the reference's layers (SURVEY 8d); the fused decoder "
                                           "up-convolution kernels (upconv_fused_*) execute 3.9x fewer multiply-adds than the "
                                           "ConvTranspose3d + Conv3d pair they are credited with, so their TFLOP/s can exceed "
@@ -269,7 +354,7 @@ def main():
             "roofline": roofline, "kernels": kernels,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.size)
+            line["cpu_baseline"] = cpu_baseline(args.size, args.model, precision, args.mode, args.batch)
         real_stdout.write(json.dumps(line) + "\n")
         real_stdout.flush()
     if distributed:

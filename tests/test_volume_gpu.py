@@ -55,15 +55,15 @@ def test_extract_stitch_round_trip_is_bit_exact(shape, patch, overlap):
 
 
 def test_split_sample_keeps_the_dataset_schema_and_stitches_predictions():
-    """A 96x64x80 synthetic skull sample -> 32^3 patch samples with the reference datasets' schema; running the patches
+    """A 96x64x96 synthetic skull sample -> 32^3 patch samples with the reference datasets' schema; running the patches
     through a network and stitching gives a full-volume prediction; with overlap 0 the stitched argmax equals the
     per-patch argmax everywhere."""
     import ctunet_amd
     from ctunet_amd.tiling import VolumeTiler
     from ctunet_amd import ops
     g = gen(5)
-    img = (torch.rand(2, 96, 64, 80, generator=g) < 0.2).float().cuda()
-    lab = (torch.rand(1, 96, 64, 80, generator=g) < 0.3).float().cuda()
+    img = (torch.rand(2, 96, 64, 96, generator=g) < 0.2).float().cuda()
+    lab = (torch.rand(1, 96, 64, 96, generator=g) < 0.3).float().cuda()
     oh = ops.one_hot(lab, 2)[0]
     t = VolumeTiler(32, 0)
     parts = t.split_sample({"image": img, "target": (oh, oh.clone()), "filepath": "synthetic://vol"})
@@ -78,7 +78,7 @@ def test_split_sample_keeps_the_dataset_schema_and_stitches_predictions():
         preds = [net(p["image"].unsqueeze(0))[1][0] for p in parts]
     coords = torch.stack([p["coords"] for p in parts])
     full = t.stitch(torch.stack(preds), coords, img.shape[1:])
-    assert full.shape == (2, 96, 64, 80)
+    assert full.shape == (2, 96, 64, 96)
     z, y, x = parts[7]["coords"].tolist()
     assert torch.equal(full[:, z:z + 32, y:y + 32, x:x + 32], preds[7])
 
@@ -124,7 +124,8 @@ def test_hausdorff_matches_the_published_definition(shape):
     empty[:, 0] = 1.0
     assert torch.isnan(ops.hausdorff(empty.cuda(), target.cuda())).all()
     assert float(hausdorff(empty.cuda(), target.cuda())) == float(max(shape))
-    assert float(hausdorff(target.cuda(), target.cuda())) == 0.0
+    hard = torch.nn.functional.one_hot(pred.argmax(1), c).movedim(-1, 1).float().cuda()
+    assert float(hausdorff(hard, hard)) == 0.0
 
 
 def test_hausdorff_at_patch_size_is_deterministic_and_bounded():
