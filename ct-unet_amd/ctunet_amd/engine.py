@@ -421,9 +421,13 @@ class UNetEngine:
         emitted: set = set()
 
         def emit():
+            """Block boundary: the gradients produced since the last one are final -- un-scale them (float16 loss
+            scaling) and hand them to the gradient exchange."""
+            new = [(nm, g) for nm, g in grads.items() if nm not in emitted and g is not None]
+            emitted.update(nm for nm, _ in new)
+            if gs != 1.0 and new:
+                ops.scale_tensors([g for _, g in new], 1.0 / gs)
             if sync is not None:
-                new = [(nm, g) for nm, g in grads.items() if nm not in emitted]
-                emitted.update(nm for nm, _ in new)
                 sync.push(new)
         k = plan.k
         # workspaces sized for the largest layer
@@ -560,8 +564,9 @@ class UNetEngine:
             else:
                 self._conv_bn_bwd(P, r1, g_d1, None, grads, ws, part)
             emit()
-        if gs != 1.0:
-            ops.scale_tensors([g for g in grads.values() if g is not None] + ([dx] if dx is not None else []), 1.0 / gs)
+        emit()
+        if gs != 1.0 and dx is not None:
+            ops.scale_tensors([dx], 1.0 / gs)
         if sync is not None:
             grads.update(sync.finish())
         return grads, dx

@@ -4,27 +4,72 @@ launch-bound inner loops in hipGraphs").
 
 The step is the reference's ``Model.forward_pass`` train branch (ctunet/pytorch/Model.py:343-374) minus its
 host round trips: the per-term ``float(loss)`` syncs become ONE device->host copy after the replay.
-With ``distributed`` set (one process per GPU) the step is TWO graphs around one eagerly launched collective:
-graph 1 = forward + loss + backward + flattening of the live gradients into one static buffer; then the gradient
-sum over ranks (one flat RCCL all-reduce, 3.3 MB for UNet()) -- no collective is ever captured --; graph 2 = the fused
-optimizer step reading the gradients straight from the flat buffer.  The bucketed,
-backward-overlapped ``parallel.GradSync`` path remains the eager alternative.
+
+With ``distributed`` set (one process per GPU) the step is a CHAIN of graph segments cut at the gradient-bucket
+boundaries of backward (head + upper decoder / deep decoder / deep encoder / rest, ``parallel.DEFAULT_BUCKET_BYTES``):
+segment k ends by flattening bucket k into a static buffer; its all-reduce (RCCL through the C ABI, never captured) is
+launched on a side stream behind an event and runs UNDER segment k+1; the last segment is the fused optimizer step,
+which waits for every bucket.  Only the last, smallest bucket's collective is exposed.  The segments are captured by
+driving the engine directly (forward, fused loss kernels, backward) on the capturing thread -- no autograd thread takes
+part, so a capture can be ended and the next begun at a bucket boundary in the middle of backward.
 """
 from __future__ import annotations
 
-from typing import List, Optional, Sequence, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 
+from . import ops
 from .losses import fused_ce_dice
 
 
+class _Segmenter:
+    """The ``sync`` object ``UNetEngine.backward`` pushes gradients into: collects them into buckets and calls
+    ``boundary(flat)`` whenever one is complete (and once more from ``finish``)."""
+
+    def __init__(self, bucket_bytes: int, boundary):
+        self.bucket_bytes, self.boundary = int(bucket_bytes), boundary
+        self.pending: List[Tuple[str, torch.Tensor]] = []
+        self.nbytes = 0
+        self.layout: List[List[Tuple[str, torch.Size, int]]] = []
+        self.flats: List[torch.Tensor] = []
+
+    def _close(self) -> None:
+        if not self.pending:
+            return
+        flat = torch.cat([g.reshape(-1) for _, g in self.pending])
+        lay, off = [], 0
+        for name, g in self.pending:
+            lay.append((name, g.shape, off))
+            off += g.numel()
+        self.layout.append(lay)
+        self.flats.append(flat)
+        self.pending, self.nbytes = [], 0
+        self.boundary(len(self.flats) - 1, flat)
+
+    def push(self, named_grads) -> None:
+        for name, g in named_grads:
+            self.pending.append((name, g))
+            self.nbytes += g.numel() * g.element_size()
+        if self.nbytes >= self.bucket_bytes:
+            self._close()
+
+    def finish(self) -> Dict[str, torch.Tensor]:
+        self._close()
+        out = {}
+        for flat, lay in zip(self.flats, self.layout):
+            for name, shape, off in lay:
+                out[name] = flat[off:off + shape.numel()].view(shape)
+        return out
+
+
 class GraphedTrainStep:
-    """model: a ctunet_amd model on the GPU; optimizer: torch.optim.Adam/AdamW built with capturable=True."""
+    """model: a ctunet_amd model on the GPU; optimizer: ctunet_amd.optim.Adam/AdamW (or torch.optim with capturable=True)."""
 
     def __init__(self, model: torch.nn.Module, optimizer: torch.optim.Optimizer, example_input: torch.Tensor,
                  example_targets: Sequence[torch.Tensor], ce_lambda: float, dice_lambda: float,
-                 input_requires_grad: bool = True, warmup: int = 3, distributed: bool = False, process_group=None):
+                 input_requires_grad: bool = True, warmup: int = 3, distributed: bool = False, process_group=None,
+                 bucket_bytes: Optional[int] = None):
         self.model, self.opt = model, optimizer
         self._params = [p for p in model.parameters()]
         self.distributed, self.group = distributed, process_group
@@ -33,41 +78,41 @@ class GraphedTrainStep:
                                "parallel.distribute() on the model (use parallel.broadcast_parameters)")
         self.ce, self.dice = float(ce_lambda), float(dice_lambda)
         self.x = example_input.detach().clone()
-        self.targets = [t.detach().clone() for t in example_targets]
+        self.targets = [t.detach().clone().contiguous() for t in example_targets]
         self.x_req = input_requires_grad
         self.double = len(self.targets) == 2
         self.values: Optional[torch.Tensor] = None
-        self.graph = torch.cuda.CUDAGraph()
+        self.skip_comm = False                 # measurement only (bench.py's comm_ms_exposed): replay without the collectives
+        self.keys = self._keys()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        if distributed:
-            import torch.distributed as dist
-            self.world = dist.get_world_size(process_group)
+        if not distributed:
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                for _ in range(warmup):
+                    self._step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            with torch.cuda.graph(self.graph):
+                self.values = self._step()
+            return
+        import torch.distributed as dist
+        from .parallel import DEFAULT_BUCKET_BYTES, get_communicator
+        self.world = dist.get_world_size(process_group)
+        self.bucket_bytes = DEFAULT_BUCKET_BYTES if bucket_bytes is None else int(bucket_bytes)
+        self.comm = get_communicator(process_group)
+        self.comm_stream = torch.cuda.Stream()
+        self.segments: List[torch.cuda.CUDAGraph] = []
+        self.flats: List[torch.Tensor] = []
         with torch.cuda.stream(side):
-            for _ in range(warmup):
-                self._step()
-                if distributed:
-                    self._eager_reduce_step()
+            for _ in range(max(1, warmup)):            # (the optimizer state must exist before its segment is captured)
+                self._segmented_step(capture=False)
+            torch.cuda.synchronize()
+            # with a process group alive other threads of the process may issue HIP calls while this one captures (the
+            # nccl backend's watchdog polls its events): thread-local capture mode, see DESIGN 6
+            self._segmented_step(capture=True)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        # capture_error_mode: with a process group alive, RCCL's watchdog THREAD polls its work events at any time; under
-        # the default "global" mode such a query from another thread invalidates the capture (and the watchdog aborts the
-        # process) -- a race that depends on when the last warm-up all-reduce retires.  Only this thread's calls matter.
-        mode = "thread_local" if distributed else "global"
-        with torch.cuda.graph(self.graph, capture_error_mode=mode):
-            self.values = self._step()
-        self.keys = self._keys()
-        if distributed:
-            if warmup == 0:                                   # the optimizer state must exist before graph 2 is captured
-                self.graph.replay()
-                self._eager_reduce_step()
-                torch.cuda.synchronize()
-            # graph 2: the optimizer reads its gradients from views of the static flat buffer graph 1 fills
-            for p, v in zip(self._live, self.flat.split([p.numel() for p in self._live])):
-                p.grad = v.view_as(p)
-            self.graph2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph2, capture_error_mode=mode):
-                self._scale_and_step()
 
     def _keys(self) -> List[str]:
         k: List[str] = []
@@ -83,6 +128,7 @@ class GraphedTrainStep:
                 k += ["dice_loss"]
         return k + ["epoch_loss"]
 
+    # ------------------------------------------------------------------ single graph (one GPU): through autograd
     def _step(self) -> torch.Tensor:
         xi = self.x.requires_grad_(self.x_req)
         xi.grad = None
@@ -105,35 +151,72 @@ class GraphedTrainStep:
         for t in terms[1:]:
             loss = loss + t
         loss.backward()
-        if not self.distributed:
-            self.opt.step()
-            for p in self.model.parameters():
-                p.grad = None
-        else:
-            # every live gradient into one flat buffer (static once captured); grads are left to the next backward,
-            # which overwrites them (parameters the graph never touches keep .grad None on every rank)
-            self._live = [p for p in self.model.parameters() if p.grad is not None]
-            self.flat = torch.cat([p.grad.reshape(-1) for p in self._live])
-            for p in self._live:
-                p.grad = None
+        self.opt.step()
+        for p in self.model.parameters():
+            p.grad = None
         return torch.stack([t.detach() for t in terms] + [loss.detach()])
 
-    def _scale_and_step(self) -> None:
-        self.opt.step()                 # the collective already averaged (ncclAvg)
+    # ------------------------------------------------------------------ segmented (N > 1): the engine driven directly
+    def _segmented_step(self, capture: bool) -> None:
+        from .engine import _tensor_dict
+        model = self.model
+        eng = model._engine()
+        P = _tensor_dict(model)
+        pool = None
 
-    def _allreduce(self) -> None:
-        """Mean over ranks of the flat gradient buffer: RCCL through the C ABI on the current stream (never captured)."""
-        from .parallel import get_communicator
-        get_communicator(self.group).allreduce_(self.flat, average=True)
+        def begin():
+            g = torch.cuda.CUDAGraph()
+            g.capture_begin(pool=pool, capture_error_mode="thread_local")
+            self.segments.append(g)
+            return g
 
-    def _eager_reduce_step(self) -> None:
-        """One eagerly launched all-reduce + optimizer step on the flat buffer the last _step() produced."""
-        for p, v in zip(self._live, self.flat.split([p.numel() for p in self._live])):
-            p.grad = v.view_as(p)
-        self._allreduce()
-        self._scale_and_step()
-        for p in self._live:
-            p.grad = None
+        def boundary(k: int, flat: torch.Tensor) -> None:
+            nonlocal pool
+            if capture:
+                self.flats.append(flat)
+                self.segments[-1].capture_end()
+                if pool is None:
+                    pool = self.segments[0].pool()
+                begin()
+            else:
+                self._launch_allreduce(flat)
+
+        if capture:
+            begin()
+        with torch.no_grad():
+            out0, out1, ctx = eng.forward(P, self.x, True, True, bool(getattr(model, "chk", False)))
+            outs = [out0] if out1 is None else [out0, out1]
+            terms, gouts = [], []
+            for o, t in zip(outs, self.targets):
+                tt, ws = ops.loss_fwd(o, t, self.ce, self.dice, self.double)
+                gouts.append(ops.loss_bwd(o, t, self.ce, self.dice, self.double, ws, None, None))
+                terms.append(tt)
+            # list order of the reference: ce terms first, then dice terms (ProblemHandler.py:252-273)
+            tl = ([t[0] for t in terms] if self.ce else []) + ([t[1] for t in terms] if self.dice else [])
+            loss = tl[0]
+            for t in tl[1:]:
+                loss = loss + t
+            values = torch.stack(tl + [loss])
+            seg = _Segmenter(self.bucket_bytes, boundary)
+            grads, _ = eng.backward(P, ctx, gouts[0], gouts[1] if len(gouts) == 2 else None, self.x_req, seg)
+            if not capture:
+                torch.cuda.current_stream().wait_stream(self.comm_stream)
+            for name, p in model.named_parameters():
+                p.grad = grads.get(name)
+            self.opt.step()
+            for p in self._params:
+                p.grad = None
+        if capture:
+            self.segments[-1].capture_end()
+            self.values = values
+
+    def _launch_allreduce(self, flat: torch.Tensor) -> None:
+        """Mean over ranks of one bucket on the side stream, behind everything enqueued on the current stream so far."""
+        cur = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        self.comm_stream.wait_event(ev)
+        self.comm.allreduce_(flat, average=True, stream=self.comm_stream)
 
     def __call__(self, x: Optional[torch.Tensor] = None, targets: Optional[Sequence[torch.Tensor]] = None) -> torch.Tensor:
         """Copies the batch into the captured buffers, replays the step, returns the loss terms (device tensor,
@@ -143,10 +226,16 @@ class GraphedTrainStep:
         if targets is not None:
             for dst, src in zip(self.targets, targets):
                 dst.copy_(src)
-        self.graph.replay()
-        if self.distributed:
-            self._allreduce()
-            self.graph2.replay()
+        if not self.distributed:
+            self.graph.replay()
+        else:
+            cur = torch.cuda.current_stream()
+            for k, flat in enumerate(self.flats):
+                self.segments[k].replay()
+                if not self.skip_comm:
+                    self._launch_allreduce(flat)           # runs under segment k + 1
+            cur.wait_stream(self.comm_stream)
+            self.segments[-1].replay()                    # the fused optimizer step, reading the averaged buckets
         # the replayed optimizer kernel wrote the parameters through raw pointers: bump their version counters, so that
         # an eagerly launched forward after this replay (the reference's train-then-validate epoch loop,
         # Model.py:240-243) re-packs the engine's MFMA-ordered weight copies instead of hitting a stale cache entry

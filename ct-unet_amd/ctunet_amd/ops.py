@@ -497,9 +497,25 @@ def pack_convt_w_lp(w: torch.Tensor, cinv, rin_p: int, nout_p: int, mode: int, d
     return wp
 
 
+def _timed_convt(tag: str, x_cp: int, o_cp: int, vox: int, w: int, elem: int):
+    """Context for the ConvTranspose launches of the stage table: algorithmic 2*8*C*C FLOP and (C + 8C) elements per coarse voxel."""
+    class _T:
+        def __enter__(self_):
+            self_.t0 = TIMER.begin() if TIMER is not None else None
+        def __exit__(self_, *exc):
+            if self_.t0 is not None and exc[0] is None:
+                TIMER.end(tag, 16.0 * x_cp * o_cp * vox, float(elem) * vox * (x_cp + 8 * o_cp), self_.t0, (w, x_cp, o_cp))
+    return _T()
+
+
 def convt_fwd(x: CL, wp: torch.Tensor, bias: Optional[torch.Tensor], out: CL) -> None:
     n, d, h, w = x.dims
     lib = _lib.load()
+    with _timed_convt("convt2_fwd" + ("_lp" if x.lp else ""), x.cp, out.cp, n * d * h * w, w, x.buf.element_size()):
+        _convt_fwd(x, wp, bias, out, lib, n, d, h, w)
+
+
+def _convt_fwd(x, wp, bias, out, lib, n, d, h, w) -> None:
     if x.lp:
         assert out.dtype == x.dtype and wp.dtype == x.dtype
         _lib.check(lib.ctu_lp_convt2_fwd(x.lp, x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), wp.data_ptr(),
@@ -514,6 +530,11 @@ def convt_fwd(x: CL, wp: torch.Tensor, bias: Optional[torch.Tensor], out: CL) ->
 def convt_bwd_data(gout: CL, wp: torch.Tensor, gin: CL) -> None:
     n, d, h, w = gin.dims
     lib = _lib.load()
+    with _timed_convt("convt2_bwd_data" + ("_lp" if gout.lp else ""), gin.cp, gout.cp, n * d * h * w, w, gout.buf.element_size()):
+        _convt_bwd_data(gout, wp, gin, lib, n, d, h, w)
+
+
+def _convt_bwd_data(gout, wp, gin, lib, n, d, h, w) -> None:
     if gout.lp:
         assert gin.dtype == gout.dtype and wp.dtype == gout.dtype
         _lib.check(lib.ctu_lp_convt2_bwd_data(gout.lp, gout.ptr, gout.cs, gout.cp, wp.data_ptr(), gin.ptr, gin.cs, gin.cp, n, d,
@@ -526,6 +547,11 @@ def convt_bwd_data(gout: CL, wp: torch.Tensor, gin: CL) -> None:
 def convt_wgrad(x: CL, g: CL, ci: int, co: int, imap, ws: torch.Tensor):
     n, d, h, w = x.dims
     lib = _lib.load()
+    with _timed_convt("convt2_wgrad" + ("_lp" if x.lp else ""), x.cp, g.cp, n * d * h * w, w, x.buf.element_size()):
+        return _convt_wgrad(x, g, ci, co, imap, ws, lib, n, d, h, w)
+
+
+def _convt_wgrad(x, g, ci, co, imap, ws, lib, n, d, h, w):
     if x.lp:
         assert g.dtype == x.dtype
         assert ws.numel() >= lib.ctu_lp_convt2_wgrad_ws_floats(n, d, h, w, x.cp, g.cp)

@@ -81,3 +81,23 @@ def test_single_process_is_noop():
     s = parallel.GradSync()
     s.push([("a", torch.ones(3))])
     assert s.finish() == {}
+
+
+def test_graph_segmenter_cuts_backward_at_bucket_boundaries():
+    """graph._Segmenter (the sync object of the segmented distributed step): buckets close when bucket_bytes are pending,
+    `boundary` fires once per bucket in order, finish() returns views of the flat buffers with the pushed values."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ct-unet_amd"))
+    from ctunet_amd.graph import _Segmenter
+    seen = []
+    seg = _Segmenter(100, lambda k, flat: seen.append((k, flat.numel())))
+    vals = {f"t{i}": torch.full((4 + i,), float(i)) for i in range(8)}       # 16, 20, 24, ... bytes
+    names = list(vals)
+    seg.push([(n, vals[n]) for n in names[:3]])          # 60 bytes: open
+    assert seen == []
+    seg.push([(n, vals[n]) for n in names[3:5]])         # +60: closes bucket 0 (5 tensors)
+    seg.push([(names[5], vals[names[5]])])               # 36: open
+    out = seg.finish()                                   # closes bucket 1
+    seg2 = seg.finish()
+    assert seen == [(0, 4 + 5 + 6 + 7 + 8), (1, 9)] and set(out) == set(names[:6]) and set(seg2) == set(out)
+    for n in names[:6]:
+        assert torch.equal(out[n], vals[n]) and out[n].shape == vals[n].shape

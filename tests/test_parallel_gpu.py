@@ -84,20 +84,37 @@ def _worker(rank, world, port, tmp):
             else:
                 exp = sum(gr[n] for gr in g) / world
                 assert torch.allclose(p.grad, exp, rtol=1e-5, atol=1e-7), n
-        # (b) graph path: one step from identical weights must leave every rank with the SAME parameters as an
-        #     un-distributed optimizer step on the mean gradient
-        torch.manual_seed(0)
-        net_g = ctunet_amd.UNet(n_blocks=2, use_checkpoint=False).cuda().train()
-        opt_g = O2.Adam(net_g.parameters(), lr=1e-2)
-        gs = GraphedTrainStep(net_g, opt_g, x.cuda(), [t.cuda()], 1.0, 1.0, warmup=0, distributed=True)
-        torch.manual_seed(0)
-        net_r = ctunet_amd.UNet(n_blocks=2, use_checkpoint=False).cuda().train()
-        opt_r = O2.Adam(net_r.parameters(), lr=1e-2)
-        for n, p in net_r.named_parameters():
-            p.grad = None if g[0][n] is None else sum(gr[n] for gr in g) / world
-        opt_r.step()
-        for (n, a), (_, b) in zip(net_r.named_parameters(), net_g.named_parameters()):
-            assert torch.allclose(a, b, rtol=1e-4, atol=1e-6), n
+        # (b) graph path (chain of graph segments with the bucket all-reduces between them): two steps -- one eager
+        #     warm-up inside the constructor, one replay -- must leave every rank with the same parameters as two steps of
+        #     the eager bucketed path (a) from identical weights
+        def two_steps(graph):
+            torch.manual_seed(0)
+            m = ctunet_amd.UNet(n_blocks=2, use_checkpoint=False).cuda().train()
+            opt = O2.Adam(m.parameters(), lr=1e-2)
+            xx, tt = _rank_inputs(rank)
+            xx, tt = xx.cuda(), tt.cuda()
+            if graph:
+                parallel.broadcast_parameters(m)
+                gs = GraphedTrainStep(m, opt, xx, [tt], 1.0, 1.0, warmup=1, distributed=True, bucket_bytes=4096)
+                assert len(gs.flats) >= 3 and len(gs.segments) == len(gs.flats) + 1
+                gs(xx, [tt])
+            else:
+                parallel.distribute(m, bucket_bytes=4096)
+                for _ in range(2):
+                    ce_, dc_ = L.fused_ce_dice(m(xx.clone().requires_grad_(True)), tt, 1.0, 1.0, False)
+                    (ce_ + dc_).backward()
+                    opt.step()
+                    for p in m.parameters():
+                        p.grad = None
+            torch.cuda.synchronize()
+            return m
+        m_e, m_g = two_steps(False), two_steps(True)
+        for (n, a), (_, b) in zip(m_e.state_dict().items(), m_g.state_dict().items()):
+            assert torch.allclose(a.float(), b.float(), rtol=1e-4, atol=1e-6), n
+        flat = torch.cat([p.detach().flatten() for p in m_g.parameters()])
+        other = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(other, flat)
+        assert all(torch.equal(other[0], o) for o in other)            # the ranks stay in lock step
         open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")
     finally:
         from ctunet_amd import parallel as par
