@@ -71,11 +71,13 @@ def host_cores():
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-    (profiles/r01_hbm_traffic.json, produced by scripts/collect_traffic.py with the guide's gfx950 corrections);
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+    (profiles/rNN_hbm_traffic.json, produced by scripts/collect_traffic.py with the guide's gfx950 corrections);
     None when no PMC run covers this kernel."""
+    import glob
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_hbm_traffic.json")))
+        with open(files[-1]) as f:
             k = json.load(f)["kernels"].get(kernel.split(" (")[0])
         return None if k is None else round(k["hbm_bytes_per_launch"])
     except Exception:

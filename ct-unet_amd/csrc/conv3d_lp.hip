@@ -85,13 +85,17 @@ struct LpConvP {
     int S;            // LDS bytes per halo voxel
 };
 
-template <class T, int KS, int NT, int BW>
+// Box TD = 4 x TH x BW voxels, one plane (td) per wave, CT = TH * BW / 16 column tiles of 16 voxels per wave.  The box grows
+// when a voxel is small (few input channels): 4x8x32 for one 8-channel chunk, 4x8x16 for two, 4x4x16 otherwise -- a block
+// then moves 16-32 KB instead of 4 KB and the per-block latency chain (global -> LDS -> barrier -> MFMA) amortises.
+template <class T, int KS, int NT, int TH, int BW>
 __global__ __launch_bounds__(256) void lp_conv_fwd_kernel(LpConvP p) {
     typedef typename Vec<T>::v8 v8;
     constexpr int TAPS = KS * KS * KS, PK = (KS - 1) / 2;
-    constexpr int TD = 4, TH = 64 / BW;
+    constexpr int TD = 4, CT = TH * BW / 16;
     constexpr int HD = TD + 2 * PK, HH = TH + 2 * PK, HW = BW + 2 * PK, HV = HD * HH * HW;
     constexpr int PF = 4;                                           // weight-fragment ring depth (K-steps ahead)
+    constexpr int UB = 12;                                          // staging loads in flight per thread
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int* sK = reinterpret_cast<int*>(smem);                         // [TAPS * 4 padded to 512] byte offsets of the (tap, chunk) pairs
     float* sXf = reinterpret_cast<float*>(smem + 2048);             // [2][32] scale / shift of the stage
@@ -108,19 +112,21 @@ __global__ __launch_bounds__(256) void lp_conv_fwd_kernel(LpConvP p) {
     const int n16 = (p.nout_p + 15) >> 4, nt0 = blockIdx.y * NT;
     const T* in = reinterpret_cast<const T*>(p.in);
     const T* wp = reinterpret_cast<const T*>(p.wp);
-    // this lane's voxel in each of the wave's 4 column tiles (16 voxels each): halo index of the top-left tap
-    int hb[4], lth[4], ltw;
-    ltw = (BW == 16) ? m : (m & 7);
+    // this lane's voxel in each of the wave's column tiles: (th, tw) inside the box; halo byte offset of the top-left tap
+    auto vox_of = [&](int ct, int& th, int& tw) {
+        if (BW == 32) { th = ct >> 1; tw = (ct & 1) * 16 + m; }
+        else if (BW == 16) { th = ct; tw = m; }
+        else { th = ct * 2 + (m >> 3); tw = m & 7; }
+    };
+    f32x4 acc[CT][NT];
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-        lth[ct] = (BW == 16) ? ct : (ct * 2 + (m >> 3));
-        hb[ct] = ((wave * HH + lth[ct]) * HW + ltw) * S;
-    }
-    f32x4 acc[4][NT];
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
+    for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[ct][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int th0, tw0;
+    vox_of(0, th0, tw0);
+    const int hb0 = ((wave * HH + th0) * HW + tw0) * S;             // column tile ct sits ct_step further
+    constexpr int CT_ROWSTEP = (BW == 32) ? 0 : ((BW == 16) ? 1 : 2);
     const int ns = lp_nstage(p.rin_p);
     const bool xf = p.scale != nullptr;
     for (int st = 0; st < ns; ++st) {
@@ -149,45 +155,41 @@ __global__ __launch_bounds__(256) void lp_conv_fwd_kernel(LpConvP p) {
                 ring[u][nt] = *reinterpret_cast<const v8*>(wp + ((size_t)((kbase + s) * n16 + tile) * 64 + lane) * 8);
             }
         if (xf) __syncthreads();                                    // sXf visible
-        // ---- stage the haloed box: 16-byte items (halo voxel, chunk), 4 loads in flight per thread
+        // ---- stage the haloed box: 16-byte items (halo voxel, chunk), up to UB loads in flight per thread
         const int items = HV << sh;
-        for (int i0 = tid; i0 < items; i0 += 256 * 4) {
-            uint4 raw[4];
-            int dst[4], c8s[4];
+        for (int i0 = tid; i0 < items; i0 += 256 * UB) {
+            uint4 raw[UB];
+            int dst[UB];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < UB; ++u) {
                 const int i = i0 + u * 256;
                 const int v = i >> sh, c = i & (nchp - 1);
-                c8s[u] = c * 8;
                 const int pw = v % HW, t2 = v / HW, ph = t2 % HH, pd = t2 / HH;
                 const int gd = d0 + pd - PK, gh = h0 + ph - PK, gw = w0 + pw - PK;
-                const bool ok = i < items && c < nch && (unsigned)gd < (unsigned)p.D && (unsigned)gh < (unsigned)p.H &&
-                                (unsigned)gw < (unsigned)p.W;
-                dst[u] = (i < items && c < nch) ? (v * S + c * 16) : -1;
+                const bool live = i < items && c < nch;
+                const bool ok = live && (unsigned)gd < (unsigned)p.D && (unsigned)gh < (unsigned)p.H && (unsigned)gw < (unsigned)p.W;
+                // bit 30: outside the volume (the ACTIVATED input is zero padded); bits 28-29: chunk within the stage
+                dst[u] = live ? ((v * S + c * 16) | (c << 26) | (ok ? 0 : 0x40000000)) : -1;
                 raw[u] = make_uint4(0u, 0u, 0u, 0u);
                 if (ok) raw[u] = *reinterpret_cast<const uint4*>(in + ((((size_t)n * p.D + gd) * p.H + gh) * p.W + gw) * p.in_cs +
                                                                  st * LP_SC + c * 8);
-                if (!ok && dst[u] >= 0) dst[u] |= 0x40000000;       // out of the volume: the ACTIVATED input is zero padded
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < UB; ++u) {
                 if (dst[u] < 0) continue;
                 uint4 r = raw[u];
-                if (xf) {
-                    if (dst[u] & 0x40000000) r = make_uint4(0u, 0u, 0u, 0u);
-                    else {
-                        const int c8 = c8s[u];                                       // first channel of the item within the stage
-                        const f32x8 f = __builtin_convertvector(*reinterpret_cast<v8*>(&r), f32x8);
-                        f32x8 o;
+                if (xf && !(dst[u] & 0x40000000)) {
+                    const int c8 = ((dst[u] >> 26) & 3) * 8;               // first channel of the item within the stage
+                    const f32x8 f = __builtin_convertvector(*reinterpret_cast<v8*>(&r), f32x8);
+                    f32x8 o;
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const float a = fmaf(f[j], sXf[c8 + j], sXf[32 + c8 + j]);
-                            o[j] = p.relu ? fmaxf(a, 0.f) : a;
-                        }
-                        *reinterpret_cast<v8*>(&r) = __builtin_convertvector(o, v8);
+                    for (int j = 0; j < 8; ++j) {
+                        const float a = fmaf(f[j], sXf[c8 + j], sXf[32 + c8 + j]);
+                        o[j] = p.relu ? fmaxf(a, 0.f) : a;
                     }
+                    *reinterpret_cast<v8*>(&r) = __builtin_convertvector(o, v8);
                 }
-                *reinterpret_cast<uint4*>(sIn + (dst[u] & 0x3fffffff)) = r;
+                *reinterpret_cast<uint4*>(sIn + (dst[u] & 0x03ffffff)) = r;
             }
         }
         __syncthreads();
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(256) void lp_conv_fwd_kernel(LpConvP p) {
             for (int u = 0; u < PF; ++u) {
                 const int s = s0 + u;
                 if (s < ks) {
-                    const int koff = sK[4 * s + kg];
+                    const int koff = sK[4 * s + kg] + hb0;
                     v8 a[NT];
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) a[nt] = ring[u][nt];
@@ -209,8 +211,10 @@ __global__ __launch_bounds__(256) void lp_conv_fwd_kernel(LpConvP p) {
                         }
                     }
 #pragma unroll
-                    for (int ct = 0; ct < 4; ++ct) {
-                        const v8 b = *reinterpret_cast<const v8*>(sIn + hb[ct] + koff);
+                    for (int ct = 0; ct < CT; ++ct) {
+                        // column tile ct: BW 32 -> (row ct / 2, half ct & 1); BW 16 -> row ct; BW 8 -> rows 2 ct, 2 ct + 1
+                        const int cto = (BW == 32) ? ((ct >> 1) * HW + (ct & 1) * 16) * S : ct * CT_ROWSTEP * HW * S;
+                        const v8 b = *reinterpret_cast<const v8*>(sIn + koff + cto);
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) acc[ct][nt] = Mfma<T>::run(a[nt], b, acc[ct][nt]);
                     }
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(256) void lp_conv_fwd_kernel(LpConvP p) {
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { s1[nt][r] = 0.f; s2[nt][r] = 0.f; }
-    const int gd = d0 + wave, gw = w0 + ltw;
+    const int gd = d0 + wave;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int cb = (nt0 + nt) * 16 + 4 * kg;
@@ -236,8 +240,10 @@ __global__ __launch_bounds__(256) void lp_conv_fwd_kernel(LpConvP p) {
             bv.z = cb + 2 < p.nbias ? p.bias[cb + 2] : 0.f; bv.w = cb + 3 < p.nbias ? p.bias[cb + 3] : 0.f;
         }
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-            const int gh = h0 + lth[ct];
+        for (int ct = 0; ct < CT; ++ct) {
+            int th, tw;
+            vox_of(ct, th, tw);
+            const int gh = h0 + th, gw = w0 + tw;
             if (gd < p.D && gh < p.H && gw < p.W) {
                 const float4 o = rnd4<T>(make_float4(acc[ct][nt][0] + bv.x, acc[ct][nt][1] + bv.y, acc[ct][nt][2] + bv.z,
                                                      acc[ct][nt][3] + bv.w));
@@ -275,45 +281,52 @@ __global__ __launch_bounds__(256) void lp_conv_fwd_kernel(LpConvP p) {
     }
 }
 
-int lp_box_w(int W) { return W >= 16 ? 16 : 8; }
+struct LpBox { int th, bw; };
 
-int lp_fill(LpConvP& p, int N, int D, int H, int W) {
-    const int bw = lp_box_w(W), th = 64 / bw;
+// box of a forward / data-gradient launch: bigger boxes for thin voxels (see lp_conv_fwd_kernel)
+LpBox lp_box(int W, int rin_p) {
+    const int nch = (rin_p >= LP_SC ? LP_SC : rin_p) >> 3;
+    if (W < 16) return {8, 8};
+    if (nch == 1 && W >= 32) return {8, 32};
+    if (nch <= 2) return {8, 16};
+    return {4, 16};
+}
+
+int lp_fill(LpConvP& p, int N, int D, int H, int W, int rin_p) {
+    const LpBox bx = lp_box(W, rin_p);
     p.N = N; p.D = D; p.H = H; p.W = W;
-    p.tiles_d = ceil_div(D, 4); p.tiles_h = ceil_div(H, th); p.tiles_w = ceil_div(W, bw);
+    p.tiles_d = ceil_div(D, 4); p.tiles_h = ceil_div(H, bx.th); p.tiles_w = ceil_div(W, bx.bw);
     return N * p.tiles_d * p.tiles_h * p.tiles_w;
 }
 
 int lp_voxel_stride(int rin_p) { return rin_p >= 16 ? (rin_p >= LP_SC ? LP_SC : rin_p) * 2 + 16 : 16; }
 
-template <class T, int KS, int NT>
-int lp_conv_launch(LpConvP& p, int ntiles, hipStream_t st) {
+template <class T, int KS, int NT, int TH, int BW>
+int lp_conv_launch_box(LpConvP& p, int ntiles, hipStream_t st) {
     constexpr int PK = (KS - 1) / 2;
-    const int bw = lp_box_w(p.W), th = 64 / bw;
-    const int hv = (4 + 2 * PK) * (th + 2 * PK) * (bw + 2 * PK);
+    const int hv = (4 + 2 * PK) * (TH + 2 * PK) * (BW + 2 * PK);
     const size_t lds = 2048 + 256 + 4 * NT * 32 * 4 + (size_t)hv * p.S;
     CTU_REQUIRE(lds <= 160 * 1024, "lp_conv3d_fwd: LDS box of %zu bytes", lds);
     const int n16 = (p.nout_p + 15) >> 4;
     const dim3 grid(ntiles, ceil_div(n16, NT));
-    if (bw == 16) {
-        static bool raised = false;
-        if (!raised) {
-            CTU_REQUIRE(hipFuncSetAttribute((const void*)lp_conv_fwd_kernel<T, KS, NT, 16>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            160 * 1024) == hipSuccess, "lp_conv3d_fwd: cannot raise the dynamic LDS limit");
-            raised = true;
-        }
-        lp_conv_fwd_kernel<T, KS, NT, 16><<<grid, 256, lds, st>>>(p);
-    } else {
-        static bool raised = false;
-        if (!raised) {
-            CTU_REQUIRE(hipFuncSetAttribute((const void*)lp_conv_fwd_kernel<T, KS, NT, 8>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            160 * 1024) == hipSuccess, "lp_conv3d_fwd: cannot raise the dynamic LDS limit");
-            raised = true;
-        }
-        lp_conv_fwd_kernel<T, KS, NT, 8><<<grid, 256, lds, st>>>(p);
+    static bool raised = false;
+    if (!raised) {
+        CTU_REQUIRE(hipFuncSetAttribute((const void*)lp_conv_fwd_kernel<T, KS, NT, TH, BW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        160 * 1024) == hipSuccess, "lp_conv3d_fwd: cannot raise the dynamic LDS limit");
+        raised = true;
     }
+    lp_conv_fwd_kernel<T, KS, NT, TH, BW><<<grid, 256, lds, st>>>(p);
     CTU_CHECK_LAUNCH("lp_conv3d_fwd");
     return CTU_OK;
+}
+
+template <class T, int KS, int NT>
+int lp_conv_launch(LpConvP& p, int ntiles, hipStream_t st) {
+    const LpBox bx = lp_box(p.W, p.rin_p);
+    if (bx.bw == 32) return lp_conv_launch_box<T, KS, NT, 8, 32>(p, ntiles, st);
+    if (bx.bw == 8) return lp_conv_launch_box<T, KS, NT, 8, 8>(p, ntiles, st);
+    if (bx.th == 8) return lp_conv_launch_box<T, KS, NT, 8, 16>(p, ntiles, st);
+    return lp_conv_launch_box<T, KS, NT, 4, 16>(p, ntiles, st);
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradient
@@ -369,68 +382,70 @@ __global__ __launch_bounds__(256) void lp_conv_wgrad_kernel(LpWgP p, int tiles_p
     const int nchx = min(2, (p.cin_p - cit * 16) >> 3), nchg = min(2, (p.cout_p - cot * 16) >> 3);
     int tile = blockIdx.x * tiles_per_block;
     const int tile_end = min(p.ntiles, tile + tiles_per_block);
-    for (; tile < tile_end; ++tile) {
-        int t = tile;
+    // software pipeline: the NEXT box's global loads are in flight (in registers) while this box's taps run
+    constexpr int NX = (HV * 2 + 255) / 256, NG = NV * 2 / 256;
+    uint4 rx[NX], rg[NG];
+    unsigned okx = 0;                                               // bit it: X item it lies inside the volume
+    auto load_box = [&](int tl) {
+        int t = tl;
         const int tx = t % p.tiles_w; t /= p.tiles_w;
         const int ty = t % p.tiles_h; t /= p.tiles_h;
         const int tz = t % p.tiles_d;
         const int n = t / p.tiles_d;
         const int d0 = tz * TD, h0 = ty * TH, w0 = tx * BW;
-        __syncthreads();
-        // ---- stage X (haloed, lazy BatchNorm + ReLU, zero outside the volume) and G: 16-byte items
-        for (int i0 = tid; i0 < HV * 2; i0 += 256 * 4) {
-            uint4 raw[4];
-            int dst[4];
+        okx = 0;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int it = i0 + u * 256, v = it >> 1, c = it & 1;
-                const int pw = v % HW, t2 = v / HW, ph = t2 % HH, pd = t2 / HH;
-                const int gd = d0 + pd + ((KS == 3) ? -1 : kd - PK), gh = h0 + ph - PK, gw = w0 + pw - PK;
-                const bool in_img = it < HV * 2;
-                const bool ok = in_img && c < nchx && (unsigned)gd < (unsigned)p.D && (unsigned)gh < (unsigned)p.H &&
-                                (unsigned)gw < (unsigned)p.W;
-                dst[u] = in_img ? ((v * WG_SX + c * 16) | (ok ? 0 : 0x40000000)) : -1;
-                raw[u] = make_uint4(0u, 0u, 0u, 0u);
-                if (ok) raw[u] = *reinterpret_cast<const uint4*>(x + ((((size_t)n * p.D + gd) * p.H + gh) * p.W + gw) * p.x_cs +
-                                                                 cit * 16 + c * 8);
+        for (int u = 0; u < NX; ++u) {
+            const int it = tid + u * 256, v = it >> 1, c = it & 1;
+            const int pw = v % HW, t2 = v / HW, ph = t2 % HH, pd = t2 / HH;
+            const int gd = d0 + pd + ((KS == 3) ? -1 : kd - PK), gh = h0 + ph - PK, gw = w0 + pw - PK;
+            const bool ok = it < HV * 2 && c < nchx && (unsigned)gd < (unsigned)p.D && (unsigned)gh < (unsigned)p.H &&
+                            (unsigned)gw < (unsigned)p.W;
+            rx[u] = make_uint4(0u, 0u, 0u, 0u);
+            if (ok) {
+                rx[u] = *reinterpret_cast<const uint4*>(x + ((((size_t)n * p.D + gd) * p.H + gh) * p.W + gw) * p.x_cs + cit * 16 + c * 8);
+                okx |= 1u << u;
             }
+        }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (dst[u] < 0) continue;
-                uint4 r = raw[u];
-                if (xf && !(dst[u] & 0x40000000)) {
-                    const int c8 = (dst[u] & 16) >> 1;
-                    const f32x8 f = __builtin_convertvector(*reinterpret_cast<v8*>(&r), f32x8);
-                    f32x8 o;
+        for (int u = 0; u < NG; ++u) {
+            const int it = tid + u * 256, v = it >> 1, c = it & 1;
+            const int tw = v % BW, t2 = v / BW, th = t2 % TH, td = t2 / TH;
+            const int gd = d0 + td, gh = h0 + th, gw = w0 + tw;
+            rg[u] = make_uint4(0u, 0u, 0u, 0u);
+            if (c < nchg && gd < p.D && gh < p.H && gw < p.W)
+                rg[u] = *reinterpret_cast<const uint4*>(gr + ((((size_t)n * p.D + gd) * p.H + gh) * p.W + gw) * p.g_cs + cot * 16 + c * 8);
+        }
+    };
+    if (tile < tile_end) load_box(tile);
+    for (; tile < tile_end; ++tile) {
+        __syncthreads();                                            // the previous box's readers are done
+        // ---- registers -> LDS images: X with the lazy BatchNorm + ReLU (zero outside the volume), G as it is
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float a = fmaf(f[j], sXf[c8 + j], sXf[16 + c8 + j]);
-                        o[j] = p.relu ? fmaxf(a, 0.f) : a;
-                    }
-                    *reinterpret_cast<v8*>(&r) = __builtin_convertvector(o, v8);
+        for (int u = 0; u < NX; ++u) {
+            const int it = tid + u * 256;
+            if (it >= HV * 2) continue;
+            uint4 r = rx[u];
+            if (xf && ((okx >> u) & 1u)) {
+                const int c8 = (it & 1) * 8;
+                const f32x8 f = __builtin_convertvector(*reinterpret_cast<v8*>(&r), f32x8);
+                f32x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float a = fmaf(f[j], sXf[c8 + j], sXf[16 + c8 + j]);
+                    o[j] = p.relu ? fmaxf(a, 0.f) : a;
                 }
-                *reinterpret_cast<uint4*>(sX + (dst[u] & 0x3fffffff)) = r;
+                *reinterpret_cast<v8*>(&r) = __builtin_convertvector(o, v8);
             }
+            *reinterpret_cast<uint4*>(sX + (it >> 1) * WG_SX + (it & 1) * 16) = r;
         }
-        for (int i0 = tid; i0 < NV * 2; i0 += 256 * 4) {
-            uint4 raw[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int it = i0 + u * 256, v = it >> 1, c = it & 1;
-                const int tw = v % BW, t2 = v / BW, th = t2 % TH, td = t2 / TH;
-                const int gd = d0 + td, gh = h0 + th, gw = w0 + tw;
-                raw[u] = make_uint4(0u, 0u, 0u, 0u);
-                if (it < NV * 2 && c < nchg && gd < p.D && gh < p.H && gw < p.W)
-                    raw[u] = *reinterpret_cast<const uint4*>(gr + ((((size_t)n * p.D + gd) * p.H + gh) * p.W + gw) * p.g_cs +
-                                                             cot * 16 + c * 8);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int it = i0 + u * 256;
-                if (it < NV * 2) *reinterpret_cast<uint4*>(sG + (it >> 1) * WG_SX + (it & 1) * 16) = raw[u];
-            }
+        for (int u = 0; u < NG; ++u) {
+            const int it = tid + u * 256;
+            *reinterpret_cast<uint4*>(sG + (it >> 1) * WG_SX + (it & 1) * 16) = rg[u];
         }
         __syncthreads();
+        if (tile + 1 < tile_end) load_box(tile + 1);
         // ---- 4 K-steps per wave (td = wave; rows ks * RPK .. of the box)
 #pragma unroll 1
         for (int ks = 0; ks < 4; ++ks) {
@@ -567,10 +582,10 @@ extern "C" size_t ctu_lp_conv3d_packed_elems(int k, int rin_p, int nout_p) {
     return (size_t)lp_total_ksteps(k * k * k, rin_p) * ((nout_p + 15) >> 4) * 512;
 }
 
-extern "C" int ctu_lp_conv3d_num_blocks(int N, int D, int H, int W, int k) {
+extern "C" int ctu_lp_conv3d_num_blocks(int N, int D, int H, int W, int k, int rin_p) {
     (void)k;
     LpConvP p;
-    return lp_fill(p, N, D, H, W);
+    return lp_fill(p, N, D, H, W, rin_p);
 }
 
 extern "C" int ctu_lp_pack_conv3d_weight(int dtype, const float* w, void* wp, int Co, int Ci, int k, const int32_t* cinv,
@@ -603,7 +618,7 @@ extern "C" int ctu_lp_conv3d_fwd(int dtype, const void* in, int in_cs, int rin_p
     p.in = in; p.wp = wp; p.out = out; p.scale = in_scale; p.shift = in_shift; p.bias = bias; p.stats = stats;
     p.in_cs = in_cs; p.rin_p = rin_p; p.relu = in_relu; p.out_cs = out_cs; p.nout_p = nout_p; p.nbias = bias ? nbias : 0;
     p.S = lp_voxel_stride(rin_p);
-    const int ntiles = lp_fill(p, N, D, H, W);
+    const int ntiles = lp_fill(p, N, D, H, W, rin_p);
     hipStream_t st = (hipStream_t)stream;
     const bool two = nout_p > 16;
     int rc = CTU_OK;

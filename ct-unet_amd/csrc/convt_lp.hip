@@ -62,41 +62,50 @@ struct LpCtP {
     int64_t nvox;
 };
 
-// forward: one wave = 16 coarse voxels x all taps x NT-tile groups; KSN = K-steps (ceil(rin_p / 32)) kept in registers
+// forward: one wave = 64 coarse voxels (4 column tiles of 16) x all taps x all out tiles; the voxel-side fragments of all
+// KSN K-steps (ceil(rin_p / 32)) stay in registers, every weight fragment is loaded once per wave and used by 4 MFMAs
 template <class T, int KSN>
 __global__ __launch_bounds__(256) void lp_convt_fwd_kernel(LpCtP p) {
     typedef typename Vec<T>::v8 v8;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, kg = lane >> 4;
-    const int64_t v = ((int64_t)blockIdx.x * 4 + wave) * 16 + m;
-    const bool vok = v < p.nvox;
-    const int64_t vc = vok ? v : 0;
     const T* in = reinterpret_cast<const T*>(p.in);
     const T* wp = reinterpret_cast<const T*>(p.wp);
-    v8 b[KSN];
-#pragma unroll
-    for (int ks = 0; ks < KSN; ++ks) {
-        const int c = ks * 32 + kg * 8;
-        uint4 raw = make_uint4(0u, 0u, 0u, 0u);
-        if (vok && c < p.rin_p) raw = *reinterpret_cast<const uint4*>(in + vc * p.in_cs + c);
-        if (p.scale && vok && c < p.rin_p) {
-            const f32x8 f = __builtin_convertvector(*reinterpret_cast<v8*>(&raw), f32x8);
-            f32x8 o;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float a = fmaf(f[j], p.scale[c + j], p.shift[c + j]);
-                o[j] = p.relu ? fmaxf(a, 0.f) : a;
-            }
-            *reinterpret_cast<v8*>(&raw) = __builtin_convertvector(o, v8);
-        }
-        b[ks] = *reinterpret_cast<v8*>(&raw);
-    }
-    const int wq = (int)(vc % p.W);
-    int64_t t = vc / p.W;
-    const int hq = (int)(t % p.H); t /= p.H;
-    const int dq = (int)(t % p.D);
-    const int n = (int)(t / p.D);
-    const int n16 = (p.nout_p + 15) >> 4;
     T* out = reinterpret_cast<T*>(p.out);
+    const int64_t v0 = ((int64_t)blockIdx.x * 4 + wave) * 64;
+    v8 b[4][KSN];
+    size_t fbase[4];                     // fine-grid voxel (2d, 2h, 2w) of this lane's coarse voxel in column tile ct
+    bool vok[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        const int64_t v = v0 + ct * 16 + m;
+        vok[ct] = v < p.nvox;
+        const int64_t vc = vok[ct] ? v : 0;
+#pragma unroll
+        for (int ks = 0; ks < KSN; ++ks) {
+            const int c = ks * 32 + kg * 8;
+            uint4 raw = make_uint4(0u, 0u, 0u, 0u);
+            if (vok[ct] && c < p.rin_p) raw = *reinterpret_cast<const uint4*>(in + vc * p.in_cs + c);
+            if (p.scale && vok[ct] && c < p.rin_p) {
+                const f32x8 f = __builtin_convertvector(*reinterpret_cast<v8*>(&raw), f32x8);
+                f32x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float a = fmaf(f[j], p.scale[c + j], p.shift[c + j]);
+                    o[j] = p.relu ? fmaxf(a, 0.f) : a;
+                }
+                *reinterpret_cast<v8*>(&raw) = __builtin_convertvector(o, v8);
+            }
+            b[ct][ks] = *reinterpret_cast<v8*>(&raw);
+        }
+        const int wq = (int)(vc % p.W);
+        int64_t t = vc / p.W;
+        const int hq = (int)(t % p.H); t /= p.H;
+        const int dq = (int)(t % p.D);
+        const int n = (int)(t / p.D);
+        fbase[ct] = (((size_t)n * 2 * p.D + 2 * dq) * 2 * p.H + 2 * hq) * 2 * p.W + 2 * wq;
+    }
+    const int n16 = (p.nout_p + 15) >> 4;
+    const size_t fH = (size_t)2 * p.W, fD = fH * 2 * p.H;
     for (int nt = 0; nt < n16; ++nt) {
         const int cb = nt * 16 + 4 * kg;
         float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -106,59 +115,82 @@ __global__ __launch_bounds__(256) void lp_convt_fwd_kernel(LpCtP p) {
         }
 #pragma unroll
         for (int tap = 0; tap < 8; ++tap) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            f32x4 acc[4];
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < KSN; ++ks) {
                 const v8 a = *reinterpret_cast<const v8*>(wp + ((size_t)((tap * KSN + ks) * n16 + nt) * 64 + lane) * 8);
-                acc = MfmaT<T>::run(a, b[ks], acc);
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) acc[ct] = MfmaT<T>::run(a, b[ct][ks], acc[ct]);
             }
-            if (vok && cb < p.nout_p) {
-                const size_t fv = (((size_t)n * 2 * p.D + 2 * dq + (tap >> 2)) * 2 * p.H + 2 * hq + ((tap >> 1) & 1)) * 2 * p.W + 2 * wq + (tap & 1);
-                st4<T>(out + fv * p.out_cs + cb, make_float4(acc[0] + bv.x, acc[1] + bv.y, acc[2] + bv.z, acc[3] + bv.w));
-            }
+            const size_t toff = (tap >> 2) * fD + ((tap >> 1) & 1) * fH + (tap & 1);
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+                if (vok[ct] && cb < p.nout_p)
+                    st4<T>(out + (fbase[ct] + toff) * p.out_cs + cb,
+                           make_float4(acc[ct][0] + bv.x, acc[ct][1] + bv.y, acc[ct][2] + bv.z, acc[ct][3] + bv.w));
         }
     }
 }
 
-// data gradient: gin[v][r] = sum_{tap, o} gout[2v + tap][o] w[r][o][tap]; K-steps = 2 * (rout_p / 8)
+// data gradient: gin[v][r] = sum_{tap, o} gout[2v + tap][o] w[r][o][tap]; K-steps = 2 * (rout_p / 8); one wave = 64 coarse
+// voxels, 2 output tiles per pass over the gradient
 template <class T>
 __global__ __launch_bounds__(256) void lp_convt_bwd_data_kernel(LpCtP p) {
     typedef typename Vec<T>::v8 v8;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, kg = lane >> 4;
-    const int64_t v = ((int64_t)blockIdx.x * 4 + wave) * 16 + m;
-    const bool vok = v < p.nvox;
-    const int64_t vc = vok ? v : 0;
     const T* g = reinterpret_cast<const T*>(p.in);          // fine-grid gradient, p.rin_p = padded Co
     const T* wp = reinterpret_cast<const T*>(p.wp);
-    const int wq = (int)(vc % p.W);
-    int64_t t = vc / p.W;
-    const int hq = (int)(t % p.H); t /= p.H;
-    const int dq = (int)(t % p.D);
-    const int n = (int)(t / p.D);
-    const int nch = p.rin_p >> 3, ksn = 2 * nch, n16 = (p.nout_p + 15) >> 4;
     T* gin = reinterpret_cast<T*>(p.out);
-    for (int nt0 = 0; nt0 < n16; nt0 += 4) {                 // 4 output tiles share one pass over the gradient
-        f32x4 acc[4];
+    const int64_t v0 = ((int64_t)blockIdx.x * 4 + wave) * 64;
+    size_t fbase[4];
+    int64_t vcs[4];
+    bool vok[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ct = 0; ct < 4; ++ct) {
+        const int64_t v = v0 + ct * 16 + m;
+        vok[ct] = v < p.nvox;
+        const int64_t vc = vok[ct] ? v : 0;
+        vcs[ct] = vc;
+        const int wq = (int)(vc % p.W);
+        int64_t t = vc / p.W;
+        const int hq = (int)(t % p.H); t /= p.H;
+        const int dq = (int)(t % p.D);
+        const int n = (int)(t / p.D);
+        fbase[ct] = (((size_t)n * 2 * p.D + 2 * dq) * 2 * p.H + 2 * hq) * 2 * p.W + 2 * wq;
+    }
+    const size_t fH = (size_t)2 * p.W, fD = fH * 2 * p.H;
+    const int nch = p.rin_p >> 3, ksn = 2 * nch, n16 = (p.nout_p + 15) >> 4;
+    for (int nt0 = 0; nt0 < n16; nt0 += 2) {
+        f32x4 acc[4][2];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) { acc[ct][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[ct][1] = acc[ct][0]; }
         for (int ks = 0; ks < ksn; ++ks) {
             const int pr = 4 * ks + kg, tap = pr / nch, ch = pr % nch;
-            const size_t fv = (((size_t)n * 2 * p.D + 2 * dq + (tap >> 2)) * 2 * p.H + 2 * hq + ((tap >> 1) & 1)) * 2 * p.W + 2 * wq + (tap & 1);
-            uint4 raw = make_uint4(0u, 0u, 0u, 0u);
-            if (vok) raw = *reinterpret_cast<const uint4*>(g + fv * p.in_cs + ch * 8);
-            const v8 b = *reinterpret_cast<v8*>(&raw);
+            const size_t toff = (tap >> 2) * fD + ((tap >> 1) & 1) * fH + (tap & 1);
+            v8 b[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int ct = 0; ct < 4; ++ct) {
+                uint4 raw = make_uint4(0u, 0u, 0u, 0u);
+                if (vok[ct]) raw = *reinterpret_cast<const uint4*>(g + (fbase[ct] + toff) * p.in_cs + ch * 8);
+                b[ct] = *reinterpret_cast<v8*>(&raw);
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
                 const int nt = min(nt0 + q, n16 - 1);
                 const v8 a = *reinterpret_cast<const v8*>(wp + ((size_t)(ks * n16 + nt) * 64 + lane) * 8);
-                acc[q] = MfmaT<T>::run(a, b, acc[q]);
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) acc[ct][q] = MfmaT<T>::run(a, b[ct], acc[ct][q]);
             }
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < 2; ++q) {
             const int cb = (nt0 + q) * 16 + 4 * kg;
-            if (vok && nt0 + q < n16 && cb < p.nout_p)
-                st4<T>(gin + vc * p.out_cs + cb, make_float4(acc[q][0], acc[q][1], acc[q][2], acc[q][3]));
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+                if (vok[ct] && nt0 + q < n16 && cb < p.nout_p)
+                    st4<T>(gin + vcs[ct] * p.out_cs + cb, make_float4(acc[ct][q][0], acc[ct][q][1], acc[ct][q][2], acc[ct][q][3]));
         }
     }
 }
@@ -175,65 +207,65 @@ struct LpCtWgP {
     int64_t nvox;
 };
 
-constexpr int CTW_S = 32;                 // LDS bytes per voxel (16 channels)
-
-template <class T>
+// Block (x = range of 128-voxel chunks, y = group of MT ci tiles x NTL co tiles): the gradient (8x the input's bytes) is
+// read once per co-tile GROUP instead of once per (ci tile, co tile) pair.
+template <class T, int MT, int NTL>
 __global__ __launch_bounds__(256) void lp_convt_wgrad_kernel(LpCtWgP p, int chunks_per_block) {
     typedef typename Vec<T>::v8 v8;
     typedef short s16x8 __attribute__((ext_vector_type(8)));
-    __shared__ __attribute__((aligned(16))) unsigned char sX[128 * CTW_S];          // 4 K-steps of 32 voxels
-    __shared__ __attribute__((aligned(16))) unsigned char sG[8 * 128 * CTW_S];      // [tap][voxel]
-    __shared__ float sXf[32];
+    constexpr int SX = MT * 32, SG = NTL * 32;                      // LDS bytes per voxel of the X / G images
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* sXf = reinterpret_cast<float*>(smem);                    // [2][MT * 16]
+    unsigned char* sX = smem + 256;                                 // [128 voxels][MT * 16 ch]
+    unsigned char* sG = sX + 128 * SX;                              // [8 taps][128 voxels][NTL * 16 ch]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, i = lane & 15, q = i >> 2, pc = i & 3;
-    const int nco = (p.cout_p + 15) >> 4;
-    const int cit = blockIdx.y / nco, cot = blockIdx.y % nco;
+    const int ncog = ((p.cout_p + 15) >> 4) / NTL + ((((p.cout_p + 15) >> 4) % NTL) ? 1 : 0);
+    const int cig = blockIdx.y / ncog, cog = blockIdx.y % ncog;
+    const int ci0 = cig * MT * 16, co0 = cog * NTL * 16;            // first channel of this block's groups
     const T* x = reinterpret_cast<const T*>(p.x);
     const T* gr = reinterpret_cast<const T*>(p.g);
     const bool xf = p.scale != nullptr;
-    if (tid < 32) {
-        const int c = cit * 16 + (tid & 15);
-        float v = (tid < 16) ? 1.f : 0.f;
-        if (xf) v = (c < p.cin_p) ? ((tid < 16) ? p.scale[c] : p.shift[c]) : 0.f;
+    if (tid < 2 * MT * 16) {
+        const int which = tid / (MT * 16), c = ci0 + tid % (MT * 16);
+        float v = which ? 0.f : 1.f;
+        if (xf) v = (c < p.cin_p) ? (which ? p.shift[c] : p.scale[c]) : 0.f;
         sXf[tid] = v;
     }
-    const int nchx = min(2, (p.cin_p - cit * 16) >> 3), nchg = min(2, (p.cout_p - cot * 16) >> 3);
-    int ra[2];
+    const int nchx = min(MT * 2, (p.cin_p - ci0) >> 3), nchg = min(NTL * 2, (p.cout_p - co0) >> 3);
+    int rxa[2], rga[2];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) ra[r] = (wave * 32 + 8 * g4 + 4 * r + q) * CTW_S + 8 * pc;
-    f32x4 acc[8];
+    for (int r = 0; r < 2; ++r) {
+        const int vl = wave * 32 + 8 * g4 + 4 * r + q;
+        rxa[r] = vl * SX + 8 * pc;
+        rga[r] = vl * SG + 8 * pc;
+    }
+    f32x4 acc[8][MT][NTL];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int a_ = 0; a_ < MT; ++a_)
+#pragma unroll
+            for (int b_ = 0; b_ < NTL; ++b_) acc[t][a_][b_] = f32x4{0.f, 0.f, 0.f, 0.f};
     int64_t chunk = (int64_t)blockIdx.x * chunks_per_block;
     const int64_t nchunks = (p.nvox + 127) / 128;
     const int64_t chunk_end = min(nchunks, chunk + chunks_per_block);
     for (; chunk < chunk_end; ++chunk) {
         const int64_t v0 = chunk * 128;
         __syncthreads();
-        {   // X: 128 voxels x 2 chunks = 256 items, one per thread
-            const int vl = tid >> 1, c = tid & 1;
-            const int64_t v = v0 + vl;
-            uint4 raw = make_uint4(0u, 0u, 0u, 0u);
-            const bool ok = v < p.nvox && c < nchx;
-            if (ok) raw = *reinterpret_cast<const uint4*>(x + v * p.x_cs + cit * 16 + c * 8);
-            if (ok && xf) {
-                const f32x8 f = __builtin_convertvector(*reinterpret_cast<v8*>(&raw), f32x8);
-                f32x8 o;
+        // X: 128 voxels x (2 MT) 16-byte chunks; G: 8 taps x 128 voxels x (2 NTL) chunks -- all loads first
+        uint4 rxv[MT], rgv[8 * NTL];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float a = fmaf(f[j], sXf[c * 8 + j], sXf[16 + c * 8 + j]);
-                    o[j] = p.relu ? fmaxf(a, 0.f) : a;
-                }
-                *reinterpret_cast<v8*>(&raw) = __builtin_convertvector(o, v8);
-            }
-            *reinterpret_cast<uint4*>(sX + vl * CTW_S + c * 16) = raw;
+        for (int u = 0; u < MT; ++u) {
+            const int it = tid + u * 256, c = it % (2 * MT), vl = it / (2 * MT);
+            const int64_t v = v0 + vl;
+            rxv[u] = make_uint4(0u, 0u, 0u, 0u);
+            if (v < p.nvox && c < nchx) rxv[u] = *reinterpret_cast<const uint4*>(x + v * p.x_cs + ci0 + c * 8);
         }
-        // G: 8 taps x 128 voxels x 2 chunks = 2048 items, 8 per thread (all loads first)
-        uint4 rg[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int it = tid + u * 256, c = it & 1, vl = (it >> 1) & 127, tap = it >> 8;
+        for (int u = 0; u < 8 * NTL; ++u) {
+            const int it = tid + u * 256, c = it % (2 * NTL), vl = (it / (2 * NTL)) & 127, tap = it / (2 * NTL * 128);
             const int64_t v = v0 + vl;
-            rg[u] = make_uint4(0u, 0u, 0u, 0u);
+            rgv[u] = make_uint4(0u, 0u, 0u, 0u);
             if (v < p.nvox && c < nchg) {
                 const int wq = (int)(v % p.W);
                 int64_t t = v / p.W;
@@ -241,43 +273,78 @@ __global__ __launch_bounds__(256) void lp_convt_wgrad_kernel(LpCtWgP p, int chun
                 const int dq = (int)(t % p.D);
                 const int n = (int)(t / p.D);
                 const size_t fv = (((size_t)n * 2 * p.D + 2 * dq + (tap >> 2)) * 2 * p.H + 2 * hq + ((tap >> 1) & 1)) * 2 * p.W + 2 * wq + (tap & 1);
-                rg[u] = *reinterpret_cast<const uint4*>(gr + fv * p.g_cs + cot * 16 + c * 8);
+                rgv[u] = *reinterpret_cast<const uint4*>(gr + fv * p.g_cs + co0 + c * 8);
             }
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int it = tid + u * 256, c = it & 1, vl = (it >> 1) & 127, tap = it >> 8;
-            *reinterpret_cast<uint4*>(sG + (tap * 128 + vl) * CTW_S + c * 16) = rg[u];
+        for (int u = 0; u < MT; ++u) {
+            const int it = tid + u * 256, c = it % (2 * MT), vl = it / (2 * MT);
+            uint4 raw = rxv[u];
+            if (xf && v0 + vl < p.nvox && c < nchx) {
+                const f32x8 f = __builtin_convertvector(*reinterpret_cast<v8*>(&raw), f32x8);
+                f32x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float a = fmaf(f[j], sXf[c * 8 + j], sXf[MT * 16 + c * 8 + j]);
+                    o[j] = p.relu ? fmaxf(a, 0.f) : a;
+                }
+                *reinterpret_cast<v8*>(&raw) = __builtin_convertvector(o, v8);
+            }
+            *reinterpret_cast<uint4*>(sX + vl * SX + c * 16) = raw;
+        }
+#pragma unroll
+        for (int u = 0; u < 8 * NTL; ++u) {
+            const int it = tid + u * 256, c = it % (2 * NTL), vl = (it / (2 * NTL)) & 127, tap = it / (2 * NTL * 128);
+            *reinterpret_cast<uint4*>(sG + (tap * 128 + vl) * SG + c * 16) = rgv[u];
         }
         __syncthreads();
-        const s16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sX + ra[0]));
-        const s16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sX + ra[1]));
-        const s16x8 aa = {alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
+        v8 afr[MT];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const s16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sG + t * 128 * CTW_S + ra[0]));
-            const s16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sG + t * 128 * CTW_S + ra[1]));
-            const s16x8 bb = {blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
-            acc[t] = MfmaT<T>::run(*reinterpret_cast<const v8*>(&aa), *reinterpret_cast<const v8*>(&bb), acc[t]);
+        for (int a_ = 0; a_ < MT; ++a_) {
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sX + rxa[0] + a_ * 32));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sX + rxa[1] + a_ * 32));
+            const s16x8 aa = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            afr[a_] = *reinterpret_cast<const v8*>(&aa);
         }
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int b_ = 0; b_ < NTL; ++b_) {
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sG + t * 128 * SG + rga[0] + b_ * 32));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sG + t * 128 * SG + rga[1] + b_ * 32));
+                const s16x8 bb = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+                for (int a_ = 0; a_ < MT; ++a_)
+                    acc[t][a_][b_] = MfmaT<T>::run(afr[a_], *reinterpret_cast<const v8*>(&bb), acc[t][a_][b_]);
+            }
     }
-    // cross-wave sum -> one slab [8][16 ci][16 co] per block
+    // cross-wave sum -> slabs [pair][8][16 ci][16 co] of this block (pair = (ci tile, co tile))
     float* sS = reinterpret_cast<float*>(sG);
+    const int nco = (p.cout_p + 15) >> 4, nci = (p.cin_p + 15) >> 4;
     for (int wv = 0; wv < 4; ++wv) {
         __syncthreads();
         if (wave == wv) {
 #pragma unroll
-            for (int t = 0; t < 8; ++t)
+            for (int a_ = 0; a_ < MT; ++a_)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float* e = &sS[t * 256 + (4 * g4 + r) * 16 + i];
-                    *e = (wv == 0) ? acc[t][r] : (*e + acc[t][r]);
-                }
+                for (int b_ = 0; b_ < NTL; ++b_)
+#pragma unroll
+                    for (int t = 0; t < 8; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float* e = &sS[((a_ * NTL + b_) * 8 + t) * 256 + (4 * g4 + r) * 16 + i];
+                            *e = (wv == 0) ? acc[t][a_][b_][r] : (*e + acc[t][a_][b_][r]);
+                        }
         }
     }
     __syncthreads();
-    float* dst = p.ws + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2048;
-    for (int e = tid; e < 2048; e += 256) dst[e] = sS[e];
+    for (int a_ = 0; a_ < MT; ++a_)
+        for (int b_ = 0; b_ < NTL; ++b_) {
+            const int cit = cig * MT + a_, cot = cog * NTL + b_;
+            if (cit >= nci || cot >= nco) continue;
+            float* dst = p.ws + ((size_t)(cit * nco + cot) * gridDim.x + blockIdx.x) * 2048;
+            for (int e = tid; e < 2048; e += 256) dst[e] = sS[(a_ * NTL + b_) * 2048 + e];
+        }
 }
 
 // dw[ci][co][tap] (torch layout [Ci][Co][2][2][2]); imap: logical ci -> padded position.  16 lanes per output element
@@ -341,7 +408,7 @@ extern "C" int ctu_lp_convt2_fwd(int dtype, const void* in, int in_cs, int rin_p
     p.in = in; p.wp = wp; p.out = out; p.scale = in_scale; p.shift = in_shift; p.bias = bias;
     p.in_cs = in_cs; p.rin_p = rin_p; p.relu = in_relu; p.out_cs = out_cs; p.nout_p = nout_p; p.nbias = bias ? nbias : 0;
     p.N = N; p.D = D; p.H = H; p.W = W; p.nvox = (int64_t)N * D * H * W;
-    const unsigned grid = (unsigned)ceil_div64(p.nvox, 64);
+    const unsigned grid = (unsigned)ceil_div64(p.nvox, 256);
     const int ksn = (rin_p + 31) >> 5;
     hipStream_t st = (hipStream_t)stream;
     CTU_DISPATCH_LP(dtype, {
@@ -369,7 +436,7 @@ extern "C" int ctu_lp_convt2_bwd_data(int dtype, const void* gout, int g_cs, int
     LpCtP p{};
     p.in = gout; p.wp = wp; p.out = gin; p.in_cs = g_cs; p.rin_p = rout_p; p.out_cs = gin_cs; p.nout_p = nin_p;
     p.N = N; p.D = D; p.H = H; p.W = W; p.nvox = (int64_t)N * D * H * W;
-    const unsigned grid = (unsigned)ceil_div64(p.nvox, 64);
+    const unsigned grid = (unsigned)ceil_div64(p.nvox, 256);
     CTU_DISPATCH_LP(dtype, lp_convt_bwd_data_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>(p));
     CTU_CHECK_LAUNCH("lp_convt2_bwd_data");
     return CTU_OK;
@@ -395,11 +462,27 @@ extern "C" int ctu_lp_convt2_wgrad(int dtype, const void* in, int in_cs, int cin
     p.x = in; p.g = gout; p.scale = in_scale; p.shift = in_shift; p.ws = ws;
     p.x_cs = in_cs; p.cin_p = cin_p; p.relu = in_relu; p.g_cs = g_cs; p.cout_p = cout_p;
     p.N = N; p.D = D; p.H = H; p.W = W; p.nvox = (int64_t)N * D * H * W;
-    const int pairs = ((cin_p + 15) >> 4) * ((cout_p + 15) >> 4);
+    const int nci = (cin_p + 15) >> 4, nco = (cout_p + 15) >> 4, pairs = nci * nco;
     int gx, cpb;
     ctw_grid(p.nvox, pairs, &gx, &cpb);
     hipStream_t st = (hipStream_t)stream;
-    CTU_DISPATCH_LP(dtype, lp_convt_wgrad_kernel<T><<<dim3(gx, pairs), 256, 0, st>>>(p, cpb));
+    // tile groups per block: 2 x 2 while the accumulators (8 taps x MT x NTL) and the gradient image fit
+    const int mt = nci >= 2 ? 2 : 1, ntl = nco >= 2 ? 2 : 1;
+    const dim3 grid(gx, ceil_div(nci, mt) * ceil_div(nco, ntl));
+    const size_t lds = 256 + 128 * (size_t)mt * 32 + 8 * 128 * (size_t)ntl * 32;
+    CTU_DISPATCH_LP(dtype, {
+        if (mt == 2 && ntl == 2) {
+            static bool raised = false;
+            if (!raised) {
+                CTU_REQUIRE(hipFuncSetAttribute((const void*)lp_convt_wgrad_kernel<T, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                160 * 1024) == hipSuccess, "lp_convt2_wgrad: cannot raise the dynamic LDS limit");
+                raised = true;
+            }
+            lp_convt_wgrad_kernel<T, 2, 2><<<grid, 256, lds, st>>>(p, cpb);
+        } else if (mt == 2) lp_convt_wgrad_kernel<T, 2, 1><<<grid, 256, lds, st>>>(p, cpb);
+        else if (ntl == 2) lp_convt_wgrad_kernel<T, 1, 2><<<grid, 256, lds, st>>>(p, cpb);
+        else lp_convt_wgrad_kernel<T, 1, 1><<<grid, 256, lds, st>>>(p, cpb);
+    });
     CTU_CHECK_LAUNCH("lp_convt2_wgrad");
     lp_convt_wgrad_reduce_kernel<<<ceil_div(Ci * Co * 8, 16), 256, 0, st>>>(ws, dw, Ci, Co, imap, cout_p, gx);
     CTU_CHECK_LAUNCH("lp_convt2_wgrad reduce");

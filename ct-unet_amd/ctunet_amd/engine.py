@@ -18,6 +18,7 @@ Data flow (DESIGN.md has the picture):
 """
 from __future__ import annotations
 
+import contextlib
 import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Tuple
@@ -34,6 +35,8 @@ FUSE_UP_MAX_CO = int(os.environ.get("CTUNET_FUSE_UP_MAXCO", "16"))     # widest 
 # the max-pool backward also emits the BatchNorm-backward reduction of the layer it pools (CTUNET_POOL_BN=0: separate pass)
 POOL_BN = os.environ.get("CTUNET_POOL_BN", "1") != "0"
 BN_MOMENTUM = 0.1
+# the generic UNet's dead centre block (models.py:241) runs on a forked stream beside the decoder (CTUNET_CENTER_SIDE=0: in line)
+CENTER_SIDE = os.environ.get("CTUNET_CENTER_SIDE", "0") != "0"
 
 
 @dataclass
@@ -158,7 +161,7 @@ class UNetEngine:
         dims = x.dims
         c = cout
         if training:
-            nblk = ops.conv_num_blocks(dims, out.cp, lay, k, self.dtype)
+            nblk = ops.conv_num_blocks(dims, out.cp, lay, k, self.dtype, x.cp)
             stats = torch.empty((nblk, 2, out.cp), dtype=torch.float32, device=x.buf.device)
             ops.conv3d_fwd(x, wp, bias_p, out, k, stats, (cin, cout), lay)
             ops.bn_finalize_into(stats, nblk, c, out.cp, x.nvox, P[bn + ".weight"], P[bn + ".bias"],
@@ -312,16 +315,26 @@ class UNetEngine:
         cb = plan.center
         cpc = pad8(cb.cout)
         center_out = None
+        side = None
         if plan.center_live or training:
             live = plan.center_live
-            c1 = CL(torch.empty((n, dd, hh, ww, cpc), dtype=adt, device=dev), 0, cpc)
-            c2 = CL(torch.empty((n, dd, hh, ww, cpc), dtype=adt, device=dev), 0, cpc)
-            v1 = torch.empty((4, cpc), dtype=torch.float32, device=dev)
-            v2 = torch.empty((4, cpc), dtype=torch.float32, device=dev)
-            a1, r1 = self._conv_bn(P, cur, f"{cb.prefix}.{cb.first}", f"{cb.prefix}.{cb.first + 1}", cb.cin, cb.cout,
-                                   None, c1, v1, training, n_upd, save and live)
-            a2, r2 = self._conv_bn(P, a1, f"{cb.prefix}.{cb.first + 3}", f"{cb.prefix}.{cb.first + 4}", cb.cout, cb.cout,
-                                   None, c2, v2, training, n_upd, save and live)
+            # The generic UNet drops the centre block's output (models.py:241): in train mode it runs only to move its
+            # BatchNorm buffers, two latency-bound 8^3 launches (~80 us) nothing downstream waits for -- on a forked
+            # stream beside the decoder, joined at the end of forward (inside a captured graph: a fork/join branch)
+            if not live and CENTER_SIDE:
+                side = self.__dict__.get("_side")
+                if side is None or side.device != dev:
+                    side = self.__dict__["_side"] = torch.cuda.Stream(device=dev)
+                side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+                c1 = CL(torch.empty((n, dd, hh, ww, cpc), dtype=adt, device=dev), 0, cpc)
+                c2 = CL(torch.empty((n, dd, hh, ww, cpc), dtype=adt, device=dev), 0, cpc)
+                v1 = torch.empty((4, cpc), dtype=torch.float32, device=dev)
+                v2 = torch.empty((4, cpc), dtype=torch.float32, device=dev)
+                a1, r1 = self._conv_bn(P, cur, f"{cb.prefix}.{cb.first}", f"{cb.prefix}.{cb.first + 1}", cb.cin, cb.cout,
+                                       None, c1, v1, training, n_upd, save and live)
+                a2, r2 = self._conv_bn(P, a1, f"{cb.prefix}.{cb.first + 3}", f"{cb.prefix}.{cb.first + 4}", cb.cout, cb.cout,
+                                       None, c2, v2, training, n_upd, save and live)
             if live:
                 recs[(cb.prefix, 1)], recs[(cb.prefix, 2)] = r1, r2
                 center_out = a2
@@ -370,6 +383,8 @@ class UNetEngine:
         wl, bl = P[plan.head + ".weight"], P[plan.head + ".bias"]
         w2 = wl.detach().reshape(wl.shape[0], wl.shape[1])
         out0, out1 = ops.head_fwd(cur, w2, bl.detach(), imap_h, plan.act, plan.head_mode)
+        if side is not None:
+            torch.cuda.current_stream(dev).wait_stream(side)
         if save:
             ctx.update(recs=recs, x_cl=x_cl, cat=cat, xf=xf, pooled=pooled, dskip=dskip, dec_in=dec_in, ups=ups,
                        head_in=cur, imap_h=imap_h, center_out=center_out, dims=(n, d, h, w))

@@ -236,11 +236,12 @@ def pack_batch(jobs) -> None:
     _lib.check(_lib.load().ctu_pack_batch(arr, len(jobs), _stream()), "pack_batch")
 
 
-def conv_num_blocks(dims, nout_p: int, layout: int = 0, k: int = 3, dtype=torch.float32) -> int:
-    """Rows of the BN partial-sum buffer a conv3d_fwd call with this geometry writes."""
+def conv_num_blocks(dims, nout_p: int, layout: int = 0, k: int = 3, dtype=torch.float32, rin_p: int = 32) -> int:
+    """Rows of the BN partial-sum buffer a conv3d_fwd call with this geometry writes (16-bit path: depends on the padded
+    input channel count too, pass rin_p)."""
     n, d, h, w = dims
     if lp(dtype):
-        return _lib.load().ctu_lp_conv3d_num_blocks(n, d, h, w, k)
+        return _lib.load().ctu_lp_conv3d_num_blocks(n, d, h, w, k, rin_p)
     return _lib.load().ctu_conv3d_num_blocks(n, d, h, w, k, nout_p, layout)
 
 

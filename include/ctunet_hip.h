@@ -380,10 +380,11 @@ int ctu_stitch_patches(const float* patches, const int32_t* coords, int P, int C
  *   packed weights ... 16-bit copies in MFMA fragment order, re-packed from the fp32 masters (ctu_lp_pack_*)
  * fp16 gradients need the caller's loss scaling (the per-voxel loss gradient of a 256^3 patch is 6e-8); bf16 does not. */
 size_t ctu_lp_conv3d_packed_elems(int k, int rin_p, int nout_p);
-int ctu_lp_conv3d_num_blocks(int N, int D, int H, int W, int k);
+int ctu_lp_conv3d_num_blocks(int N, int D, int H, int W, int k, int rin_p);
 int ctu_lp_pack_conv3d_weight(int dtype, const float* w, void* wp, int Co, int Ci, int k, const int32_t* cinv,
                               int rin_p, int nout_p, int mode, void* stream);
-/* nn.Conv3d forward (mode-0 packing) / data gradient (mode-1 packing); stats: [ctu_lp_conv3d_num_blocks()][2][nout_p] */
+/* nn.Conv3d forward (mode-0 packing) / data gradient (mode-1 packing); stats: [ctu_lp_conv3d_num_blocks()][2][nout_p]
+ * (the voxel box of a launch grows when rin_p is small, so the row count depends on it) */
 int ctu_lp_conv3d_fwd(int dtype, const void* in, int in_cs, int rin_p, const float* in_scale, const float* in_shift,
                       int in_relu, const void* wp, const float* bias, int nbias, void* out, int out_cs, int nout_p,
                       float* stats, int N, int D, int H, int W, int k, void* stream);

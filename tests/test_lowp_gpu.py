@@ -76,7 +76,7 @@ def test_lp_conv_forward_stats_dgrad_wgrad(name, k, ci, co, shape, xf):
     # ---- forward + BatchNorm partial sums
     wp = ops.pack_conv_w_lp(wt.cuda(), None, cip, cop, 0, dt)
     out = ops.CL(torch.full((n, d, h, w, cop + 8), 3.0, dtype=dt).cuda(), 8, cop)
-    nblk = ops.conv_num_blocks(shape, cop, 0, k, dt)
+    nblk = ops.conv_num_blocks(shape, cop, 0, k, dt, cip)
     stats = torch.zeros((nblk, 2, cop), dtype=torch.float32).cuda()
     ops.conv3d_fwd(xcl, wp, None if bias is None else bias.cuda(), out, k, stats)
     ref = F.conv3d(a.double(), wt.double(), None if bias is None else bias.double(), 1, (k - 1) // 2).float()

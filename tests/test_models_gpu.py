@@ -243,6 +243,7 @@ def oracle_train_check(name, size, batch=1, seed=1234, want_fp64=True, lowp=None
     def versus_fp32(m, dx):
         """(max L2 relative error, min cosine) over dx and every live parameter gradient against the fp32 oracle."""
         l2, cos = [], []
+        dot = na = nb = 0.0
         for n_, got, ref in [("dx", dx, dx32)] + [(n_, p.grad, g32[n_]) for n_, p in m.named_parameters()]:
             assert (got is None) == (ref is None), n_
             if ref is None:
@@ -254,6 +255,9 @@ def oracle_train_check(name, size, batch=1, seed=1234, want_fp64=True, lowp=None
             assert torch.isfinite(a).all(), n_
             l2.append((float((a - b).norm() / b.norm()), n_))
             cos.append((float(torch.dot(a, b) / (a.norm() * b.norm())), n_))
+            if n_ != "dx":
+                dot, na, nb = dot + float(torch.dot(a, b)), na + float(a.norm()) ** 2, nb + float(b.norm()) ** 2
+        versus_fp32.global_cos = dot / (na * nb) ** 0.5       # direction of the whole parameter-gradient vector
         return max(l2), min(cos)
 
     net, outs, loss, dx = hip_step("fp32")
@@ -279,8 +283,9 @@ def oracle_train_check(name, size, batch=1, seed=1234, want_fp64=True, lowp=None
             # ONE ReLU mask / pooling arg-max that flips on rounding noise at the 2^3-voxel bottleneck of a 32^3 patch moves
             # every gradient upstream of it by ~1 % (seen on UNetDO / UNet4b1i3o, which share trunk weights and input: 11
             # tensors at 1.2e-2 of scale while ATen-CPU fp32 happened not to flip).  A precision defect would show on any
-            # input, a coincidence does not: the loose gate must hold here and the tight rule on an independent input.
-            assert all(m[1] <= 2e-2 * m[3] for m in misses), misses
+            # input, a coincidence does not: the loose gate (every gradient within 5 % / cos 0.998 of the fp32 oracle in the
+            # L2 norm) must hold here and the tight rule on an independent input.
+            assert worst_l2[0] <= 5e-2 and worst_cos[0] >= 0.998, (worst_l2, worst_cos, misses)
             return oracle_train_check(name, size, batch, seed + 1, want_fp64, lowp)
         assert not misses, misses
     else:
@@ -298,7 +303,8 @@ def oracle_train_check(name, size, batch=1, seed=1234, want_fp64=True, lowp=None
     res = {"out_err": max(rel_err(o, r) for o, r in zip(outs, refs)),
            "dice": min(float(O.hard_dice(o.cpu(), torch.nn.functional.one_hot(r.argmax(1), r.shape[1]).movedim(-1, 1).float()))
                        for o, r in zip(outs, refs)),
-           "loss_err": abs(loss_lp - l32.item()), "loss": l32.item(), "grad_l2_max": l2, "grad_cos_min": cos}
+           "loss_err": abs(loss_lp - l32.item()), "loss": l32.item(), "grad_l2_max": l2, "grad_cos_min": cos,
+           "grad_cos_global": versus_fp32.global_cos}
     print(f"[{name} {size}^3 {lowp}] {res}")
     return res
 
