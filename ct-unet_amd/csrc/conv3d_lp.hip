@@ -101,6 +101,10 @@ __global__ __launch_bounds__(256) void lp_conv_fwd_kernel(LpConvP p) {
     float* sXf = reinterpret_cast<float*>(smem + 2048);             // [2][32] scale / shift of the stage
     float* sRed = reinterpret_cast<float*>(smem + 2048 + 256);      // [4 waves][NT][2][16]
     unsigned char* sIn = smem + 2048 + 256 + 4 * NT * 32 * 4;       // haloed input box of the stage
+    // k = 3: the stage's weight fragments sit in LDS behind the box (<= 27 NT KB); a K-step then waits for LDS, not for L2.
+    // k = 5 (125 K-steps per full stage) keeps reading them from global through the register ring.
+    constexpr bool WLDS = KS == 3;
+    unsigned char* sW = sIn + (size_t)HV * p.S;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 15, kg = lane >> 4;
     const int S = p.S;
     int t = blockIdx.x;
@@ -147,13 +151,33 @@ __global__ __launch_bounds__(256) void lp_conv_fwd_kernel(LpConvP p) {
         // first weight fragments of the stage (independent of LDS)
         const int kbase = st * TAPS;
         v8 ring[PF][NT];
+        if constexpr (!WLDS) {
 #pragma unroll
-        for (int u = 0; u < PF; ++u)
+            for (int u = 0; u < PF; ++u)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int tile = min(nt0 + nt, n16 - 1), s = min(u, ks - 1);
-                ring[u][nt] = *reinterpret_cast<const v8*>(wp + ((size_t)((kbase + s) * n16 + tile) * 64 + lane) * 8);
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int tile = min(nt0 + nt, n16 - 1), s = min(u, ks - 1);
+                    ring[u][nt] = *reinterpret_cast<const v8*>(wp + ((size_t)((kbase + s) * n16 + tile) * 64 + lane) * 8);
+                }
+        } else {
+            // ks * NT fragments of 1 KB: 16-byte pieces, batched branch-free loads (clamped index), L2-resident
+            const int pieces = ks * NT * 64;
+            for (int i0 = tid; i0 < pieces; i0 += 256 * 8) {
+                uint4 w8[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = min(i0 + u * 256, pieces - 1);
+                    const int ln = i & 63, fr = i >> 6, nt = fr % NT, s = fr / NT;
+                    const int tile = min(nt0 + nt, n16 - 1);
+                    w8[u] = *reinterpret_cast<const uint4*>(wp + ((size_t)((kbase + s) * n16 + tile) * 64 + ln) * 8);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = i0 + u * 256;
+                    if (i < pieces) *reinterpret_cast<uint4*>(sW + (size_t)i * 16) = w8[u];
+                }
             }
+        }
         if (xf) __syncthreads();                                    // sXf visible
         // ---- stage the haloed box: 16-byte items (halo voxel, chunk), up to UB loads in flight per thread
         const int items = HV << sh;
@@ -170,15 +194,19 @@ __global__ __launch_bounds__(256) void lp_conv_fwd_kernel(LpConvP p) {
                 const bool ok = live && (unsigned)gd < (unsigned)p.D && (unsigned)gh < (unsigned)p.H && (unsigned)gw < (unsigned)p.W;
                 // bit 30: outside the volume (the ACTIVATED input is zero padded); bits 28-29: chunk within the stage
                 dst[u] = live ? ((v * S + c * 16) | (c << 26) | (ok ? 0 : 0x40000000)) : -1;
-                raw[u] = make_uint4(0u, 0u, 0u, 0u);
-                if (ok) raw[u] = *reinterpret_cast<const uint4*>(in + ((((size_t)n * p.D + gd) * p.H + gh) * p.W + gw) * p.in_cs +
-                                                                 st * LP_SC + c * 8);
+                // branch-free: every item loads (a clamped, always valid address); the out-of-volume ones are zeroed below.
+                // A load behind a per-item branch is waited for before the next one is issued (one HBM round trip each).
+                const int cd = min(max(gd, 0), p.D - 1), chh = min(max(gh, 0), p.H - 1), cw = min(max(gw, 0), p.W - 1);
+                const int cc = live ? c : 0;
+                raw[u] = *reinterpret_cast<const uint4*>(in + ((((size_t)n * p.D + cd) * p.H + chh) * p.W + cw) * p.in_cs +
+                                                         st * LP_SC + cc * 8);
             }
 #pragma unroll
             for (int u = 0; u < UB; ++u) {
                 if (dst[u] < 0) continue;
                 uint4 r = raw[u];
-                if (xf && !(dst[u] & 0x40000000)) {
+                if (dst[u] & 0x40000000) r = make_uint4(0u, 0u, 0u, 0u);
+                else if (xf) {
                     const int c8 = ((dst[u] >> 26) & 3) * 8;               // first channel of the item within the stage
                     const f32x8 f = __builtin_convertvector(*reinterpret_cast<v8*>(&r), f32x8);
                     f32x8 o;
@@ -194,6 +222,21 @@ __global__ __launch_bounds__(256) void lp_conv_fwd_kernel(LpConvP p) {
         }
         __syncthreads();
         // ---- K loop
+        if constexpr (WLDS) {
+            for (int s = 0; s < ks; ++s) {
+                const int koff = sK[4 * s + kg] + hb0;
+                v8 a[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) a[nt] = *reinterpret_cast<const v8*>(sW + ((size_t)(s * NT + nt) * 64 + lane) * 16);
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const int cto = (BW == 32) ? ((ct >> 1) * HW + (ct & 1) * 16) * S : ct * CT_ROWSTEP * HW * S;
+                    const v8 b = *reinterpret_cast<const v8*>(sIn + koff + cto);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[ct][nt] = Mfma<T>::run(a[nt], b, acc[ct][nt]);
+                }
+            }
+        } else
         for (int s0 = 0; s0 < ks; s0 += PF) {
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
@@ -305,7 +348,9 @@ template <class T, int KS, int NT, int TH, int BW>
 int lp_conv_launch_box(LpConvP& p, int ntiles, hipStream_t st) {
     constexpr int PK = (KS - 1) / 2;
     const int hv = (4 + 2 * PK) * (TH + 2 * PK) * (BW + 2 * PK);
-    const size_t lds = 2048 + 256 + 4 * NT * 32 * 4 + (size_t)hv * p.S;
+    const int nch_max = (p.rin_p >= LP_SC ? LP_SC : p.rin_p) >> 3;
+    const size_t wlds = KS == 3 ? (size_t)lp_ksteps(27, nch_max) * NT * 1024 : 0;
+    const size_t lds = 2048 + 256 + 4 * NT * 32 * 4 + (size_t)hv * p.S + wlds;
     CTU_REQUIRE(lds <= 160 * 1024, "lp_conv3d_fwd: LDS box of %zu bytes", lds);
     const int n16 = (p.nout_p + 15) >> 4;
     const dim3 grid(ntiles, ceil_div(n16, NT));
@@ -401,20 +446,22 @@ __global__ __launch_bounds__(256) void lp_conv_wgrad_kernel(LpWgP p, int tiles_p
             const int gd = d0 + pd + ((KS == 3) ? -1 : kd - PK), gh = h0 + ph - PK, gw = w0 + pw - PK;
             const bool ok = it < HV * 2 && c < nchx && (unsigned)gd < (unsigned)p.D && (unsigned)gh < (unsigned)p.H &&
                             (unsigned)gw < (unsigned)p.W;
-            rx[u] = make_uint4(0u, 0u, 0u, 0u);
-            if (ok) {
-                rx[u] = *reinterpret_cast<const uint4*>(x + ((((size_t)n * p.D + gd) * p.H + gh) * p.W + gw) * p.x_cs + cit * 16 + c * 8);
-                okx |= 1u << u;
-            }
+            // branch-free loads from clamped addresses (see lp_conv_fwd_kernel); zeroed at the LDS write
+            const int cd = min(max(gd, 0), p.D - 1), chh = min(max(gh, 0), p.H - 1), cw = min(max(gw, 0), p.W - 1);
+            rx[u] = *reinterpret_cast<const uint4*>(x + ((((size_t)n * p.D + cd) * p.H + chh) * p.W + cw) * p.x_cs + cit * 16 +
+                                                    (c < nchx ? c : 0) * 8);
+            okx |= ok ? (1u << u) : 0u;
         }
 #pragma unroll
         for (int u = 0; u < NG; ++u) {
             const int it = tid + u * 256, v = it >> 1, c = it & 1;
             const int tw = v % BW, t2 = v / BW, th = t2 % TH, td = t2 / TH;
             const int gd = d0 + td, gh = h0 + th, gw = w0 + tw;
-            rg[u] = make_uint4(0u, 0u, 0u, 0u);
-            if (c < nchg && gd < p.D && gh < p.H && gw < p.W)
-                rg[u] = *reinterpret_cast<const uint4*>(gr + ((((size_t)n * p.D + gd) * p.H + gh) * p.W + gw) * p.g_cs + cot * 16 + c * 8);
+            const bool ok = c < nchg && gd < p.D && gh < p.H && gw < p.W;
+            const int cd = min(gd, p.D - 1), chh = min(gh, p.H - 1), cw = min(gw, p.W - 1);
+            const uint4 r = *reinterpret_cast<const uint4*>(gr + ((((size_t)n * p.D + cd) * p.H + chh) * p.W + cw) * p.g_cs + cot * 16 +
+                                                            (c < nchg ? c : 0) * 8);
+            rg[u] = ok ? r : make_uint4(0u, 0u, 0u, 0u);
         }
     };
     if (tile < tile_end) load_box(tile);
@@ -426,7 +473,8 @@ __global__ __launch_bounds__(256) void lp_conv_wgrad_kernel(LpWgP p, int tiles_p
             const int it = tid + u * 256;
             if (it >= HV * 2) continue;
             uint4 r = rx[u];
-            if (xf && ((okx >> u) & 1u)) {
+            if (!((okx >> u) & 1u)) r = make_uint4(0u, 0u, 0u, 0u);
+            else if (xf) {
                 const int c8 = (it & 1) * 8;
                 const f32x8 f = __builtin_convertvector(*reinterpret_cast<v8*>(&r), f32x8);
                 f32x8 o;

@@ -62,30 +62,32 @@ struct LpCtP {
     int64_t nvox;
 };
 
-// forward: one wave = 64 coarse voxels (4 column tiles of 16) x all taps x all out tiles; the voxel-side fragments of all
+// forward: one wave = 16 CTV coarse voxels (CTV column tiles of 16: 4 on large grids, 1 where that would leave CUs idle) x all
+// taps x all out tiles; the voxel-side fragments of all
 // KSN K-steps (ceil(rin_p / 32)) stay in registers, every weight fragment is loaded once per wave and used by 4 MFMAs
-template <class T, int KSN>
+template <class T, int KSN, int CTV>
 __global__ __launch_bounds__(256) void lp_convt_fwd_kernel(LpCtP p) {
     typedef typename Vec<T>::v8 v8;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, kg = lane >> 4;
     const T* in = reinterpret_cast<const T*>(p.in);
     const T* wp = reinterpret_cast<const T*>(p.wp);
     T* out = reinterpret_cast<T*>(p.out);
-    const int64_t v0 = ((int64_t)blockIdx.x * 4 + wave) * 64;
-    v8 b[4][KSN];
-    size_t fbase[4];                     // fine-grid voxel (2d, 2h, 2w) of this lane's coarse voxel in column tile ct
-    bool vok[4];
+    const int64_t v0 = ((int64_t)blockIdx.x * 4 + wave) * (16 * CTV);
+    v8 b[CTV][KSN];
+    size_t fbase[CTV];                   // fine-grid voxel (2d, 2h, 2w) of this lane's coarse voxel in column tile ct
+    bool vok[CTV];
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
+    for (int ct = 0; ct < CTV; ++ct) {
         const int64_t v = v0 + ct * 16 + m;
         vok[ct] = v < p.nvox;
         const int64_t vc = vok[ct] ? v : 0;
 #pragma unroll
         for (int ks = 0; ks < KSN; ++ks) {
             const int c = ks * 32 + kg * 8;
-            uint4 raw = make_uint4(0u, 0u, 0u, 0u);
-            if (vok[ct] && c < p.rin_p) raw = *reinterpret_cast<const uint4*>(in + vc * p.in_cs + c);
-            if (p.scale && vok[ct] && c < p.rin_p) {
+            const bool live = vok[ct] && c < p.rin_p;                      // branch-free load from a valid address, zeroed after
+            uint4 raw = *reinterpret_cast<const uint4*>(in + vc * p.in_cs + (c < p.rin_p ? c : 0));
+            if (!live) raw = make_uint4(0u, 0u, 0u, 0u);
+            if (p.scale && live) {
                 const f32x8 f = __builtin_convertvector(*reinterpret_cast<v8*>(&raw), f32x8);
                 f32x8 o;
 #pragma unroll
@@ -115,18 +117,18 @@ __global__ __launch_bounds__(256) void lp_convt_fwd_kernel(LpCtP p) {
         }
 #pragma unroll
         for (int tap = 0; tap < 8; ++tap) {
-            f32x4 acc[4];
+            f32x4 acc[CTV];
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int ct = 0; ct < CTV; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < KSN; ++ks) {
                 const v8 a = *reinterpret_cast<const v8*>(wp + ((size_t)((tap * KSN + ks) * n16 + nt) * 64 + lane) * 8);
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) acc[ct] = MfmaT<T>::run(a, b[ct][ks], acc[ct]);
+                for (int ct = 0; ct < CTV; ++ct) acc[ct] = MfmaT<T>::run(a, b[ct][ks], acc[ct]);
             }
             const size_t toff = (tap >> 2) * fD + ((tap >> 1) & 1) * fH + (tap & 1);
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct)
+            for (int ct = 0; ct < CTV; ++ct)
                 if (vok[ct] && cb < p.nout_p)
                     st4<T>(out + (fbase[ct] + toff) * p.out_cs + cb,
                            make_float4(acc[ct][0] + bv.x, acc[ct][1] + bv.y, acc[ct][2] + bv.z, acc[ct][3] + bv.w));
@@ -136,19 +138,19 @@ __global__ __launch_bounds__(256) void lp_convt_fwd_kernel(LpCtP p) {
 
 // data gradient: gin[v][r] = sum_{tap, o} gout[2v + tap][o] w[r][o][tap]; K-steps = 2 * (rout_p / 8); one wave = 64 coarse
 // voxels, 2 output tiles per pass over the gradient
-template <class T>
+template <class T, int CTV>
 __global__ __launch_bounds__(256) void lp_convt_bwd_data_kernel(LpCtP p) {
     typedef typename Vec<T>::v8 v8;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, kg = lane >> 4;
     const T* g = reinterpret_cast<const T*>(p.in);          // fine-grid gradient, p.rin_p = padded Co
     const T* wp = reinterpret_cast<const T*>(p.wp);
     T* gin = reinterpret_cast<T*>(p.out);
-    const int64_t v0 = ((int64_t)blockIdx.x * 4 + wave) * 64;
-    size_t fbase[4];
-    int64_t vcs[4];
-    bool vok[4];
+    const int64_t v0 = ((int64_t)blockIdx.x * 4 + wave) * (16 * CTV);
+    size_t fbase[CTV];
+    int64_t vcs[CTV];
+    bool vok[CTV];
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
+    for (int ct = 0; ct < CTV; ++ct) {
         const int64_t v = v0 + ct * 16 + m;
         vok[ct] = v < p.nvox;
         const int64_t vc = vok[ct] ? v : 0;
@@ -163,17 +165,17 @@ __global__ __launch_bounds__(256) void lp_convt_bwd_data_kernel(LpCtP p) {
     const size_t fH = (size_t)2 * p.W, fD = fH * 2 * p.H;
     const int nch = p.rin_p >> 3, ksn = 2 * nch, n16 = (p.nout_p + 15) >> 4;
     for (int nt0 = 0; nt0 < n16; nt0 += 2) {
-        f32x4 acc[4][2];
+        f32x4 acc[CTV][2];
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) { acc[ct][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[ct][1] = acc[ct][0]; }
+        for (int ct = 0; ct < CTV; ++ct) { acc[ct][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[ct][1] = acc[ct][0]; }
         for (int ks = 0; ks < ksn; ++ks) {
             const int pr = 4 * ks + kg, tap = pr / nch, ch = pr % nch;
             const size_t toff = (tap >> 2) * fD + ((tap >> 1) & 1) * fH + (tap & 1);
-            v8 b[4];
+            v8 b[CTV];
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) {
-                uint4 raw = make_uint4(0u, 0u, 0u, 0u);
-                if (vok[ct]) raw = *reinterpret_cast<const uint4*>(g + (fbase[ct] + toff) * p.in_cs + ch * 8);
+            for (int ct = 0; ct < CTV; ++ct) {
+                uint4 raw = *reinterpret_cast<const uint4*>(g + (fbase[ct] + toff) * p.in_cs + ch * 8);     // vc is clamped: valid
+                if (!vok[ct]) raw = make_uint4(0u, 0u, 0u, 0u);
                 b[ct] = *reinterpret_cast<v8*>(&raw);
             }
 #pragma unroll
@@ -181,14 +183,14 @@ __global__ __launch_bounds__(256) void lp_convt_bwd_data_kernel(LpCtP p) {
                 const int nt = min(nt0 + q, n16 - 1);
                 const v8 a = *reinterpret_cast<const v8*>(wp + ((size_t)(ks * n16 + nt) * 64 + lane) * 8);
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) acc[ct][q] = MfmaT<T>::run(a, b[ct], acc[ct][q]);
+                for (int ct = 0; ct < CTV; ++ct) acc[ct][q] = MfmaT<T>::run(a, b[ct], acc[ct][q]);
             }
         }
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int cb = (nt0 + q) * 16 + 4 * kg;
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct)
+            for (int ct = 0; ct < CTV; ++ct)
                 if (vok[ct] && nt0 + q < n16 && cb < p.nout_p)
                     st4<T>(gin + vcs[ct] * p.out_cs + cb, make_float4(acc[ct][q][0], acc[ct][q][1], acc[ct][q][2], acc[ct][q][3]));
         }
@@ -258,22 +260,24 @@ __global__ __launch_bounds__(256) void lp_convt_wgrad_kernel(LpCtWgP p, int chun
         for (int u = 0; u < MT; ++u) {
             const int it = tid + u * 256, c = it % (2 * MT), vl = it / (2 * MT);
             const int64_t v = v0 + vl;
-            rxv[u] = make_uint4(0u, 0u, 0u, 0u);
-            if (v < p.nvox && c < nchx) rxv[u] = *reinterpret_cast<const uint4*>(x + v * p.x_cs + ci0 + c * 8);
+            const int64_t vv = v < p.nvox ? v : p.nvox - 1;
+            rxv[u] = *reinterpret_cast<const uint4*>(x + vv * p.x_cs + ci0 + (c < nchx ? c : 0) * 8);
+            if (!(v < p.nvox && c < nchx)) rxv[u] = make_uint4(0u, 0u, 0u, 0u);
         }
 #pragma unroll
         for (int u = 0; u < 8 * NTL; ++u) {
             const int it = tid + u * 256, c = it % (2 * NTL), vl = (it / (2 * NTL)) & 127, tap = it / (2 * NTL * 128);
             const int64_t v = v0 + vl;
-            rgv[u] = make_uint4(0u, 0u, 0u, 0u);
-            if (v < p.nvox && c < nchg) {
-                const int wq = (int)(v % p.W);
-                int64_t t = v / p.W;
+            {
+                const int64_t vv = v < p.nvox ? v : p.nvox - 1;
+                const int wq = (int)(vv % p.W);
+                int64_t t = vv / p.W;
                 const int hq = (int)(t % p.H); t /= p.H;
                 const int dq = (int)(t % p.D);
                 const int n = (int)(t / p.D);
                 const size_t fv = (((size_t)n * 2 * p.D + 2 * dq + (tap >> 2)) * 2 * p.H + 2 * hq + ((tap >> 1) & 1)) * 2 * p.W + 2 * wq + (tap & 1);
-                rgv[u] = *reinterpret_cast<const uint4*>(gr + fv * p.g_cs + co0 + c * 8);
+                rgv[u] = *reinterpret_cast<const uint4*>(gr + fv * p.g_cs + co0 + (c < nchg ? c : 0) * 8);
+                if (!(v < p.nvox && c < nchg)) rgv[u] = make_uint4(0u, 0u, 0u, 0u);
             }
         }
 #pragma unroll
@@ -408,21 +412,24 @@ extern "C" int ctu_lp_convt2_fwd(int dtype, const void* in, int in_cs, int rin_p
     p.in = in; p.wp = wp; p.out = out; p.scale = in_scale; p.shift = in_shift; p.bias = bias;
     p.in_cs = in_cs; p.rin_p = rin_p; p.relu = in_relu; p.out_cs = out_cs; p.nout_p = nout_p; p.nbias = bias ? nbias : 0;
     p.N = N; p.D = D; p.H = H; p.W = W; p.nvox = (int64_t)N * D * H * W;
-    const unsigned grid = (unsigned)ceil_div64(p.nvox, 256);
     const int ksn = (rin_p + 31) >> 5;
     hipStream_t st = (hipStream_t)stream;
+    const bool wide = p.nvox > 65536;                  // 64 voxels per wave only where that still fills the chip
+    const unsigned grid = (unsigned)ceil_div64(p.nvox, wide ? 256 : 64);
+#define CTU_CT_FWD(K)                                                                   \
+    case K:                                                                             \
+        if (wide) lp_convt_fwd_kernel<T, K, 4><<<grid, 256, 0, st>>>(p);                \
+        else lp_convt_fwd_kernel<T, K, 1><<<grid, 256, 0, st>>>(p);                     \
+        break;
     CTU_DISPATCH_LP(dtype, {
         switch (ksn) {
-            case 1: lp_convt_fwd_kernel<T, 1><<<grid, 256, 0, st>>>(p); break;
-            case 2: lp_convt_fwd_kernel<T, 2><<<grid, 256, 0, st>>>(p); break;
-            case 3: lp_convt_fwd_kernel<T, 3><<<grid, 256, 0, st>>>(p); break;
-            case 4: lp_convt_fwd_kernel<T, 4><<<grid, 256, 0, st>>>(p); break;
-            case 5: lp_convt_fwd_kernel<T, 5><<<grid, 256, 0, st>>>(p); break;
-            case 6: lp_convt_fwd_kernel<T, 6><<<grid, 256, 0, st>>>(p); break;
-            case 7: lp_convt_fwd_kernel<T, 7><<<grid, 256, 0, st>>>(p); break;
-            default: lp_convt_fwd_kernel<T, 8><<<grid, 256, 0, st>>>(p); break;
+            CTU_CT_FWD(1) CTU_CT_FWD(2) CTU_CT_FWD(3) CTU_CT_FWD(4) CTU_CT_FWD(5) CTU_CT_FWD(6) CTU_CT_FWD(7)
+            default:
+                if (wide) lp_convt_fwd_kernel<T, 8, 4><<<grid, 256, 0, st>>>(p);
+                else lp_convt_fwd_kernel<T, 8, 1><<<grid, 256, 0, st>>>(p);
         }
     });
+#undef CTU_CT_FWD
     CTU_CHECK_LAUNCH("lp_convt2_fwd");
     return CTU_OK;
 }
@@ -436,8 +443,12 @@ extern "C" int ctu_lp_convt2_bwd_data(int dtype, const void* gout, int g_cs, int
     LpCtP p{};
     p.in = gout; p.wp = wp; p.out = gin; p.in_cs = g_cs; p.rin_p = rout_p; p.out_cs = gin_cs; p.nout_p = nin_p;
     p.N = N; p.D = D; p.H = H; p.W = W; p.nvox = (int64_t)N * D * H * W;
-    const unsigned grid = (unsigned)ceil_div64(p.nvox, 256);
-    CTU_DISPATCH_LP(dtype, lp_convt_bwd_data_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>(p));
+    const bool wide = p.nvox > 65536;
+    const unsigned grid = (unsigned)ceil_div64(p.nvox, wide ? 256 : 64);
+    CTU_DISPATCH_LP(dtype, {
+        if (wide) lp_convt_bwd_data_kernel<T, 4><<<grid, 256, 0, (hipStream_t)stream>>>(p);
+        else lp_convt_bwd_data_kernel<T, 1><<<grid, 256, 0, (hipStream_t)stream>>>(p);
+    });
     CTU_CHECK_LAUNCH("lp_convt2_bwd_data");
     return CTU_OK;
 }
