@@ -223,18 +223,47 @@ __global__ __launch_bounds__(256) void lp_conv_fwd_kernel(LpConvP p) {
         __syncthreads();
         // ---- K loop
         if constexpr (WLDS) {
-            for (int s = 0; s < ks; ++s) {
-                const int koff = sK[4 * s + kg] + hb0;
-                v8 a[NT];
+            // A compiler-scheduled "read, wait, MFMA" chain pays one LDS latency (~100 cycles) per 16-cycle MFMA.  Instead: the
+            // fragments of half a K-step (CT / 2 column tiles) are read as one batch while the other half's MFMAs run.
+            constexpr int HB = CT / 2;
+            auto read_b = [&](int koff, int half, v8 (&bb)[HB]) {
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) a[nt] = *reinterpret_cast<const v8*>(sW + ((size_t)(s * NT + nt) * 64 + lane) * 16);
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct) {
+                for (int j = 0; j < HB; ++j) {
+                    const int ct = half * HB + j;
                     const int cto = (BW == 32) ? ((ct >> 1) * HW + (ct & 1) * 16) * S : ct * CT_ROWSTEP * HW * S;
-                    const v8 b = *reinterpret_cast<const v8*>(sIn + koff + cto);
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) acc[ct][nt] = Mfma<T>::run(a[nt], b, acc[ct][nt]);
+                    bb[j] = *reinterpret_cast<const v8*>(sIn + koff + cto);
                 }
+            };
+            v8 b0[HB], b1[HB], a[NT];
+            int koff = sK[kg] + hb0;
+            int koff_n = sK[4 * min(1, ks - 1) + kg] + hb0;         // the offset table is read TWO K-steps ahead: its (in-order)
+#pragma unroll                                                      // LDS read is then the oldest in flight when it is needed
+            for (int nt = 0; nt < NT; ++nt) a[nt] = *reinterpret_cast<const v8*>(sW + ((size_t)nt * 64 + lane) * 16);
+            read_b(koff, 0, b0);
+            for (int s = 0; s < ks; ++s) {
+                const int koff_nn = sK[4 * min(s + 2, ks - 1) + kg] + hb0;
+                read_b(koff, 1, b1);                                // second half of K-step s: lands under the first half's MFMAs
+                const int sn = min(s + 1, ks - 1);
+                v8 an[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) an[nt] = *reinterpret_cast<const v8*>(sW + ((size_t)(sn * NT + nt) * 64 + lane) * 16);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < HB; ++j)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[j][nt] = Mfma<T>::run(a[nt], b0[j], acc[j][nt]);
+                __builtin_amdgcn_sched_barrier(0);
+                read_b(koff_n, 0, b0);                              // first half of K-step s + 1: under the second half's MFMAs
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < HB; ++j)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[HB + j][nt] = Mfma<T>::run(a[nt], b1[j], acc[HB + j][nt]);
+                __builtin_amdgcn_sched_barrier(0);
+                koff = koff_n;
+                koff_n = koff_nn;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) a[nt] = an[nt];
             }
         } else
         for (int s0 = 0; s0 < ks; s0 += PF) {
@@ -506,15 +535,33 @@ __global__ __launch_bounds__(256) void lp_conv_wgrad_kernel(LpWgP p, int tiles_p
                 const s16x8 bb = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 b = *reinterpret_cast<const v8*>(&bb);
             }
+            // taps in groups (k = 3: the 9 taps of one kd plane, k = 5: the 5 of one kh row): the NEXT group's transposed
+            // fragment reads are issued before this group's MFMAs, so a tap no longer pays its own LDS latency
+            constexpr int GT = (KS == 3) ? 9 : KS, NGRP = NTAP / GT;
+            typedef short s16x8 __attribute__((ext_vector_type(8)));
+            auto read_grp = [&](int grp, s16x8 (&fr)[GT]) {
 #pragma unroll
-            for (int t = 0; t < NTAP; ++t) {
-                const int kdd = (KS == 3) ? t / 9 : 0, kh = (KS == 3) ? (t / 3) % 3 : t / KS, kw = (KS == 3) ? t % 3 : t % KS;
-                const int to = ((kdd * HH + kh) * HW + kw) * WG_SX;
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sX + xa[0] + xo + to));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sX + xa[1] + xo + to));
-                typedef short s16x8 __attribute__((ext_vector_type(8)));
-                const s16x8 aa = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                acc[t] = Mfma<T>::run(*reinterpret_cast<const v8*>(&aa), b, acc[t]);
+                for (int j = 0; j < GT; ++j) {
+                    const int t = grp * GT + j;
+                    const int kdd = (KS == 3) ? t / 9 : 0, kh = (KS == 3) ? (t / 3) % 3 : t / KS, kw = (KS == 3) ? t % 3 : t % KS;
+                    const int to = ((kdd * HH + kh) * HW + kw) * WG_SX;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sX + xa[0] + xo + to));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sX + xa[1] + xo + to));
+                    fr[j] = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
+            };
+            s16x8 f0[GT], f1[GT];
+            read_grp(0, f0);
+#pragma unroll
+            for (int grp = 0; grp < NGRP; ++grp) {
+                s16x8 (&cur)[GT] = (grp & 1) ? f1 : f0;
+                s16x8 (&nxt)[GT] = (grp & 1) ? f0 : f1;
+                if (grp + 1 < NGRP) read_grp(grp + 1, nxt);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < GT; ++j)
+                    acc[grp * GT + j] = Mfma<T>::run(*reinterpret_cast<const v8*>(&cur[j]), b, acc[grp * GT + j]);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
@@ -668,7 +715,8 @@ extern "C" int ctu_lp_conv3d_fwd(int dtype, const void* in, int in_cs, int rin_p
     p.S = lp_voxel_stride(rin_p);
     const int ntiles = lp_fill(p, N, D, H, W, rin_p);
     hipStream_t st = (hipStream_t)stream;
-    const bool two = nout_p > 16;
+    // two out tiles per block share one staged box -- unless that leaves CUs idle (small volumes: one tile per block)
+    const bool two = nout_p > 16 && (int64_t)ntiles * ceil_div((nout_p + 15) >> 4, 2) >= 256;
     int rc = CTU_OK;
     CTU_DISPATCH_LP(dtype, {
         if (k == 3) rc = two ? lp_conv_launch<T, 3, 2>(p, ntiles, st) : lp_conv_launch<T, 3, 1>(p, ntiles, st);
