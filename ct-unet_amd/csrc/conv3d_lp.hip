@@ -43,12 +43,11 @@ template <> struct Mfma<f16_t> {
 // wp[kstep (global over stages)][16-wide out tile][lane][8]: element j of lane l = A[row l&15][k = 8 (l>>4) + j] of that
 // K-step: pair p = 4 s + (l >> 4) -> (tap, chunk) = (p / nch, p % nch) of the stage (nch chunks), zero for the padding pairs.
 template <class T, int KS>
-__global__ void lp_pack_conv_w_kernel(const float* __restrict__ w, T* __restrict__ wp, int Co, int Ci, const int32_t* __restrict__ cinv,
-                                      int rin_p, int nout_p, int mode) {
+__device__ __forceinline__ void lp_pack_conv_w_elem(int idx, const float* __restrict__ w, T* __restrict__ wp, int Co, int Ci,
+                                                    const int32_t* __restrict__ cinv, int rin_p, int nout_p, int mode) {
     constexpr int TAPS = KS * KS * KS;
     const int n16 = (nout_p + 15) >> 4;
     const int total = lp_total_ksteps(TAPS, rin_p) * n16 * 512;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const int j = idx & 7, lane = (idx >> 3) & 63;
     const int nt = (idx >> 9) % n16, kg = (idx >> 9) / n16;
@@ -69,6 +68,66 @@ __global__ void lp_pack_conv_w_kernel(const float* __restrict__ w, T* __restrict
         }
     }
     wp[idx] = (T)v;
+}
+
+template <class T, int KS>
+__global__ void lp_pack_conv_w_kernel(const float* __restrict__ w, T* __restrict__ wp, int Co, int Ci, const int32_t* __restrict__ cinv,
+                                      int rin_p, int nout_p, int mode) {
+    lp_pack_conv_w_elem<T, KS>(blockIdx.x * blockDim.x + threadIdx.x, w, wp, Co, Ci, cinv, rin_p, nout_p, mode);
+}
+
+// ConvTranspose3d(C, C, 2, 2) packing (layouts: convt_lp.hip): mode 0 wp[tap][ks][n16][lane][8], mode 1 wp[ks][n16][lane][8]
+template <class T>
+__device__ __forceinline__ void lp_pack_convt_w_elem(int idx, const float* __restrict__ w, T* __restrict__ wp, int Ci, int Co,
+                                                     const int32_t* __restrict__ cinv, int rin_p, int nout_p, int mode) {
+    const int j = idx & 7, lane = (idx >> 3) & 63, m = lane & 15, kg = lane >> 4;
+    float v = 0.f;
+    if (mode == 0) {
+        const int ksn = (rin_p + 31) >> 5, n16 = (nout_p + 15) >> 4;
+        if (idx >= 8 * ksn * n16 * 512) return;
+        int r = idx >> 9;
+        const int nt = r % n16; r /= n16;
+        const int ks = r % ksn;
+        const int tap = r / ksn;
+        const int rp = ks * 32 + kg * 8 + j, o = nt * 16 + m;
+        const int ci = (rp < rin_p) ? (cinv ? cinv[rp] : (rp < Ci ? rp : -1)) : -1;
+        if (ci >= 0 && o < Co) v = w[((size_t)ci * Co + o) * 8 + tap];
+    } else {
+        const int nch = rin_p >> 3, ksn = 2 * nch, n16 = (nout_p + 15) >> 4;
+        if (idx >= ksn * n16 * 512) return;
+        int r = idx >> 9;
+        const int nt = r % n16;
+        const int ks = r / n16;
+        const int pr = 4 * ks + kg, tap = pr / nch, ch = pr % nch;
+        const int o = ch * 8 + j, rp = nt * 16 + m;
+        const int ci = (rp < nout_p) ? (cinv ? cinv[rp] : (rp < Ci ? rp : -1)) : -1;
+        if (ci >= 0 && o < Co) v = w[((size_t)ci * Co + o) * 8 + tap];
+    }
+    wp[idx] = (T)v;
+}
+
+// every 16-bit weight copy of a network in ONE launch: the job table travels in the kernel arguments (blockIdx.y = job)
+constexpr int LP_PACK_MAXJ = 48;
+struct LpPackTable {
+    ctu_pack_job j[LP_PACK_MAXJ];
+};
+
+template <class T>
+__global__ void lp_pack_batch_kernel(LpPackTable tb) {
+    const ctu_pack_job& jb = tb.j[blockIdx.y];
+    T* wp = reinterpret_cast<T*>(jb.wp);
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x;; idx += gridDim.x * blockDim.x) {
+        int total;
+        if (jb.kind == 0) total = lp_total_ksteps(jb.k * jb.k * jb.k, jb.rin_p) * ((jb.nout_p + 15) >> 4) * 512;
+        else total = (jb.mode == 0 ? 8 * ((jb.rin_p + 31) >> 5) : 2 * (jb.rin_p >> 3)) * ((jb.nout_p + 15) >> 4) * 512;
+        if (idx >= total) break;
+        if (jb.kind == 0) {
+            if (jb.k == 3) lp_pack_conv_w_elem<T, 3>(idx, jb.w, wp, jb.Co, jb.Ci, jb.cinv, jb.rin_p, jb.nout_p, jb.mode);
+            else lp_pack_conv_w_elem<T, 5>(idx, jb.w, wp, jb.Co, jb.Ci, jb.cinv, jb.rin_p, jb.nout_p, jb.mode);
+        } else {
+            lp_pack_convt_w_elem<T>(idx, jb.w, wp, jb.Ci, jb.Co, jb.cinv, jb.rin_p, jb.nout_p, jb.mode);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ forward / data gradient
@@ -383,11 +442,12 @@ int lp_conv_launch_box(LpConvP& p, int ntiles, hipStream_t st) {
     CTU_REQUIRE(lds <= 160 * 1024, "lp_conv3d_fwd: LDS box of %zu bytes", lds);
     const int n16 = (p.nout_p + 15) >> 4;
     const dim3 grid(ntiles, ceil_div(n16, NT));
-    static bool raised = false;
-    if (!raised) {
-        CTU_REQUIRE(hipFuncSetAttribute((const void*)lp_conv_fwd_kernel<T, KS, NT, TH, BW>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        160 * 1024) == hipSuccess, "lp_conv3d_fwd: cannot raise the dynamic LDS limit");
-        raised = true;
+    // the dynamic-LDS limit is raised only for launches that need more than the default 64 KB, and only to what they need
+    static size_t raised = 64 * 1024;
+    if (lds > raised) {
+        CTU_REQUIRE(hipFuncSetAttribute((const void*)lp_conv_fwd_kernel<T, KS, NT, TH, BW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess,
+                    "lp_conv3d_fwd: cannot raise the dynamic LDS limit");
+        raised = lds;
     }
     lp_conv_fwd_kernel<T, KS, NT, TH, BW><<<grid, 256, lds, st>>>(p);
     CTU_CHECK_LAUNCH("lp_conv3d_fwd");
@@ -650,11 +710,12 @@ int lp_wgrad_launch(LpWgP& p, int gx, int tpb, int pairs, hipStream_t st) {
     constexpr int NTAP = (KS == 3) ? 27 : KS * KS;
     size_t lds = 128 + (size_t)(HV + NV) * WG_SX;
     if (lds < 128 + (size_t)NTAP * 1024) lds = 128 + (size_t)NTAP * 1024;
-    static bool raised = false;
-    if (!raised) {
-        CTU_REQUIRE(hipFuncSetAttribute((const void*)lp_conv_wgrad_kernel<T, KS, BW>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        160 * 1024) == hipSuccess, "lp_conv3d_wgrad: cannot raise the dynamic LDS limit");
-        raised = true;
+    // the dynamic-LDS limit is raised only for launches that need more than the default 64 KB, and only to what they need
+    static size_t raised = 64 * 1024;
+    if (lds > raised) {
+        CTU_REQUIRE(hipFuncSetAttribute((const void*)lp_conv_wgrad_kernel<T, KS, BW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess,
+                    "lp_conv3d_wgrad: cannot raise the dynamic LDS limit");
+        raised = lds;
     }
     lp_conv_wgrad_kernel<T, KS, BW><<<dim3(gx, pairs, KS == 3 ? 1 : KS), 256, lds, st>>>(p, tpb);
     CTU_CHECK_LAUNCH("lp_conv3d_wgrad");
@@ -762,5 +823,32 @@ extern "C" int ctu_lp_conv3d_wgrad(int dtype, const void* in, int in_cs, int cin
     if (k == 3) lp_wgrad_reduce_kernel<3><<<ceil_div(total, 64), 1024, 0, st>>>(ws, dw, Co, Ci, cinv, cin_p, cout_p, gx);
     else lp_wgrad_reduce_kernel<5><<<ceil_div(total, 64), 1024, 0, st>>>(ws, dw, Co, Ci, cinv, cin_p, cout_p, gx);
     CTU_CHECK_LAUNCH("lp_conv3d_wgrad reduce");
+    return CTU_OK;
+}
+
+// jobs: HOST array of ctu_pack_job (kind 0 = Conv3d [Co,Ci,k,k,k], kind 1 = ConvTranspose3d [Ci,Co,2,2,2]; `layout` unused);
+// wp of each job: 16-bit buffer of ctu_lp_conv3d_packed_elems / ctu_lp_convt_packed_elems elements.
+extern "C" int ctu_lp_pack_batch(int dtype, const ctu_pack_job* jobs, int n, void* stream) {
+    CTU_REQUIRE(jobs && n > 0, "lp_pack_batch: no jobs");
+    hipStream_t st = (hipStream_t)stream;
+    for (int j0 = 0; j0 < n; j0 += LP_PACK_MAXJ) {
+        const int nj = (n - j0) < LP_PACK_MAXJ ? (n - j0) : LP_PACK_MAXJ;
+        LpPackTable tb;
+        size_t mx = 1;
+        for (int j = 0; j < nj; ++j) {
+            const ctu_pack_job& jb = jobs[j0 + j];
+            CTU_REQUIRE(jb.w && jb.wp && (jb.kind == 0 || jb.kind == 1) && (jb.mode == 0 || jb.mode == 1) && jb.rin_p > 0 &&
+                        jb.rin_p % 8 == 0 && jb.nout_p > 0 && jb.nout_p % 8 == 0 && (jb.kind == 1 || jb.k == 3 || jb.k == 5),
+                        "lp_pack_batch: bad job %d", j0 + j);
+            tb.j[j] = jb;
+            const size_t tot = jb.kind == 0 ? ctu_lp_conv3d_packed_elems(jb.k, jb.rin_p, jb.nout_p)
+                                            : (size_t)(jb.mode == 0 ? 8 * ((jb.rin_p + 31) >> 5) : 2 * (jb.rin_p >> 3)) * ((jb.nout_p + 15) >> 4) * 512;
+            if (tot > mx) mx = tot;
+        }
+        int gx = (int)ceil_div64((int64_t)mx, 256 * 4);
+        if (gx > 256) gx = 256;
+        CTU_DISPATCH_LP(dtype, lp_pack_batch_kernel<T><<<dim3(gx, nj), 256, 0, st>>>(tb));
+        CTU_CHECK_LAUNCH("lp_pack_batch");
+    }
     return CTU_OK;
 }

@@ -76,6 +76,8 @@ __global__ __launch_bounds__(256) void lp_convt_fwd_kernel(LpCtP p) {
     v8 b[CTV][KSN];
     size_t fbase[CTV];                   // fine-grid voxel (2d, 2h, 2w) of this lane's coarse voxel in column tile ct
     bool vok[CTV];
+    // all voxel-side loads first (branch-free: a load behind a branch is waited for before the next one is issued)
+    uint4 rawb[CTV][KSN];
 #pragma unroll
     for (int ct = 0; ct < CTV; ++ct) {
         const int64_t v = v0 + ct * 16 + m;
@@ -84,19 +86,41 @@ __global__ __launch_bounds__(256) void lp_convt_fwd_kernel(LpCtP p) {
 #pragma unroll
         for (int ks = 0; ks < KSN; ++ks) {
             const int c = ks * 32 + kg * 8;
-            const bool live = vok[ct] && c < p.rin_p;                      // branch-free load from a valid address, zeroed after
-            uint4 raw = *reinterpret_cast<const uint4*>(in + vc * p.in_cs + (c < p.rin_p ? c : 0));
-            if (!live) raw = make_uint4(0u, 0u, 0u, 0u);
-            if (p.scale && live) {
+            rawb[ct][ks] = *reinterpret_cast<const uint4*>(in + vc * p.in_cs + (c < p.rin_p ? c : 0));
+        }
+    }
+    float scv[KSN][8], shv[KSN][8];
+    if (p.scale) {
+#pragma unroll
+        for (int ks = 0; ks < KSN; ++ks) {
+            const int c = ks * 32 + kg * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                scv[ks][j] = c < p.rin_p ? p.scale[c + j] : 0.f;
+                shv[ks][j] = c < p.rin_p ? p.shift[c + j] : 0.f;
+            }
+        }
+    }
+#pragma unroll
+    for (int ct = 0; ct < CTV; ++ct) {
+        const int64_t v = v0 + ct * 16 + m;
+        const int64_t vc = vok[ct] ? v : 0;
+#pragma unroll
+        for (int ks = 0; ks < KSN; ++ks) {
+            const int c = ks * 32 + kg * 8;
+            const bool live = vok[ct] && c < p.rin_p;
+            uint4 raw = rawb[ct][ks];
+            if (p.scale) {
                 const f32x8 f = __builtin_convertvector(*reinterpret_cast<v8*>(&raw), f32x8);
                 f32x8 o;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float a = fmaf(f[j], p.scale[c + j], p.shift[c + j]);
+                    const float a = fmaf(f[j], scv[ks][j], shv[ks][j]);
                     o[j] = p.relu ? fmaxf(a, 0.f) : a;
                 }
                 *reinterpret_cast<v8*>(&raw) = __builtin_convertvector(o, v8);
             }
+            if (!live) raw = make_uint4(0u, 0u, 0u, 0u);
             b[ct][ks] = *reinterpret_cast<v8*>(&raw);
         }
         const int wq = (int)(vc % p.W);
@@ -115,23 +139,33 @@ __global__ __launch_bounds__(256) void lp_convt_fwd_kernel(LpCtP p) {
             bv.x = cb + 0 < p.nbias ? p.bias[cb + 0] : 0.f; bv.y = cb + 1 < p.nbias ? p.bias[cb + 1] : 0.f;
             bv.z = cb + 2 < p.nbias ? p.bias[cb + 2] : 0.f; bv.w = cb + 3 < p.nbias ? p.bias[cb + 3] : 0.f;
         }
+        // weight fragments of a GROUP of taps are loaded together (<= 16 fragments in flight), then their MFMAs and stores
+        constexpr int TG = KSN <= 2 ? 8 : (KSN <= 4 ? 4 : 2);
 #pragma unroll
-        for (int tap = 0; tap < 8; ++tap) {
-            f32x4 acc[CTV];
+        for (int tg = 0; tg < 8; tg += TG) {
+            v8 aw[TG][KSN];
 #pragma unroll
-            for (int ct = 0; ct < CTV; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int u = 0; u < TG; ++u)
 #pragma unroll
-            for (int ks = 0; ks < KSN; ++ks) {
-                const v8 a = *reinterpret_cast<const v8*>(wp + ((size_t)((tap * KSN + ks) * n16 + nt) * 64 + lane) * 8);
+                for (int ks = 0; ks < KSN; ++ks)
+                    aw[u][ks] = *reinterpret_cast<const v8*>(wp + ((size_t)(((tg + u) * KSN + ks) * n16 + nt) * 64 + lane) * 8);
 #pragma unroll
-                for (int ct = 0; ct < CTV; ++ct) acc[ct] = MfmaT<T>::run(a, b[ct][ks], acc[ct]);
+            for (int u = 0; u < TG; ++u) {
+                const int tap = tg + u;
+                f32x4 acc[CTV];
+#pragma unroll
+                for (int ct = 0; ct < CTV; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KSN; ++ks)
+#pragma unroll
+                    for (int ct = 0; ct < CTV; ++ct) acc[ct] = MfmaT<T>::run(aw[u][ks], b[ct][ks], acc[ct]);
+                const size_t toff = (tap >> 2) * fD + ((tap >> 1) & 1) * fH + (tap & 1);
+#pragma unroll
+                for (int ct = 0; ct < CTV; ++ct)
+                    if (vok[ct] && cb < p.nout_p)
+                        st4<T>(out + (fbase[ct] + toff) * p.out_cs + cb,
+                               make_float4(acc[ct][0] + bv.x, acc[ct][1] + bv.y, acc[ct][2] + bv.z, acc[ct][3] + bv.w));
             }
-            const size_t toff = (tap >> 2) * fD + ((tap >> 1) & 1) * fH + (tap & 1);
-#pragma unroll
-            for (int ct = 0; ct < CTV; ++ct)
-                if (vok[ct] && cb < p.nout_p)
-                    st4<T>(out + (fbase[ct] + toff) * p.out_cs + cb,
-                           make_float4(acc[ct][0] + bv.x, acc[ct][1] + bv.y, acc[ct][2] + bv.z, acc[ct][3] + bv.w));
         }
     }
 }
@@ -168,22 +202,40 @@ __global__ __launch_bounds__(256) void lp_convt_bwd_data_kernel(LpCtP p) {
         f32x4 acc[CTV][2];
 #pragma unroll
         for (int ct = 0; ct < CTV; ++ct) { acc[ct][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[ct][1] = acc[ct][0]; }
-        for (int ks = 0; ks < ksn; ++ks) {
+        // K-step ks + 1's gradient and weight fragments are in flight while K-step ks multiplies
+        auto load_ks = [&](int ks, uint4 (&rb)[CTV], v8 (&ra)[2]) {
             const int pr = 4 * ks + kg, tap = pr / nch, ch = pr % nch;
             const size_t toff = (tap >> 2) * fD + ((tap >> 1) & 1) * fH + (tap & 1);
-            v8 b[CTV];
 #pragma unroll
-            for (int ct = 0; ct < CTV; ++ct) {
-                uint4 raw = *reinterpret_cast<const uint4*>(g + (fbase[ct] + toff) * p.in_cs + ch * 8);     // vc is clamped: valid
-                if (!vok[ct]) raw = make_uint4(0u, 0u, 0u, 0u);
-                b[ct] = *reinterpret_cast<v8*>(&raw);
-            }
+            for (int ct = 0; ct < CTV; ++ct)
+                rb[ct] = *reinterpret_cast<const uint4*>(g + (fbase[ct] + toff) * p.in_cs + ch * 8);     // vc is clamped: valid
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int nt = min(nt0 + q, n16 - 1);
-                const v8 a = *reinterpret_cast<const v8*>(wp + ((size_t)(ks * n16 + nt) * 64 + lane) * 8);
+                ra[q] = *reinterpret_cast<const v8*>(wp + ((size_t)(ks * n16 + nt) * 64 + lane) * 8);
+            }
+        };
+        uint4 rb0[CTV], rb1[CTV];
+        v8 ra0[2], ra1[2];
+        load_ks(0, rb0, ra0);
+        for (int ks = 0; ks < ksn; ks += 2) {
+            load_ks(min(ks + 1, ksn - 1), rb1, ra1);
 #pragma unroll
-                for (int ct = 0; ct < CTV; ++ct) acc[ct][q] = MfmaT<T>::run(a, b[ct], acc[ct][q]);
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int ct = 0; ct < CTV; ++ct) {
+                    uint4 raw = vok[ct] ? rb0[ct] : make_uint4(0u, 0u, 0u, 0u);
+                    acc[ct][q] = MfmaT<T>::run(ra0[q], *reinterpret_cast<v8*>(&raw), acc[ct][q]);
+                }
+            load_ks(min(ks + 2, ksn - 1), rb0, ra0);
+            if (ks + 1 < ksn) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int ct = 0; ct < CTV; ++ct) {
+                        uint4 raw = vok[ct] ? rb1[ct] : make_uint4(0u, 0u, 0u, 0u);
+                        acc[ct][q] = MfmaT<T>::run(ra1[q], *reinterpret_cast<v8*>(&raw), acc[ct][q]);
+                    }
             }
         }
 #pragma unroll
@@ -251,11 +303,10 @@ __global__ __launch_bounds__(256) void lp_convt_wgrad_kernel(LpCtWgP p, int chun
     int64_t chunk = (int64_t)blockIdx.x * chunks_per_block;
     const int64_t nchunks = (p.nvox + 127) / 128;
     const int64_t chunk_end = min(nchunks, chunk + chunks_per_block);
-    for (; chunk < chunk_end; ++chunk) {
-        const int64_t v0 = chunk * 128;
-        __syncthreads();
-        // X: 128 voxels x (2 MT) 16-byte chunks; G: 8 taps x 128 voxels x (2 NTL) chunks -- all loads first
-        uint4 rxv[MT], rgv[8 * NTL];
+    // software pipeline over the 128-voxel chunks: the next chunk's loads are in flight while this one multiplies
+    uint4 rxv[MT], rgv[8 * NTL];
+    auto load_chunk = [&](int64_t ch) {
+        const int64_t v0 = ch * 128;
 #pragma unroll
         for (int u = 0; u < MT; ++u) {
             const int it = tid + u * 256, c = it % (2 * MT), vl = it / (2 * MT);
@@ -268,18 +319,21 @@ __global__ __launch_bounds__(256) void lp_convt_wgrad_kernel(LpCtWgP p, int chun
         for (int u = 0; u < 8 * NTL; ++u) {
             const int it = tid + u * 256, c = it % (2 * NTL), vl = (it / (2 * NTL)) & 127, tap = it / (2 * NTL * 128);
             const int64_t v = v0 + vl;
-            {
-                const int64_t vv = v < p.nvox ? v : p.nvox - 1;
-                const int wq = (int)(vv % p.W);
-                int64_t t = vv / p.W;
-                const int hq = (int)(t % p.H); t /= p.H;
-                const int dq = (int)(t % p.D);
-                const int n = (int)(t / p.D);
-                const size_t fv = (((size_t)n * 2 * p.D + 2 * dq + (tap >> 2)) * 2 * p.H + 2 * hq + ((tap >> 1) & 1)) * 2 * p.W + 2 * wq + (tap & 1);
-                rgv[u] = *reinterpret_cast<const uint4*>(gr + fv * p.g_cs + co0 + (c < nchg ? c : 0) * 8);
-                if (!(v < p.nvox && c < nchg)) rgv[u] = make_uint4(0u, 0u, 0u, 0u);
-            }
+            const int64_t vv = v < p.nvox ? v : p.nvox - 1;
+            const int wq = (int)(vv % p.W);
+            int64_t t = vv / p.W;
+            const int hq = (int)(t % p.H); t /= p.H;
+            const int dq = (int)(t % p.D);
+            const int n = (int)(t / p.D);
+            const size_t fv = (((size_t)n * 2 * p.D + 2 * dq + (tap >> 2)) * 2 * p.H + 2 * hq + ((tap >> 1) & 1)) * 2 * p.W + 2 * wq + (tap & 1);
+            rgv[u] = *reinterpret_cast<const uint4*>(gr + fv * p.g_cs + co0 + (c < nchg ? c : 0) * 8);
+            if (!(v < p.nvox && c < nchg)) rgv[u] = make_uint4(0u, 0u, 0u, 0u);
         }
+    };
+    if (chunk < chunk_end) load_chunk(chunk);
+    for (; chunk < chunk_end; ++chunk) {
+        const int64_t v0 = chunk * 128;
+        __syncthreads();
 #pragma unroll
         for (int u = 0; u < MT; ++u) {
             const int it = tid + u * 256, c = it % (2 * MT), vl = it / (2 * MT);
@@ -302,7 +356,9 @@ __global__ __launch_bounds__(256) void lp_convt_wgrad_kernel(LpCtWgP p, int chun
             *reinterpret_cast<uint4*>(sG + (tap * 128 + vl) * SG + c * 16) = rgv[u];
         }
         __syncthreads();
-        v8 afr[MT];
+        if (chunk + 1 < chunk_end) load_chunk(chunk + 1);
+        // all transposed fragment reads of the chunk first, then the MFMAs
+        v8 afr[MT], bfr[8][NTL];
 #pragma unroll
         for (int a_ = 0; a_ < MT; ++a_) {
             const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sX + rxa[0] + a_ * 32));
@@ -317,10 +373,16 @@ __global__ __launch_bounds__(256) void lp_convt_wgrad_kernel(LpCtWgP p, int chun
                 const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sG + t * 128 * SG + rga[0] + b_ * 32));
                 const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sG + t * 128 * SG + rga[1] + b_ * 32));
                 const s16x8 bb = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                bfr[t][b_] = *reinterpret_cast<const v8*>(&bb);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int b_ = 0; b_ < NTL; ++b_)
 #pragma unroll
                 for (int a_ = 0; a_ < MT; ++a_)
-                    acc[t][a_][b_] = MfmaT<T>::run(afr[a_], *reinterpret_cast<const v8*>(&bb), acc[t][a_][b_]);
-            }
+                    acc[t][a_][b_] = MfmaT<T>::run(afr[a_], bfr[t][b_], acc[t][a_][b_]);
     }
     // cross-wave sum -> slabs [pair][8][16 ci][16 co] of this block (pair = (ci tile, co tile))
     float* sS = reinterpret_cast<float*>(sG);
@@ -483,12 +545,13 @@ extern "C" int ctu_lp_convt2_wgrad(int dtype, const void* in, int in_cs, int cin
     const size_t lds = 256 + 128 * (size_t)mt * 32 + 8 * 128 * (size_t)ntl * 32;
     CTU_DISPATCH_LP(dtype, {
         if (mt == 2 && ntl == 2) {
-            static bool raised = false;
-            if (!raised) {
-                CTU_REQUIRE(hipFuncSetAttribute((const void*)lp_convt_wgrad_kernel<T, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                160 * 1024) == hipSuccess, "lp_convt2_wgrad: cannot raise the dynamic LDS limit");
-                raised = true;
-            }
+            // the dynamic-LDS limit is raised only for launches that need more than the default 64 KB, and only to what they need
+    static size_t raised = 64 * 1024;
+    if (lds > raised) {
+        CTU_REQUIRE(hipFuncSetAttribute((const void*)lp_convt_wgrad_kernel<T, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess,
+                    "lp_convt2_wgrad: cannot raise the dynamic LDS limit");
+        raised = lds;
+    }
             lp_convt_wgrad_kernel<T, 2, 2><<<grid, 256, lds, st>>>(p, cpb);
         } else if (mt == 2) lp_convt_wgrad_kernel<T, 2, 1><<<grid, 256, lds, st>>>(p, cpb);
         else if (ntl == 2) lp_convt_wgrad_kernel<T, 1, 2><<<grid, 256, lds, st>>>(p, cpb);

@@ -142,12 +142,12 @@ class UNetEngine:
                 continue
             ver = (w._version, w.data_ptr())
             if force or ent[0] != ver:
-                if dt != torch.float32:
-                    self._pack_lp(kind, w.detach(), ent[2], rin_p, nout_p, mode, ent[1])
-                else:
-                    jobs.append((kind, w.detach().contiguous(), ent[1], ent[2], rin_p, nout_p, mode, layout))
+                jobs.append((kind, w.detach().contiguous(), ent[1], ent[2], rin_p, nout_p, mode, layout))
                 self._pack_cache[key] = (ver, ent[1], ent[2])
-        ops.pack_batch(jobs)
+        if self.dtype != torch.float32:
+            ops.pack_batch_lp(jobs, self.dtype)
+        else:
+            ops.pack_batch(jobs)
 
     # ------------------------------------------------------------------ forward pieces
     def _conv_bn(self, P, x: CL, conv: str, bn: str, cin: int, cout: int, imap, out: CL, vec4: torch.Tensor,

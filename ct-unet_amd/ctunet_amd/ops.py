@@ -236,6 +236,23 @@ def pack_batch(jobs) -> None:
     _lib.check(_lib.load().ctu_pack_batch(arr, len(jobs), _stream()), "pack_batch")
 
 
+def pack_batch_lp(jobs, dtype: torch.dtype) -> None:
+    """jobs as in pack_batch (layout ignored): every 16-bit weight copy in ONE launch."""
+    if not jobs:
+        return
+    arr = (_lib.PackJob * len(jobs))()
+    for a, (kind, w, wp, cinv, rin_p, nout_p, mode, layout) in zip(arr, jobs):
+        _need_cuda(w, "weight")
+        assert w.is_contiguous() and wp.dtype == dtype
+        a.w, a.wp, a.cinv = w.data_ptr(), wp.data_ptr(), (None if cinv is None else cinv.data_ptr())
+        if kind == "conv":
+            a.kind, a.Co, a.Ci, a.k = 0, w.shape[0], w.shape[1], w.shape[2]
+        else:
+            a.kind, a.Ci, a.Co, a.k = 1, w.shape[0], w.shape[1], 2
+        a.rin_p, a.nout_p, a.mode, a.layout = rin_p, nout_p, mode, 0
+    _lib.check(_lib.load().ctu_lp_pack_batch(LP_CODE[dtype], arr, len(jobs), _stream()), "lp_pack_batch")
+
+
 def conv_num_blocks(dims, nout_p: int, layout: int = 0, k: int = 3, dtype=torch.float32, rin_p: int = 32) -> int:
     """Rows of the BN partial-sum buffer a conv3d_fwd call with this geometry writes (16-bit path: depends on the padded
     input channel count too, pass rin_p)."""

@@ -383,6 +383,8 @@ size_t ctu_lp_conv3d_packed_elems(int k, int rin_p, int nout_p);
 int ctu_lp_conv3d_num_blocks(int N, int D, int H, int W, int k, int rin_p);
 int ctu_lp_pack_conv3d_weight(int dtype, const float* w, void* wp, int Co, int Ci, int k, const int32_t* cinv,
                               int rin_p, int nout_p, int mode, void* stream);
+/* every 16-bit weight copy of a network in ONE launch (ctu_pack_job as above; `layout` unused, kind 1 = ConvTranspose3d) */
+int ctu_lp_pack_batch(int dtype, const ctu_pack_job* jobs, int n, void* stream);
 /* nn.Conv3d forward (mode-0 packing) / data gradient (mode-1 packing); stats: [ctu_lp_conv3d_num_blocks()][2][nout_p]
  * (the voxel box of a launch grows when rin_p is small, so the row count depends on it) */
 int ctu_lp_conv3d_fwd(int dtype, const void* in, int in_cs, int rin_p, const float* in_scale, const float* in_shift,
