@@ -412,6 +412,253 @@ __global__ __launch_bounds__(256) void lp_conv_fwd_kernel(LpConvP p) {
     }
 }
 
+// ---- persistent single-stage k = 3 variant (rin_p <= 32: every 128^3 / 64^3 layer of the shipped nets).  With 16-byte voxels
+// the box kernel above is VALU-bound on index arithmetic (SQ counters: ~2000 vector instructions per wave for 112 MFMAs), so:
+//   * a block walks a contiguous range of boxes; tap-offset table, BatchNorm vectors and ALL weight fragments are staged once;
+//   * per-thread item offsets are computed once per block -- an interior box costs one 32-bit add per load;
+//   * the next box's loads are in flight (in registers) under this box's MFMAs and epilogue;
+//   * BatchNorm partial sums stay in registers across the boxes: ONE stats row per block.
+template <class T, int NT, int TH, int BW>
+__global__ __launch_bounds__(256) void lp_conv_fwd_p1_kernel(LpConvP p, int ntiles, int tiles_per_block) {
+    typedef typename Vec<T>::v8 v8;
+    constexpr int KS = 3, TAPS = 27, PK = 1;
+    constexpr int TD = 4, CT = TH * BW / 16, HB = CT / 2;
+    constexpr int HD = TD + 2, HH = TH + 2, HW = BW + 2, HV = HD * HH * HW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int* sK = reinterpret_cast<int*>(smem);
+    float* sXf = reinterpret_cast<float*>(smem + 2048);
+    float* sRed = reinterpret_cast<float*>(smem + 2048 + 256);
+    unsigned char* sIn = smem + 2048 + 256 + 4 * NT * 32 * 4;
+    unsigned char* sW = sIn + (size_t)HV * p.S;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 15, kg = lane >> 4;
+    const int S = p.S;
+    const int n16 = (p.nout_p + 15) >> 4, nt0 = blockIdx.y * NT;
+    const T* in = reinterpret_cast<const T*>(p.in);
+    const T* wp = reinterpret_cast<const T*>(p.wp);
+    T* out = reinterpret_cast<T*>(p.out);
+    const int nch = p.rin_p >> 3, nchp = nch == 3 ? 4 : nch, sh = nchp == 4 ? 2 : (nchp == 2 ? 1 : 0);
+    const int ks = lp_ksteps(TAPS, nch);
+    const bool xf = p.scale != nullptr;
+    // ---- once per block: tables and weights
+    for (int i = tid; i < ks * 4; i += 256) {
+        const int tap = i / nch, ch = i % nch;
+        int off = 0;
+        if (tap < TAPS) off = (((tap / 9) * HH + (tap / 3) % 3) * HW + tap % 3) * S + ch * 16;
+        sK[i] = off;
+    }
+    if (tid < 64) {
+        const int c = tid & 31;
+        sXf[tid] = (xf && c < p.rin_p) ? ((tid < 32) ? p.scale[c] : p.shift[c]) : 0.f;
+    }
+    {
+        const int pieces = ks * NT * 64;
+        for (int i0 = tid; i0 < pieces; i0 += 256 * 8) {
+            uint4 w8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = min(i0 + u * 256, pieces - 1);
+                const int ln = i & 63, fr = i >> 6, nt = fr % NT, sx = fr / NT;
+                const int tile = min(nt0 + nt, n16 - 1);
+                w8[u] = *reinterpret_cast<const uint4*>(wp + ((size_t)(sx * n16 + tile) * 64 + ln) * 8);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * 256;
+                if (i < pieces) *reinterpret_cast<uint4*>(sW + (size_t)i * 16) = w8[u];
+            }
+        }
+    }
+    // ---- per-thread staging items: byte offset relative to the halo origin, LDS destination, chunk
+    constexpr int MAXCH = (BW == 32) ? 1 : ((TH == 8) ? 2 : 4);     // chunks per voxel this box is chosen for (lp_box)
+    constexpr int NI = (HV * MAXCH + 255) / 256;
+    const int items = HV << sh;
+    unsigned ioff[NI];
+    int dst[NI];
+    unsigned live = 0;
+#pragma unroll
+    for (int u = 0; u < NI; ++u) {
+        const int i = tid + u * 256;
+        const int v = min(i >> sh, HV - 1), c = i & (nchp - 1);
+        const bool lv = i < items && c < nch;
+        const int pw = v % HW, t2 = v / HW, ph = t2 % HH, pd = t2 / HH;
+        ioff[u] = (unsigned)((((pd * p.H + ph) * p.W + pw) * p.in_cs + (lv ? c : 0) * 8) * (int)sizeof(T));
+        dst[u] = (v * S + c * 16) | (c << 26);
+        live |= lv ? (1u << u) : 0u;
+    }
+    auto vox_of = [&](int ct, int& th, int& tw) {
+        if (BW == 32) { th = ct >> 1; tw = (ct & 1) * 16 + m; }
+        else if (BW == 16) { th = ct; tw = m; }
+        else { th = ct * 2 + (m >> 3); tw = m & 7; }
+    };
+    int th0, tw0;
+    vox_of(0, th0, tw0);
+    const int hb0 = ((wave * HH + th0) * HW + tw0) * S;
+    constexpr int CT_ROWSTEP = (BW == 32) ? 0 : ((BW == 16) ? 1 : 2);
+    float s1[NT][4], s2[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s1[nt][r] = 0.f; s2[nt][r] = 0.f; }
+    int tile = blockIdx.x * tiles_per_block;
+    const int tile_end = min(ntiles, tile + tiles_per_block);
+    uint4 raw[NI];
+    unsigned okb = 0;
+    auto box_of = [&](int t, int& n, int& d0, int& h0, int& w0) {
+        const int tx = t % p.tiles_w; t /= p.tiles_w;
+        const int ty = t % p.tiles_h; t /= p.tiles_h;
+        const int tz = t % p.tiles_d;
+        n = t / p.tiles_d; d0 = tz * TD; h0 = ty * TH; w0 = tx * BW;
+    };
+    auto load_box = [&](int t) {
+        int n, d0, h0, w0;
+        box_of(t, n, d0, h0, w0);
+        if (d0 >= 1 && d0 + TD + 1 <= p.D && h0 >= 1 && h0 + TH + 1 <= p.H && w0 >= 1 && w0 + BW + 1 <= p.W) {   // uniform
+            const char* base = reinterpret_cast<const char*>(in + ((((size_t)n * p.D + d0 - 1) * p.H + h0 - 1) * p.W + w0 - 1) * p.in_cs);
+#pragma unroll
+            for (int u = 0; u < NI; ++u) raw[u] = *reinterpret_cast<const uint4*>(base + ioff[u]);
+            okb = live;
+            return;
+        }
+        okb = 0;
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {                              // border / ragged box: clamped, branch-free
+            const int i = tid + u * 256;
+            const int v = min(i >> sh, HV - 1), c = i & (nchp - 1);
+            const int pw = v % HW, t2 = v / HW, ph = t2 % HH, pd = t2 / HH;
+            const int gd = d0 + pd - PK, gh = h0 + ph - PK, gw = w0 + pw - PK;
+            const bool ok = ((live >> u) & 1u) && (unsigned)gd < (unsigned)p.D && (unsigned)gh < (unsigned)p.H && (unsigned)gw < (unsigned)p.W;
+            const int cd = min(max(gd, 0), p.D - 1), chh = min(max(gh, 0), p.H - 1), cw = min(max(gw, 0), p.W - 1);
+            raw[u] = *reinterpret_cast<const uint4*>(in + ((((size_t)n * p.D + cd) * p.H + chh) * p.W + cw) * p.in_cs + (((live >> u) & 1u) ? c : 0) * 8);
+            okb |= ok ? (1u << u) : 0u;
+        }
+    };
+    if (tile < tile_end) load_box(tile);
+    for (; tile < tile_end; ++tile) {
+        __syncthreads();                                            // tables visible (first pass) / previous box's readers done
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+            if (!((live >> u) & 1u)) continue;
+            uint4 r = raw[u];
+            if (!((okb >> u) & 1u)) r = make_uint4(0u, 0u, 0u, 0u);
+            else if (xf) {
+                const int c8 = ((dst[u] >> 26) & 3) * 8;
+                const f32x8 f = __builtin_convertvector(*reinterpret_cast<v8*>(&r), f32x8);
+                f32x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float a = fmaf(f[j], sXf[c8 + j], sXf[32 + c8 + j]);
+                    o[j] = p.relu ? fmaxf(a, 0.f) : a;
+                }
+                *reinterpret_cast<v8*>(&r) = __builtin_convertvector(o, v8);
+            }
+            *reinterpret_cast<uint4*>(sIn + (dst[u] & 0x03ffffff)) = r;
+        }
+        __syncthreads();
+        if (tile + 1 < tile_end) load_box(tile + 1);
+        // ---- K loop (see lp_conv_fwd_kernel)
+        f32x4 acc[CT][NT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[ct][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        {
+            auto read_b = [&](int koff, int half, v8 (&bb)[HB]) {
+#pragma unroll
+                for (int j = 0; j < HB; ++j) {
+                    const int ct = half * HB + j;
+                    const int cto = (BW == 32) ? ((ct >> 1) * HW + (ct & 1) * 16) * S : ct * CT_ROWSTEP * HW * S;
+                    bb[j] = *reinterpret_cast<const v8*>(sIn + koff + cto);
+                }
+            };
+            v8 b0[HB], b1[HB], a[NT];
+            int koff = sK[kg] + hb0;
+            int koff_n = sK[4 * min(1, ks - 1) + kg] + hb0;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) a[nt] = *reinterpret_cast<const v8*>(sW + ((size_t)nt * 64 + lane) * 16);
+            read_b(koff, 0, b0);
+            for (int s = 0; s < ks; ++s) {
+                const int koff_nn = sK[4 * min(s + 2, ks - 1) + kg] + hb0;
+                read_b(koff, 1, b1);
+                const int sn = min(s + 1, ks - 1);
+                v8 an[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) an[nt] = *reinterpret_cast<const v8*>(sW + ((size_t)(sn * NT + nt) * 64 + lane) * 16);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < HB; ++j)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[j][nt] = Mfma<T>::run(a[nt], b0[j], acc[j][nt]);
+                __builtin_amdgcn_sched_barrier(0);
+                read_b(koff_n, 0, b0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < HB; ++j)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[HB + j][nt] = Mfma<T>::run(a[nt], b1[j], acc[HB + j][nt]);
+                __builtin_amdgcn_sched_barrier(0);
+                koff = koff_n;
+                koff_n = koff_nn;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) a[nt] = an[nt];
+            }
+        }
+        // ---- epilogue of this box
+        int n, d0, h0, w0;
+        box_of(tile, n, d0, h0, w0);
+        const bool full = d0 + TD <= p.D && h0 + TH <= p.H && w0 + BW <= p.W;        // uniform
+        T* obase = out + ((((size_t)n * p.D + d0 + wave) * p.H + h0) * p.W + w0) * p.out_cs;
+        const int orow = p.W * p.out_cs;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int cb = (nt0 + nt) * 16 + 4 * kg;
+            if (cb >= p.nout_p) continue;
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.bias) {
+                bv.x = cb + 0 < p.nbias ? p.bias[cb + 0] : 0.f; bv.y = cb + 1 < p.nbias ? p.bias[cb + 1] : 0.f;
+                bv.z = cb + 2 < p.nbias ? p.bias[cb + 2] : 0.f; bv.w = cb + 3 < p.nbias ? p.bias[cb + 3] : 0.f;
+            }
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                int th, tw;
+                vox_of(ct, th, tw);
+                if (full || (d0 + wave < p.D && h0 + th < p.H && w0 + tw < p.W)) {
+                    const float4 o = rnd4<T>(make_float4(acc[ct][nt][0] + bv.x, acc[ct][nt][1] + bv.y, acc[ct][nt][2] + bv.z,
+                                                         acc[ct][nt][3] + bv.w));
+                    st4<T>(obase + th * orow + tw * p.out_cs + cb, o);
+                    s1[nt][0] += o.x; s1[nt][1] += o.y; s1[nt][2] += o.z; s1[nt][3] += o.w;
+                    s2[nt][0] += o.x * o.x; s2[nt][1] += o.y * o.y; s2[nt][2] += o.z * o.z; s2[nt][3] += o.w * o.w;
+                }
+            }
+        }
+    }
+    if (p.stats) {                                                  // ONE BatchNorm partial row [2][nout_p] per block
+        __syncthreads();
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float a1 = s1[nt][r], a2 = s2[nt][r];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { a1 += __shfl_xor(a1, o); a2 += __shfl_xor(a2, o); }
+                if (m == 0) {
+                    sRed[((wave * NT + nt) * 2 + 0) * 16 + 4 * kg + r] = a1;
+                    sRed[((wave * NT + nt) * 2 + 1) * 16 + 4 * kg + r] = a2;
+                }
+            }
+        __syncthreads();
+        if (tid < NT * 32) {
+            const int nt = tid >> 5, which = (tid >> 4) & 1, c = tid & 15;
+            const int ch = (nt0 + nt) * 16 + c;
+            if (ch < p.nout_p) {
+                float sx = 0.f;
+#pragma unroll
+                for (int wv = 0; wv < 4; ++wv) sx += sRed[((wv * NT + nt) * 2 + which) * 16 + c];
+                p.stats[(size_t)blockIdx.x * 2 * p.nout_p + which * p.nout_p + ch] = sx;
+            }
+        }
+    }
+}
+
 struct LpBox { int th, bw; };
 
 // box of a forward / data-gradient launch: bigger boxes for thin voxels (see lp_conv_fwd_kernel)
@@ -428,6 +675,16 @@ int lp_fill(LpConvP& p, int N, int D, int H, int W, int rin_p) {
     p.N = N; p.D = D; p.H = H; p.W = W;
     p.tiles_d = ceil_div(D, 4); p.tiles_h = ceil_div(H, bx.th); p.tiles_w = ceil_div(W, bx.bw);
     return N * p.tiles_d * p.tiles_h * p.tiles_w;
+}
+
+// persistent single-stage kernel: k = 3, one stage, enough boxes to give every CU a few
+bool lp_use_persist(int k, int rin_p, int ntiles) { return k == 3 && rin_p <= LP_SC && ntiles >= 1024; }
+
+void lp_persist_grid(int ntiles, int* gx, int* tpb) {
+    int g = 512;                                                    // 2 blocks per CU
+    if (g > ntiles) g = ntiles;
+    *tpb = ceil_div(ntiles, g);
+    *gx = ceil_div(ntiles, *tpb);
 }
 
 int lp_voxel_stride(int rin_p) { return rin_p >= 16 ? (rin_p >= LP_SC ? LP_SC : rin_p) * 2 + 16 : 16; }
@@ -454,9 +711,35 @@ int lp_conv_launch_box(LpConvP& p, int ntiles, hipStream_t st) {
     return CTU_OK;
 }
 
+template <class T, int NT, int TH, int BW>
+int lp_conv_launch_persist(LpConvP& p, int ntiles, hipStream_t st) {
+    const int hv = 6 * (TH + 2) * (BW + 2);
+    const size_t lds = 2048 + 256 + 4 * NT * 32 * 4 + (size_t)hv * p.S + (size_t)lp_ksteps(27, p.rin_p >> 3) * NT * 1024;
+    CTU_REQUIRE(lds <= 160 * 1024, "lp_conv3d_fwd: LDS box of %zu bytes", lds);
+    int gx, tpb;
+    lp_persist_grid(ntiles, &gx, &tpb);
+    const int n16 = (p.nout_p + 15) >> 4;
+    static size_t raised = 64 * 1024;
+    if (lds > raised) {
+        CTU_REQUIRE(hipFuncSetAttribute((const void*)lp_conv_fwd_p1_kernel<T, NT, TH, BW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)lds) == hipSuccess, "lp_conv3d_fwd: cannot raise the dynamic LDS limit");
+        raised = lds;
+    }
+    lp_conv_fwd_p1_kernel<T, NT, TH, BW><<<dim3(gx, ceil_div(n16, NT)), 256, lds, st>>>(p, ntiles, tpb);
+    CTU_CHECK_LAUNCH("lp_conv3d_fwd (persistent)");
+    return CTU_OK;
+}
+
 template <class T, int KS, int NT>
 int lp_conv_launch(LpConvP& p, int ntiles, hipStream_t st) {
     const LpBox bx = lp_box(p.W, p.rin_p);
+    if constexpr (KS == 3) {
+        if (lp_use_persist(3, p.rin_p, ntiles)) {
+            if (bx.bw == 32) return lp_conv_launch_persist<T, NT, 8, 32>(p, ntiles, st);
+            if (bx.th == 8 && bx.bw == 16) return lp_conv_launch_persist<T, NT, 8, 16>(p, ntiles, st);
+            if (bx.bw == 16) return lp_conv_launch_persist<T, NT, 4, 16>(p, ntiles, st);
+        }
+    }
     if (bx.bw == 32) return lp_conv_launch_box<T, KS, NT, 8, 32>(p, ntiles, st);
     if (bx.bw == 8) return lp_conv_launch_box<T, KS, NT, 8, 8>(p, ntiles, st);
     if (bx.th == 8) return lp_conv_launch_box<T, KS, NT, 8, 16>(p, ntiles, st);
@@ -520,6 +803,27 @@ __global__ __launch_bounds__(256) void lp_conv_wgrad_kernel(LpWgP p, int tiles_p
     constexpr int NX = (HV * 2 + 255) / 256, NG = NV * 2 / 256;
     uint4 rx[NX], rg[NG];
     unsigned okx = 0;                                               // bit it: X item it lies inside the volume
+    // per-thread item offsets (bytes, relative to the box's halo origin / first voxel), computed ONCE per block: an interior
+    // box then costs one 32-bit add per load instead of ~50 VALU instructions of index arithmetic (the 8-channel layers
+    // are VALU-bound otherwise: 16 bytes per voxel leave no room for per-voxel address math)
+    unsigned xoff[NX], goff[NG], xlive = 0, glive = 0;
+#pragma unroll
+    for (int u = 0; u < NX; ++u) {
+        const int it = tid + u * 256, v = it >> 1, c = it & 1;
+        const bool live = it < HV * 2 && c < nchx;
+        const int vv = it < HV * 2 ? v : 0;
+        const int pw = vv % HW, t2 = vv / HW, ph = t2 % HH, pd = t2 / HH;
+        xoff[u] = (unsigned)((((pd * p.H + ph) * p.W + pw) * p.x_cs + cit * 16 + (live ? c : 0) * 8) * (int)sizeof(T));
+        xlive |= live ? (1u << u) : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < NG; ++u) {
+        const int it = tid + u * 256, v = it >> 1, c = it & 1;
+        const bool live = c < nchg;
+        const int tw = v % BW, t2 = v / BW, th = t2 % TH, td = t2 / TH;
+        goff[u] = (unsigned)((((td * p.H + th) * p.W + tw) * p.g_cs + cot * 16 + (live ? c : 0) * 8) * (int)sizeof(T));
+        glive |= live ? (1u << u) : 0u;
+    }
     auto load_box = [&](int tl) {
         int t = tl;
         const int tx = t % p.tiles_w; t /= p.tiles_w;
@@ -527,6 +831,21 @@ __global__ __launch_bounds__(256) void lp_conv_wgrad_kernel(LpWgP p, int tiles_p
         const int tz = t % p.tiles_d;
         const int n = t / p.tiles_d;
         const int d0 = tz * TD, h0 = ty * TH, w0 = tx * BW;
+        const int dlo = d0 + ((KS == 3) ? -1 : kd - PK), hlo = h0 - PK, wlo = w0 - PK;
+        // uniform: the whole haloed box (and the gradient box) lies inside the volume
+        if (dlo >= 0 && dlo + HD <= p.D && hlo >= 0 && hlo + HH <= p.H && wlo >= 0 && wlo + HW <= p.W) {
+            const char* xb = reinterpret_cast<const char*>(x + ((((size_t)n * p.D + dlo) * p.H + hlo) * p.W + wlo) * p.x_cs);
+            const char* gb = reinterpret_cast<const char*>(gr + ((((size_t)n * p.D + d0) * p.H + h0) * p.W + w0) * p.g_cs);
+#pragma unroll
+            for (int u = 0; u < NX; ++u) rx[u] = *reinterpret_cast<const uint4*>(xb + xoff[u]);
+#pragma unroll
+            for (int u = 0; u < NG; ++u) {
+                const uint4 r = *reinterpret_cast<const uint4*>(gb + goff[u]);
+                rg[u] = ((glive >> u) & 1u) ? r : make_uint4(0u, 0u, 0u, 0u);
+            }
+            okx = xlive;
+            return;
+        }
         okx = 0;
 #pragma unroll
         for (int u = 0; u < NX; ++u) {
@@ -739,9 +1058,14 @@ extern "C" size_t ctu_lp_conv3d_packed_elems(int k, int rin_p, int nout_p) {
 }
 
 extern "C" int ctu_lp_conv3d_num_blocks(int N, int D, int H, int W, int k, int rin_p) {
-    (void)k;
     LpConvP p;
-    return lp_fill(p, N, D, H, W, rin_p);
+    const int ntiles = lp_fill(p, N, D, H, W, rin_p);
+    if (lp_use_persist(k, rin_p, ntiles) && lp_box(W, rin_p).bw >= 16) {
+        int gx, tpb;
+        lp_persist_grid(ntiles, &gx, &tpb);
+        return gx;
+    }
+    return ntiles;
 }
 
 extern "C" int ctu_lp_pack_conv3d_weight(int dtype, const float* w, void* wp, int Co, int Ci, int k, const int32_t* cinv,
