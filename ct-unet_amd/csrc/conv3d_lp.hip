@@ -418,6 +418,19 @@ __global__ __launch_bounds__(256) void lp_conv_fwd_kernel(LpConvP p) {
 //   * per-thread item offsets are computed once per block -- an interior box costs one 32-bit add per load;
 //   * the next box's loads are in flight (in registers) under this box's MFMAs and epilogue;
 //   * BatchNorm partial sums stay in registers across the boxes: ONE stats row per block.
+#ifdef CTU_LP_STAMP
+// diagnostic build only (scripts/diag_stamp_lp.hip): per-phase cycle sums of wave 0, written to a buffer of their own
+__device__ unsigned long long* g_lp_stamp_out = nullptr;
+#define LPSTAMP(var)                                                                 \
+    do {                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                           \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");  \
+        __builtin_amdgcn_sched_barrier(0);                                           \
+    } while (0)
+#else
+#define LPSTAMP(var) do { } while (0)
+#endif
+
 template <class T, int NT, int TH, int BW>
 __global__ __launch_bounds__(256) void lp_conv_fwd_p1_kernel(LpConvP p, int ntiles, int tiles_per_block) {
     typedef typename Vec<T>::v8 v8;
@@ -494,6 +507,9 @@ __global__ __launch_bounds__(256) void lp_conv_fwd_p1_kernel(LpConvP p, int ntil
     vox_of(0, th0, tw0);
     const int hb0 = ((wave * HH + th0) * HW + tw0) * S;
     constexpr int CT_ROWSTEP = (BW == 32) ? 0 : ((BW == 16) ? 1 : 2);
+    // output byte offsets: row pitch, voxel pitch, and this lane's offset inside the box for column tile 0 / out tile nt0
+    const int orow_b = p.W * p.out_cs * (int)sizeof(T), vox_b = p.out_cs * (int)sizeof(T);
+    const unsigned eoff0 = (unsigned)(th0 * orow_b + tw0 * vox_b + (nt0 * 16 + 4 * kg) * (int)sizeof(T));
     float s1[NT][4], s2[NT][4];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -533,8 +549,13 @@ __global__ __launch_bounds__(256) void lp_conv_fwd_p1_kernel(LpConvP p, int ntil
         }
     };
     if (tile < tile_end) load_box(tile);
+#ifdef CTU_LP_STAMP
+    unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0, ph_[5] = {0, 0, 0, 0, 0}, nst = 0;
+    LPSTAMP(q0);
+#endif
     for (; tile < tile_end; ++tile) {
         __syncthreads();                                            // tables visible (first pass) / previous box's readers done
+        LPSTAMP(q1);
 #pragma unroll
         for (int u = 0; u < NI; ++u) {
             if (!((live >> u) & 1u)) continue;
@@ -554,7 +575,9 @@ __global__ __launch_bounds__(256) void lp_conv_fwd_p1_kernel(LpConvP p, int ntil
             *reinterpret_cast<uint4*>(sIn + (dst[u] & 0x03ffffff)) = r;
         }
         __syncthreads();
+        LPSTAMP(q2);
         if (tile + 1 < tile_end) load_box(tile + 1);
+        LPSTAMP(q3);
         // ---- K loop (see lp_conv_fwd_kernel)
         f32x4 acc[CT][NT];
 #pragma unroll
@@ -602,12 +625,12 @@ __global__ __launch_bounds__(256) void lp_conv_fwd_p1_kernel(LpConvP p, int ntil
                 for (int nt = 0; nt < NT; ++nt) a[nt] = an[nt];
             }
         }
+        LPSTAMP(q4);
         // ---- epilogue of this box
         int n, d0, h0, w0;
         box_of(tile, n, d0, h0, w0);
         const bool full = d0 + TD <= p.D && h0 + TH <= p.H && w0 + BW <= p.W;        // uniform
-        T* obase = out + ((((size_t)n * p.D + d0 + wave) * p.H + h0) * p.W + w0) * p.out_cs;
-        const int orow = p.W * p.out_cs;
+        char* obase = reinterpret_cast<char*>(out + ((((size_t)n * p.D + d0 + wave) * p.H + h0) * p.W + w0) * p.out_cs);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int cb = (nt0 + nt) * 16 + 4 * kg;
@@ -624,13 +647,28 @@ __global__ __launch_bounds__(256) void lp_conv_fwd_p1_kernel(LpConvP p, int ntil
                 if (full || (d0 + wave < p.D && h0 + th < p.H && w0 + tw < p.W)) {
                     const float4 o = rnd4<T>(make_float4(acc[ct][nt][0] + bv.x, acc[ct][nt][1] + bv.y, acc[ct][nt][2] + bv.z,
                                                          acc[ct][nt][3] + bv.w));
-                    st4<T>(obase + th * orow + tw * p.out_cs + cb, o);
+                    // byte offset inside the box: precomputed per lane (eoff0) + a per-tile multiple of the row pitch
+                    const unsigned eo = eoff0 + (unsigned)((BW == 32 ? (ct >> 1) : (BW == 16 ? ct : 2 * ct)) * orow_b) +
+                                        (unsigned)((BW == 32 ? (ct & 1) * 16 : 0) * vox_b) + (unsigned)(nt * 16 * (int)sizeof(T));
+                    st4<T>(reinterpret_cast<T*>(obase + eo), o);
                     s1[nt][0] += o.x; s1[nt][1] += o.y; s1[nt][2] += o.z; s1[nt][3] += o.w;
                     s2[nt][0] += o.x * o.x; s2[nt][1] += o.y * o.y; s2[nt][2] += o.z * o.z; s2[nt][3] += o.w * o.w;
                 }
             }
         }
+#ifdef CTU_LP_STAMP
+        LPSTAMP(q5);
+        ph_[0] += q1 - q0; ph_[1] += q2 - q1; ph_[2] += q3 - q2; ph_[3] += q4 - q3; ph_[4] += q5 - q4;
+        q0 = q5; ++nst;
+#endif
     }
+#ifdef CTU_LP_STAMP
+    if (g_lp_stamp_out && tid == 0) {
+        unsigned long long* o_ = g_lp_stamp_out + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 6;
+        for (int k_ = 0; k_ < 5; ++k_) o_[k_] = ph_[k_];
+        o_[5] = nst;
+    }
+#endif
     if (p.stats) {                                                  // ONE BatchNorm partial row [2][nout_p] per block
         __syncthreads();
 #pragma unroll
@@ -665,7 +703,8 @@ struct LpBox { int th, bw; };
 LpBox lp_box(int W, int rin_p) {
     const int nch = (rin_p >= LP_SC ? LP_SC : rin_p) >> 3;
     if (W < 16) return {8, 8};
-    if (nch == 1 && W >= 32) return {8, 32};
+    // (a 4x8x32 box for single-chunk layers was tried: 16 column tiles per wave cost 277 registers = one wave per SIMD, and
+    //  the stamps showed every phase serialised in that one wave: 17.6 k cycles per box against 1.8 k of MFMA work)
     if (nch <= 2) return {8, 16};
     return {4, 16};
 }
