@@ -14,6 +14,7 @@
 // (m, kq) holds channels {2kq, 2kq+1}; MFMA #0 contracts channels {0,2,4,6}, #1 {1,3,5,7}.
 #include "common.h"
 #include "pack.h"
+#include "bn_tail.h"
 
 #ifndef CTU_K3S_OCC
 #define CTU_K3S_OCC 2
@@ -44,6 +45,7 @@ struct ConvP {
     int N, D, H, W;
     int tiles_d, tiles_h, tiles_w;
     int n16;                 // number of 16-wide output-channel tiles in the packed weights
+    ctu_bn_tail tail;        // counter != NULL: the last block of the launch finalizes the BatchNorm (bn_tail.h)
 };
 
 
@@ -327,10 +329,11 @@ __global__ __launch_bounds__(256) void conv3d_fwd_kernel(ConvP p) {
                     b += sRed[((w * NT) * 16 + tid) * 2 + 1];
                 }
                 float* row = p.stats + (size_t)blockIdx.x * 2 * p.nout_p;
-                row[co] = a;
-                row[p.nout_p + co] = b;
+                st_sc1(row + co, a);
+                st_sc1(row + p.nout_p + co, b);
             }
         }
+        if (p.tail.counter) bn_fwd_tail(p.tail, p.stats, gridDim.x, p.nout_p, gridDim.x * gridDim.y);
     }
 }
 
@@ -691,10 +694,11 @@ __global__ __launch_bounds__(256, (NT == 1 && !PAIR) ? 3 : 2) void conv3d_fwd_k3
                     a2 += sRed[(w * NT * 16 + tid) * 2 + 1];
                 }
                 float* row = p.stats + (size_t)blockIdx.x * 2 * p.nout_p;
-                row[co] = a1;
-                row[p.nout_p + co] = a2;
+                st_sc1(row + co, a1);
+                st_sc1(row + p.nout_p + co, a2);
             }
         }
+        if (p.tail.counter) bn_fwd_tail(p.tail, p.stats, gridDim.x, p.nout_p, gridDim.x * gridDim.y);
     }
 }
 
@@ -1527,7 +1531,7 @@ static int launch_fwd(const ConvP& p0, int td, int th, int tw, hipStream_t st) {
 
 extern "C" int ctu_conv3d_fwd(const float* in, int in_cs, int rin_p, const float* in_scale, const float* in_shift,
                               int in_relu, const float* wp, const float* bias, int nbias, float* out, int out_cs,
-                              int nout_p, float* stats, int N, int D, int H, int W, int k, int layout, void* stream) {
+                              int nout_p, float* stats, int N, int D, int H, int W, int k, int layout, const ctu_bn_tail* tail, void* stream) {
     CTU_REQUIRE(k == 3 || k == 5, "conv3d_fwd: k=%d unsupported (3 or 5)", k);
     CTU_REQUIRE(in && wp && out, "conv3d_fwd: null pointer");
     CTU_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0, "conv3d_fwd: empty volume %dx%dx%dx%d", N, D, H, W);
@@ -1540,6 +1544,10 @@ extern "C" int ctu_conv3d_fwd(const float* in, int in_cs, int rin_p, const float
     CTU_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv3d_fwd: scale/shift must come together");
     ConvP p;
     p.in = in; p.in_scale = in_scale; p.in_shift = in_shift; p.wp = wp; p.bias = bias; p.out = out; p.stats = stats;
+    CTU_REQUIRE(!tail || (stats && tail->counter && tail->gamma && tail->beta && tail->scale && tail->shift && tail->mean &&
+                          tail->invstd && tail->C > 0 && tail->C <= nout_p && tail->count > 0),
+                "conv3d_fwd: incomplete BatchNorm tail");
+    p.tail = tail_or_off(tail);
     p.in_cs = in_cs; p.rin_p = rin_p; p.in_relu = in_relu; p.out_cs = out_cs; p.nout_p = nout_p;
     p.nbias = bias ? nbias : 0;
     p.N = N; p.D = D; p.H = H; p.W = W;

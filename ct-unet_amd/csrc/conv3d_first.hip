@@ -9,6 +9,7 @@
 //   weight gradient . MFMA with M = (tap, c_in) (27*C_in rows, padded to 32/64), N = c_out, K = voxels
 // All three are persistent over 4x4x32 / 4x4x16 voxel boxes with the box staged in LDS.
 #include "common.h"
+#include "bn_tail.h"
 
 namespace {
 
@@ -40,7 +41,7 @@ __device__ __forceinline__ void box_origin(const FirstP& p, int t, int TW, int& 
 // K = 36*CIN -> 9*CIN MFMAs per 32 voxels.  The per-lane weight fragments (9*CIN floats) and LDS offsets are
 // computed once per block; each MFMA needs a single ds_read_b32.  Box 4x4x32, persistent, register prefetch.
 template <int CIN, class T>
-__global__ __launch_bounds__(256) void first_fwd_kernel(FirstP p, int tiles_per_block) {
+__global__ __launch_bounds__(256) void first_fwd_kernel(FirstP p, int tiles_per_block, ctu_bn_tail tail) {
     constexpr int TW = 32, HD = TD + 2, HH = TH + 2, HW = TW + 2, HV = HD * HH * HW;
     constexpr int NIT = (HV * CIN + 255) / 256;
     constexpr int NS = 9 * CIN;                                     // K-steps of 4
@@ -135,7 +136,8 @@ __global__ __launch_bounds__(256) void first_fwd_kernel(FirstP p, int tiles_per_
             if (m == 0 && kq < 2) { sRed[wave * 16 + cq + r] = a1; sRed[wave * 16 + 8 + cq + r] = a2; }
         }
         __syncthreads();
-        if (tid < 16) p.stats[(size_t)blockIdx.x * 16 + tid] = (sRed[tid] + sRed[16 + tid]) + (sRed[32 + tid] + sRed[48 + tid]);
+        if (tid < 16) st_sc1(p.stats + (size_t)blockIdx.x * 16 + tid, (sRed[tid] + sRed[16 + tid]) + (sRed[32 + tid] + sRed[48 + tid]));
+        if (tail.counter) bn_fwd_tail(tail, p.stats, gridDim.x, 8, gridDim.x);
     }
 }
 
@@ -390,7 +392,10 @@ namespace {
 
 template <class T>
 int first_fwd_impl(const float* x, int cin, const float* w, const float* bias, int nbias, T* out, int out_cs, int Co, float* stats,
-                   int N, int D, int H, int W, void* stream) {
+                   int N, int D, int H, int W, const ctu_bn_tail* tail, void* stream) {
+    CTU_REQUIRE(!tail || (stats && tail->counter && tail->gamma && tail->beta && tail->scale && tail->shift && tail->mean &&
+                          tail->invstd && tail->C > 0 && tail->C <= 8 && tail->count > 0),
+                "conv3d_first_fwd: incomplete BatchNorm tail");
     CTU_REQUIRE(x && w && out, "conv3d_first_fwd: null pointer");
     CTU_REQUIRE((cin == 1 || cin == 2) && Co >= 1 && Co <= 8, "conv3d_first_fwd: cin=%d Co=%d unsupported", cin, Co);
     CTU_REQUIRE(out_cs >= 8 && out_cs % 4 == 0 && ((uintptr_t)out & (4 * sizeof(T) - 1)) == 0, "conv3d_first_fwd: output slice alignment");
@@ -398,8 +403,8 @@ int first_fwd_impl(const float* x, int cin, const float* w, const float* bias, i
     p.x = x; p.w = w; p.bias = bias; p.nbias = bias ? nbias : 0; p.out = out; p.out_cs = out_cs; p.Co = Co; p.stats = stats;
     int gx, tpb;
     grid_for(fill(p, N, D, H, W, 32), 4, &gx, &tpb);
-    if (cin == 1) first_fwd_kernel<1, T><<<gx, 256, 0, (hipStream_t)stream>>>(p, tpb);
-    else first_fwd_kernel<2, T><<<gx, 256, 0, (hipStream_t)stream>>>(p, tpb);
+    if (cin == 1) first_fwd_kernel<1, T><<<gx, 256, 0, (hipStream_t)stream>>>(p, tpb, tail_or_off(tail));
+    else first_fwd_kernel<2, T><<<gx, 256, 0, (hipStream_t)stream>>>(p, tpb, tail_or_off(tail));
     CTU_CHECK_LAUNCH("conv3d_first_fwd");
     return CTU_OK;
 }
@@ -444,12 +449,12 @@ int first_wgrad_impl(const float* x, int cin, const T* g, int g_cs, float* dw, i
 }  // namespace
 
 extern "C" int ctu_conv3d_first_fwd(const float* x, int cin, const float* w, const float* bias, int nbias, float* out,
-                                    int out_cs, int Co, float* stats, int N, int D, int H, int W, void* stream) {
-    return first_fwd_impl<float>(x, cin, w, bias, nbias, out, out_cs, Co, stats, N, D, H, W, stream);
+                                    int out_cs, int Co, float* stats, int N, int D, int H, int W, const ctu_bn_tail* tail, void* stream) {
+    return first_fwd_impl<float>(x, cin, w, bias, nbias, out, out_cs, Co, stats, N, D, H, W, tail, stream);
 }
 extern "C" int ctu_lp_conv3d_first_fwd(int dtype, const float* x, int cin, const float* w, const float* bias, int nbias, void* out,
-                                       int out_cs, int Co, float* stats, int N, int D, int H, int W, void* stream) {
-    CTU_DISPATCH_LP(dtype, return first_fwd_impl<T>(x, cin, w, bias, nbias, (T*)out, out_cs, Co, stats, N, D, H, W, stream));
+                                       int out_cs, int Co, float* stats, int N, int D, int H, int W, const ctu_bn_tail* tail, void* stream) {
+    CTU_DISPATCH_LP(dtype, return first_fwd_impl<T>(x, cin, w, bias, nbias, (T*)out, out_cs, Co, stats, N, D, H, W, tail, stream));
 }
 
 extern "C" int ctu_conv3d_first_bwd_data(const float* g, int g_cs, const float* w, int cin, int Co, float* dx, int N, int D,

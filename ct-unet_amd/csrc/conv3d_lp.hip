@@ -15,6 +15,7 @@
 //   LDS images read with ds_read_b64_tr_b16 (the hardware transpose), one accumulator per tap, one slab per block,
 //   deterministic slab reduction (no float atomics).
 #include "common.h"
+#include "bn_tail.h"
 
 namespace {
 
@@ -142,6 +143,7 @@ struct LpConvP {
     int in_cs, rin_p, relu, out_cs, nout_p, nbias;
     int N, D, H, W, tiles_d, tiles_h, tiles_w;
     int S;            // LDS bytes per halo voxel
+    ctu_bn_tail tail; // counter != NULL: the last block of the launch finalizes the BatchNorm (bn_tail.h)
 };
 
 // Box TD = 4 x TH x BW voxels, one plane (td) per wave, CT = TH * BW / 16 column tiles of 16 voxels per wave.  The box grows
@@ -406,9 +408,10 @@ __global__ __launch_bounds__(256) void lp_conv_fwd_kernel(LpConvP p) {
                 float s = 0.f;
 #pragma unroll
                 for (int wv = 0; wv < 4; ++wv) s += sRed[((wv * NT + nt) * 2 + which) * 16 + c];
-                p.stats[(size_t)blockIdx.x * 2 * p.nout_p + which * p.nout_p + ch] = s;
+                st_sc1(p.stats + (size_t)blockIdx.x * 2 * p.nout_p + which * p.nout_p + ch, s);
             }
         }
+        if (p.tail.counter) bn_fwd_tail(p.tail, p.stats, gridDim.x, p.nout_p, gridDim.x * gridDim.y);
     }
 }
 
@@ -691,9 +694,10 @@ __global__ __launch_bounds__(256) void lp_conv_fwd_p1_kernel(LpConvP p, int ntil
                 float sx = 0.f;
 #pragma unroll
                 for (int wv = 0; wv < 4; ++wv) sx += sRed[((wv * NT + nt) * 2 + which) * 16 + c];
-                p.stats[(size_t)blockIdx.x * 2 * p.nout_p + which * p.nout_p + ch] = sx;
+                st_sc1(p.stats + (size_t)blockIdx.x * 2 * p.nout_p + which * p.nout_p + ch, sx);
             }
         }
+        if (p.tail.counter) bn_fwd_tail(p.tail, p.stats, gridDim.x, p.nout_p, gridDim.x * gridDim.y);
     }
 }
 
@@ -1125,7 +1129,7 @@ extern "C" int ctu_lp_pack_conv3d_weight(int dtype, const float* w, void* wp, in
 
 extern "C" int ctu_lp_conv3d_fwd(int dtype, const void* in, int in_cs, int rin_p, const float* in_scale, const float* in_shift,
                                  int in_relu, const void* wp, const float* bias, int nbias, void* out, int out_cs, int nout_p,
-                                 float* stats, int N, int D, int H, int W, int k, void* stream) {
+                                 float* stats, int N, int D, int H, int W, int k, const ctu_bn_tail* tail, void* stream) {
     CTU_REQUIRE(in && wp && out, "lp_conv3d_fwd: null pointer");
     CTU_REQUIRE((k == 3 || k == 5) && rin_p > 0 && rin_p % 8 == 0 && nout_p > 0 && nout_p % 8 == 0,
                 "lp_conv3d_fwd: k=%d rin_p=%d nout_p=%d", k, rin_p, nout_p);
@@ -1135,6 +1139,10 @@ extern "C" int ctu_lp_conv3d_fwd(int dtype, const void* in, int in_cs, int rin_p
     CTU_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0, "lp_conv3d_fwd: empty volume");
     LpConvP p{};
     p.in = in; p.wp = wp; p.out = out; p.scale = in_scale; p.shift = in_shift; p.bias = bias; p.stats = stats;
+    CTU_REQUIRE(!tail || (stats && tail->counter && tail->gamma && tail->beta && tail->scale && tail->shift && tail->mean &&
+                          tail->invstd && tail->C > 0 && tail->C <= nout_p && tail->count > 0),
+                "lp_conv3d_fwd: incomplete BatchNorm tail");
+    p.tail = tail_or_off(tail);
     p.in_cs = in_cs; p.rin_p = rin_p; p.relu = in_relu; p.out_cs = out_cs; p.nout_p = nout_p; p.nbias = bias ? nbias : 0;
     p.S = lp_voxel_stride(rin_p);
     const int ntiles = lp_fill(p, N, D, H, W, rin_p);

@@ -4,6 +4,7 @@
 // two-stage (per-block partials, then a small finalize kernel) -- no float atomics, so
 // results are bitwise reproducible run to run.
 #include "common.h"
+#include "bn_tail.h"
 
 static thread_local char g_err[512] = "";
 
@@ -135,7 +136,7 @@ __global__ void bn_relu_bwd_reduce_kernel(const T* __restrict__ y, int y_cs, con
                                           int g_cs, int cp, const float* __restrict__ scale,
                                           const float* __restrict__ shift, const float* __restrict__ mean,
                                           const float* __restrict__ invstd, int64_t nvox,
-                                          float* __restrict__ partials) {
+                                          float* __restrict__ partials, ctu_bn_bwd_tail tail) {
     const int nq = cp >> 2;
     const int tpv = EW_BLOCK / nq;                  // voxels per block pass (nq divides 256 or not: extra threads idle)
     const int qd = threadIdx.x % nq, vl = threadIdx.x / nq;
@@ -167,9 +168,10 @@ __global__ void bn_relu_bwd_reduce_kernel(const T* __restrict__ y, int y_cs, con
             s1 += red[(l * nq + q) * 8 + j];
             s2 += red[(l * nq + q) * 8 + 4 + j];
         }
-        partials[(size_t)blockIdx.x * 2 * cp + c] = s1;
-        partials[(size_t)blockIdx.x * 2 * cp + cp + c] = s2;
+        st_sc1(partials + (size_t)blockIdx.x * 2 * cp + c, s1);
+        st_sc1(partials + (size_t)blockIdx.x * 2 * cp + cp + c, s2);
     }
+    if (tail.counter) bn_bwd_tail(tail, partials, gridDim.x, cp, gridDim.x);
 }
 
 // coef[0..cp) = gamma*invstd ; coef[cp..2cp) = dbeta/n ; coef[2cp..3cp) = dgamma/n
@@ -307,7 +309,7 @@ __global__ void maxpool2_bwd_kernel(const T* __restrict__ in, int in_cs, int cp,
                                     const float* __restrict__ shift, int relu, const T* __restrict__ gout,
                                     int gout_cs, T* __restrict__ gin, int gin_cs, int accumulate, int N, int D,
                                     int H, int W, const float* __restrict__ mean, const float* __restrict__ invstd,
-                                    float* __restrict__ partials) {
+                                    float* __restrict__ partials, ctu_bn_bwd_tail tail) {
     const int nq = cp >> 2;
     const int Do = D >> 1, Ho = H >> 1, Wo = W >> 1;
     const int64_t total = (int64_t)N * Do * Ho * Wo * nq;
@@ -384,9 +386,10 @@ __global__ void maxpool2_bwd_kernel(const T* __restrict__ in, int in_cs, int cp,
                 s1 += red[(l * nq + q) * 8 + j];
                 s2 += red[(l * nq + q) * 8 + 4 + j];
             }
-            partials[(size_t)blockIdx.x * 2 * cp + c] = s1;
-            partials[(size_t)blockIdx.x * 2 * cp + cp + c] = s2;
+            st_sc1(partials + (size_t)blockIdx.x * 2 * cp + c, s1);
+            st_sc1(partials + (size_t)blockIdx.x * 2 * cp + cp + c, s2);
         }
+        if (tail.counter) bn_bwd_tail(tail, partials, gridDim.x, cp, gridDim.x);
     }
 }
 
@@ -519,11 +522,15 @@ int ndhwc_to_ncdhw_impl(const T* src, float* dst, int N, int C, int D, int H, in
 
 template <class T>
 int bn_relu_bwd_reduce_impl(const T* y, int y_cs, const T* ga, int g_cs, int cp, const float* scale, const float* shift,
-                            const float* mean, const float* invstd, int64_t nvox, float* partials, void* stream) {
+                            const float* mean, const float* invstd, int64_t nvox, float* partials, const ctu_bn_bwd_tail* tail,
+                            void* stream) {
     CTU_REQUIRE(y && ga && scale && shift && mean && invstd && partials, "bn_relu_bwd_reduce: null pointer");
+    CTU_REQUIRE(!tail || (tail->counter && tail->gamma && tail->invstd && tail->dgamma && tail->dbeta && tail->coef &&
+                          tail->C > 0 && tail->C <= cp && tail->count > 0 && (!tail->running_mean || (tail->mean && tail->running_var))),
+                "bn_relu_bwd_reduce: incomplete BatchNorm tail");
     CTU_REQUIRE(cp % 8 == 0 && cp > 0 && cp <= 256 && y_cs % 4 == 0 && g_cs % 4 == 0, "bn_relu_bwd_reduce: cp=%d", cp);
     bn_relu_bwd_reduce_kernel<T><<<ctu_bn_bwd_num_blocks(nvox), EW_BLOCK, 0, (hipStream_t)stream>>>(
-        y, y_cs, ga, g_cs, cp, scale, shift, mean, invstd, nvox, partials);
+        y, y_cs, ga, g_cs, cp, scale, shift, mean, invstd, nvox, partials, bwd_tail_or_off(tail));
     CTU_CHECK_LAUNCH("bn_relu_bwd_reduce");
     return CTU_OK;
 }
@@ -559,7 +566,8 @@ int maxpool2_bwd_impl(const T* in, int in_cs, int cp, const float* in_scale, con
     CTU_REQUIRE(cp % 8 == 0 && cp > 0 && D % 2 == 0 && H % 2 == 0 && W % 2 == 0, "maxpool2_bwd: D,H,W must be even");
     const int64_t total = (int64_t)N * (D / 2) * (H / 2) * (W / 2) * (cp >> 2);
     maxpool2_bwd_kernel<false, T><<<(unsigned)ceil_div64(total, EW_BLOCK), EW_BLOCK, 0, (hipStream_t)stream>>>(
-        in, in_cs, cp, in_scale, in_shift, in_relu, gout, gout_cs, gin, gin_cs, accumulate, N, D, H, W, nullptr, nullptr, nullptr);
+        in, in_cs, cp, in_scale, in_shift, in_relu, gout, gout_cs, gin, gin_cs, accumulate, N, D, H, W, nullptr, nullptr, nullptr,
+        bwd_tail_or_off(nullptr));
     CTU_CHECK_LAUNCH("maxpool2_bwd");
     return CTU_OK;
 }
@@ -567,13 +575,17 @@ int maxpool2_bwd_impl(const T* in, int in_cs, int cp, const float* in_scale, con
 template <class T>
 int maxpool2_bwd_bn_impl(const T* in, int in_cs, int cp, const float* in_scale, const float* in_shift, const float* mean,
                          const float* invstd, const T* gout, int gout_cs, T* gin, int gin_cs, int accumulate, int N, int D,
-                         int H, int W, float* partials, void* stream) {
+                         int H, int W, float* partials, const ctu_bn_bwd_tail* tail, void* stream) {
     CTU_REQUIRE(in && gout && gin && in_scale && in_shift && mean && invstd && partials, "maxpool2_bwd_bn: null pointer");
+    CTU_REQUIRE(!tail || (tail->counter && tail->gamma && tail->invstd && tail->dgamma && tail->dbeta && tail->coef &&
+                          tail->C > 0 && tail->C <= cp && tail->count > 0 && (!tail->running_mean || (tail->mean && tail->running_var))),
+                "maxpool2_bwd_bn: incomplete BatchNorm tail");
     CTU_REQUIRE(cp % 8 == 0 && cp > 0 && cp <= EW_BLOCK && EW_BLOCK % (cp >> 2) == 0 && D % 2 == 0 && H % 2 == 0 && W % 2 == 0,
                 "maxpool2_bwd_bn: cp=%d must be a multiple of 8 whose quads divide the block; D,H,W even", cp);
     const int nb = ctu_maxpool2_bwd_bn_num_blocks(N, D, H, W, cp);
     maxpool2_bwd_kernel<true, T><<<nb, EW_BLOCK, 0, (hipStream_t)stream>>>(
-        in, in_cs, cp, in_scale, in_shift, 1, gout, gout_cs, gin, gin_cs, accumulate, N, D, H, W, mean, invstd, partials);
+        in, in_cs, cp, in_scale, in_shift, 1, gout, gout_cs, gin, gin_cs, accumulate, N, D, H, W, mean, invstd, partials,
+        bwd_tail_or_off(tail));
     CTU_CHECK_LAUNCH("maxpool2_bwd_bn");
     return CTU_OK;
 }
@@ -657,14 +669,14 @@ extern "C" int ctu_bn_bwd_num_blocks(int64_t nvox) {
 
 extern "C" int ctu_bn_relu_bwd_reduce(const float* y, int y_cs, const float* ga, int g_cs, int cp, const float* scale,
                                       const float* shift, const float* mean, const float* invstd, int64_t nvox,
-                                      float* partials, void* stream) {
-    return bn_relu_bwd_reduce_impl<float>(y, y_cs, ga, g_cs, cp, scale, shift, mean, invstd, nvox, partials, stream);
+                                      float* partials, const ctu_bn_bwd_tail* tail, void* stream) {
+    return bn_relu_bwd_reduce_impl<float>(y, y_cs, ga, g_cs, cp, scale, shift, mean, invstd, nvox, partials, tail, stream);
 }
 extern "C" int ctu_lp_bn_relu_bwd_reduce(int dtype, const void* y, int y_cs, const void* ga, int g_cs, int cp, const float* scale,
                                          const float* shift, const float* mean, const float* invstd, int64_t nvox,
-                                         float* partials, void* stream) {
+                                         float* partials, const ctu_bn_bwd_tail* tail, void* stream) {
     CTU_DISPATCH_LP(dtype, return bn_relu_bwd_reduce_impl<T>((const T*)y, y_cs, (const T*)ga, g_cs, cp, scale, shift, mean, invstd,
-                                                             nvox, partials, stream));
+                                                             nvox, partials, tail, stream));
 }
 
 extern "C" int ctu_bn_bwd_finalize(const float* partials, int nb, int C, int cp, double count, const float* gamma,
@@ -724,15 +736,15 @@ extern "C" int ctu_maxpool2_bwd_bn_num_blocks(int N, int D, int H, int W, int cp
 
 extern "C" int ctu_maxpool2_bwd_bn(const float* in, int in_cs, int cp, const float* in_scale, const float* in_shift,
                                    const float* mean, const float* invstd, const float* gout, int gout_cs, float* gin,
-                                   int gin_cs, int accumulate, int N, int D, int H, int W, float* partials, void* stream) {
+                                   int gin_cs, int accumulate, int N, int D, int H, int W, float* partials, const ctu_bn_bwd_tail* tail, void* stream) {
     return maxpool2_bwd_bn_impl<float>(in, in_cs, cp, in_scale, in_shift, mean, invstd, gout, gout_cs, gin, gin_cs, accumulate, N, D,
-                                       H, W, partials, stream);
+                                       H, W, partials, tail, stream);
 }
 extern "C" int ctu_lp_maxpool2_bwd_bn(int dtype, const void* in, int in_cs, int cp, const float* in_scale, const float* in_shift,
                                       const float* mean, const float* invstd, const void* gout, int gout_cs, void* gin,
-                                      int gin_cs, int accumulate, int N, int D, int H, int W, float* partials, void* stream) {
+                                      int gin_cs, int accumulate, int N, int D, int H, int W, float* partials, const ctu_bn_bwd_tail* tail, void* stream) {
     CTU_DISPATCH_LP(dtype, return maxpool2_bwd_bn_impl<T>((const T*)in, in_cs, cp, in_scale, in_shift, mean, invstd, (const T*)gout,
-                                                          gout_cs, (T*)gin, gin_cs, accumulate, N, D, H, W, partials, stream));
+                                                          gout_cs, (T*)gin, gin_cs, accumulate, N, D, H, W, partials, tail, stream));
 }
 
 extern "C" int ctu_skip_add(const float* a, int a_cs, const float* a_scale, const float* a_shift, int a_relu,

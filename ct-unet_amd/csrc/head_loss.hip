@@ -7,6 +7,7 @@
 //           dice_loss                                               ctunet/utilities.py:35-50
 //           softmax + nn.CrossEntropyLoss + argmax loss assembly    ctunet/pytorch/ProblemHandler.py:59-88,228-298
 #include "common.h"
+#include "bn_tail.h"
 
 namespace {
 
@@ -276,8 +277,15 @@ __global__ __launch_bounds__(HB) void head_bwd_q_kernel(HeadP p, const float* __
 template <int CP>
 __global__ __launch_bounds__(HB) void head_bwd_final_kernel(const float* __restrict__ partials, int nb, int Ci, int Co,
                                                             const int32_t* __restrict__ imap, float* __restrict__ dw,
-                                                            float* __restrict__ db) {
+                                                            float* __restrict__ db, const float* __restrict__ bn_partials,
+                                                            int bn_cp, ctu_bn_bwd_tail tail) {
     const int i = blockIdx.x;
+    if (i == Co * Ci + Co) {
+        // one extra block: the BatchNorm-backward finalize of the layer feeding the head (rows written by the kernel before
+        // this one, so plain visibility; same arithmetic as ctu_bn_bwd_finalize)
+        bn_bwd_finalize_rows(tail, bn_partials, nb, bn_cp);
+        return;
+    }
     const int row = MAXCO * CP + MAXCO;
     int col;
     if (i < Co * Ci) {
@@ -454,7 +462,10 @@ template <class T>
 int head_bwd_impl(const T* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift, int in_relu, const float* w,
                   const float* bias, const int32_t* imap, int Ci, int Co, int act, int head_mode, const float* g0, const float* g1,
                   T* gin, int gin_cs, float* dw, float* db, float* ws, int N, int64_t nvox_per_item, const float* bn_mean,
-                  const float* bn_invstd, int bn_cp, float* bn_partials, void* stream) {
+                  const float* bn_invstd, int bn_cp, float* bn_partials, const ctu_bn_bwd_tail* tail, void* stream) {
+    CTU_REQUIRE(!tail || (bn_partials && tail->gamma && tail->invstd && tail->dgamma && tail->dbeta && tail->coef &&
+                          tail->C > 0 && tail->C <= bn_cp && tail->count > 0 && (!tail->running_mean || (tail->mean && tail->running_var))),
+                "head_bwd: incomplete BatchNorm tail");
     HeadP p;
     int rc = fill_head(p, in, in_cs, cin_p, in_scale, in_shift, in_relu, w, bias, imap, Ci, Co, act, head_mode, N,
                        nvox_per_item, "head_bwd");
@@ -465,16 +476,17 @@ int head_bwd_impl(const T* in, int in_cs, int cin_p, const float* in_scale, cons
                 "head_bwd: the BatchNorm reduction needs mean/invstd, a BN+ReLU input transform and bn_cp <= cin_p (bn_cp=%d)", bn_cp);
     const int nb = head_blocks((int64_t)N * nvox_per_item);
     hipStream_t st = (hipStream_t)stream;
-    const int nfin = Co * Ci + Co;
+    const int nfin = Co * Ci + Co + (tail ? 1 : 0);      // + the BatchNorm finalize block
+    const ctu_bn_bwd_tail tl = bwd_tail_or_off(tail);
     if (cin_p == 8) {
         head_bwd_q_kernel<8, T><<<nb, HB, 0, st>>>(p, g0, g1, gin, gin_cs, ws, bn_mean, bn_invstd, bn_cp, bn_partials);
-        head_bwd_final_kernel<8><<<nfin, HB, 0, st>>>(ws, nb, Ci, Co, imap, dw, db);
+        head_bwd_final_kernel<8><<<nfin, HB, 0, st>>>(ws, nb, Ci, Co, imap, dw, db, bn_partials, bn_cp, tl);
     } else if (cin_p == 16) {
         head_bwd_q_kernel<16, T><<<nb, HB, 0, st>>>(p, g0, g1, gin, gin_cs, ws, bn_mean, bn_invstd, bn_cp, bn_partials);
-        head_bwd_final_kernel<16><<<nfin, HB, 0, st>>>(ws, nb, Ci, Co, imap, dw, db);
+        head_bwd_final_kernel<16><<<nfin, HB, 0, st>>>(ws, nb, Ci, Co, imap, dw, db, bn_partials, bn_cp, tl);
     } else {
         head_bwd_q_kernel<32, T><<<nb, HB, 0, st>>>(p, g0, g1, gin, gin_cs, ws, bn_mean, bn_invstd, bn_cp, bn_partials);
-        head_bwd_final_kernel<32><<<nfin, HB, 0, st>>>(ws, nb, Ci, Co, imap, dw, db);
+        head_bwd_final_kernel<32><<<nfin, HB, 0, st>>>(ws, nb, Ci, Co, imap, dw, db, bn_partials, bn_cp, tl);
     }
     CTU_CHECK_LAUNCH("head_bwd");
     return CTU_OK;
@@ -507,26 +519,26 @@ extern "C" int ctu_head_bwd(const float* in, int in_cs, int cin_p, const float* 
                             int head_mode, const float* g0, const float* g1, float* gin, int gin_cs, float* dw,
                             float* db, float* ws, int N, int64_t nvox_per_item, void* stream) {
     return head_bwd_impl<float>(in, in_cs, cin_p, in_scale, in_shift, in_relu, w, bias, imap, Ci, Co, act, head_mode, g0, g1, gin,
-                                gin_cs, dw, db, ws, N, nvox_per_item, nullptr, nullptr, 0, nullptr, stream);
+                                gin_cs, dw, db, ws, N, nvox_per_item, nullptr, nullptr, 0, nullptr, nullptr, stream);
 }
 
 extern "C" int ctu_head_bwd_bn(const float* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
                                int in_relu, const float* w, const float* bias, const int32_t* imap, int Ci, int Co, int act,
                                int head_mode, const float* g0, const float* g1, float* gin, int gin_cs, float* dw,
                                float* db, float* ws, int N, int64_t nvox_per_item, const float* bn_mean,
-                               const float* bn_invstd, int bn_cp, float* bn_partials, void* stream) {
+                               const float* bn_invstd, int bn_cp, float* bn_partials, const ctu_bn_bwd_tail* tail, void* stream) {
     return head_bwd_impl<float>(in, in_cs, cin_p, in_scale, in_shift, in_relu, w, bias, imap, Ci, Co, act, head_mode, g0, g1, gin,
-                                gin_cs, dw, db, ws, N, nvox_per_item, bn_mean, bn_invstd, bn_cp, bn_partials, stream);
+                                gin_cs, dw, db, ws, N, nvox_per_item, bn_mean, bn_invstd, bn_cp, bn_partials, tail, stream);
 }
 /* bn_partials NULL: plain head backward */
 extern "C" int ctu_lp_head_bwd_bn(int dtype, const void* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
                                   int in_relu, const float* w, const float* bias, const int32_t* imap, int Ci, int Co, int act,
                                   int head_mode, const float* g0, const float* g1, void* gin, int gin_cs, float* dw,
                                   float* db, float* ws, int N, int64_t nvox_per_item, const float* bn_mean,
-                                  const float* bn_invstd, int bn_cp, float* bn_partials, void* stream) {
+                                  const float* bn_invstd, int bn_cp, float* bn_partials, const ctu_bn_bwd_tail* tail, void* stream) {
     CTU_DISPATCH_LP(dtype, return head_bwd_impl<T>((const T*)in, in_cs, cin_p, in_scale, in_shift, in_relu, w, bias, imap, Ci, Co, act,
                                                    head_mode, g0, g1, (T*)gin, gin_cs, dw, db, ws, N, nvox_per_item, bn_mean,
-                                                   bn_invstd, bn_cp, bn_partials, stream));
+                                                   bn_invstd, bn_cp, bn_partials, tail, stream));
 }
 
 extern "C" size_t ctu_loss_ws_floats(int N, int64_t V) {

@@ -18,6 +18,7 @@
 // scatters to the fine grid (float4 per lane), adds the border-class bias and carries the BatchNorm partial sums.
 #include <type_traits>
 #include "common.h"
+#include "bn_tail.h"
 
 namespace {
 
@@ -34,6 +35,7 @@ struct UpP {
     int in_cs, rin_p, in_relu, out_cs, nout_p;
     int N, D, H, W;           // COARSE dims
     int tiles_d, tiles_h, tiles_w;
+    ctu_bn_tail tail;         // counter != NULL: the last block of the launch finalizes the BatchNorm (bn_tail.h)
 };
 
 // PW (8 padded output channels): a 16-wide tile would be half empty, so the w-parity moves into the tile instead --
@@ -317,9 +319,10 @@ __global__ __launch_bounds__(256, 2) void upconv_fused_fwd_kernel(UpP p, int nti
                 a1 += sRed[(w * NTP * 16 + ch) * 2 + 0];
                 a2 += sRed[(w * NTP * 16 + ch) * 2 + 1];
             }
-            row[ch] = a1;
-            row[p.nout_p + ch] = a2;
+            st_sc1(row + ch, a1);
+            st_sc1(row + p.nout_p + ch, a2);
         }
+        if (p.tail.counter) bn_fwd_tail(p.tail, p.stats, gridDim.x * gridDim.y, p.nout_p, gridDim.x * gridDim.y);
     }
 }
 
@@ -930,7 +933,7 @@ extern "C" int ctu_upconv_fused_pack(const float* wt, const float* bt, const flo
 
 extern "C" int ctu_upconv_fused_fwd(const float* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
                                     int in_relu, const float* wp, const float* beff, float* out, int out_cs, int nout_p,
-                                    float* stats, int N, int D, int H, int W, void* stream) {
+                                    float* stats, int N, int D, int H, int W, const ctu_bn_tail* tail, void* stream) {
     CTU_REQUIRE(in && wp && beff && out, "upconv_fused_fwd: null pointer");
     CTU_REQUIRE(ctu_upconv_fused_supported(3, D, H, W, cin_p, nout_p), "upconv_fused_fwd: unsupported geometry (W=%d cin_p=%d nout_p=%d)",
                 W, cin_p, nout_p);
@@ -942,6 +945,10 @@ extern "C" int ctu_upconv_fused_fwd(const float* in, int in_cs, int cin_p, const
                 "upconv_fused_fwd: volume too large for 32-bit offsets");
     UpP p;
     p.in = in; p.in_scale = in_scale; p.in_shift = in_shift; p.wp = wp; p.beff = beff; p.out = out; p.stats = stats;
+    CTU_REQUIRE(!tail || (stats && tail->counter && tail->gamma && tail->beta && tail->scale && tail->shift && tail->mean &&
+                          tail->invstd && tail->C > 0 && tail->C <= nout_p && tail->count > 0),
+                "upconv_fused_fwd: incomplete BatchNorm tail");
+    p.tail = tail_or_off(tail);
     p.in_cs = in_cs; p.rin_p = cin_p; p.in_relu = in_relu; p.out_cs = out_cs; p.nout_p = nout_p;
     p.N = N; p.D = D; p.H = H; p.W = W;
     p.tiles_d = ceil_div(D, 4); p.tiles_h = ceil_div(H, 4); p.tiles_w = ceil_div(W, 16);

@@ -27,6 +27,22 @@ class PackJob(C.Structure):
                 ("layout", C.c_int)]
 
 
+class BnTail(C.Structure):
+    """ctu_bn_tail of include/ctunet_hip.h."""
+    _fields_ = [("gamma", C.c_void_p), ("beta", C.c_void_p), ("running_mean", C.c_void_p), ("running_var", C.c_void_p),
+                ("scale", C.c_void_p), ("shift", C.c_void_p), ("mean", C.c_void_p), ("invstd", C.c_void_p),
+                ("num_batches_tracked", C.c_void_p), ("counter", C.c_void_p), ("count", C.c_double),
+                ("momentum", C.c_float), ("eps", C.c_float), ("C", C.c_int), ("n_updates", C.c_int)]
+
+
+class BnBwdTail(C.Structure):
+    """ctu_bn_bwd_tail of include/ctunet_hip.h."""
+    _fields_ = [("gamma", C.c_void_p), ("invstd", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p),
+                ("coef", C.c_void_p), ("mean", C.c_void_p), ("running_mean", C.c_void_p), ("running_var", C.c_void_p),
+                ("num_batches_tracked", C.c_void_p), ("counter", C.c_void_p), ("count", C.c_double),
+                ("momentum", C.c_float), ("eps", C.c_float), ("C", C.c_int)]
+
+
 # name -> (restype, argtypes); mirrors include/ctunet_hip.h one to one
 SIGNATURES = {
     "ctu_last_error": (C.c_char_p, []),
@@ -41,25 +57,25 @@ SIGNATURES = {
     "ctu_conv3d_num_blocks": (I, [I, I, I, I, I, I, I]),
     "ctu_pack_conv3d_weight": (I, [P, P, I, I, I, P, I, I, I, I, P]),
     "ctu_pack_batch": (I, [P, I, P]),
-    "ctu_conv3d_fwd": (I, [P, I, I, P, P, I, P, P, I, P, I, I, P, I, I, I, I, I, I, P]),
+    "ctu_conv3d_fwd": (I, [P, I, I, P, P, I, P, P, I, P, I, I, P, I, I, I, I, I, I, P, P]),
     "ctu_conv3d_wgrad_ws_floats": (Z, [I, I, I, I, I, I, I]),
     "ctu_conv3d_wgrad": (I, [P, I, I, P, P, I, P, I, I, P, P, I, I, P, P, I, I, I, I, I, P]),
     "ctu_conv3d_first_supported": (I, [I, I, I, I]),
     "ctu_conv3d_first_num_blocks": (I, [I, I, I, I]),
-    "ctu_conv3d_first_fwd": (I, [P, I, P, P, I, P, I, I, P, I, I, I, I, P]),
+    "ctu_conv3d_first_fwd": (I, [P, I, P, P, I, P, I, I, P, I, I, I, I, P, P]),
     "ctu_conv3d_first_bwd_data": (I, [P, I, P, I, I, P, I, I, I, I, P]),
     "ctu_conv3d_first_wgrad_ws_floats": (Z, [I, I, I, I, I]),
     "ctu_conv3d_first_wgrad": (I, [P, I, P, I, P, I, P, I, I, I, I, P]),
     "ctu_bn_finalize": (I, [P, I, I, I, D, P, P, P, P, F, F, I, P, P, P, P, P, P]),
     "ctu_bn_eval_affine": (I, [P, P, P, P, F, I, I, P, P, P]),
     "ctu_bn_bwd_num_blocks": (I, [L]),
-    "ctu_bn_relu_bwd_reduce": (I, [P, I, P, I, I, P, P, P, P, L, P, P]),
+    "ctu_bn_relu_bwd_reduce": (I, [P, I, P, I, I, P, P, P, P, L, P, P, P]),
     "ctu_bn_bwd_finalize": (I, [P, I, I, I, D, P, P, P, P, P, P, P, P, F, F, P, P]),
     "ctu_bn_relu_bwd_apply": (I, [P, I, P, I, I, P, P, P, P, P, L, P]),
     "ctu_maxpool2_fwd": (I, [P, I, I, P, P, I, P, I, I, I, I, I, P]),
     "ctu_maxpool2_bwd": (I, [P, I, I, P, P, I, P, I, P, I, I, I, I, I, I, P]),
     "ctu_maxpool2_bwd_bn_num_blocks": (I, [I, I, I, I, I]),
-    "ctu_maxpool2_bwd_bn": (I, [P, I, I, P, P, P, P, P, I, P, I, I, I, I, I, I, P, P]),
+    "ctu_maxpool2_bwd_bn": (I, [P, I, I, P, P, P, P, P, I, P, I, I, I, I, I, I, P, P, P]),
     "ctu_convt_packed_floats": (Z, [I, I]),
     "ctu_pack_convt_weight": (I, [P, P, I, I, P, I, I, I, P]),
     "ctu_convt2_fwd": (I, [P, I, I, P, P, I, P, P, I, P, I, I, I, I, I, I, P]),
@@ -70,7 +86,7 @@ SIGNATURES = {
     "ctu_head_bwd_ws_floats": (Z, [I, L, I, I]),
     "ctu_head_bwd": (I, [P, I, I, P, P, I, P, P, P, I, I, I, I, P, P, P, I, P, P, P, I, L, P]),
     "ctu_head_bwd_num_blocks": (I, [I, L]),
-    "ctu_head_bwd_bn": (I, [P, I, I, P, P, I, P, P, P, I, I, I, I, P, P, P, I, P, P, P, I, L, P, P, I, P, P]),
+    "ctu_head_bwd_bn": (I, [P, I, I, P, P, I, P, P, P, I, I, I, I, P, P, P, I, P, P, P, I, L, P, P, I, P, P, P]),
     "ctu_loss_ws_floats": (Z, [I, L]),
     "ctu_loss_fwd": (I, [P, P, I, L, F, F, I, P, P, P]),
     "ctu_loss_bwd": (I, [P, P, I, L, F, F, I, P, P, P, P, I, P]),
@@ -80,7 +96,7 @@ SIGNATURES = {
     "ctu_upconv_fused_num_blocks": (I, [I, I, I, I, I]),
     "ctu_upconv_fused_pack_ws_floats": (Z, [I, I]),
     "ctu_upconv_fused_pack": (I, [P, P, P, I, I, P, I, I, P, P, P, P]),
-    "ctu_upconv_fused_fwd": (I, [P, I, I, P, P, I, P, P, P, I, I, P, I, I, I, I, P]),
+    "ctu_upconv_fused_fwd": (I, [P, I, I, P, P, I, P, P, P, I, I, P, I, I, I, I, P, P]),
     "ctu_upconv_fused_wgrad_ws_floats": (Z, [I, I, I, I, I, I]),
     "ctu_upconv_fused_wgrad": (I, [P, I, I, P, P, I, P, I, I, P, P, I, I, I, I, P]),
     "ctu_upconv_fused_project_ws_floats": (Z, [I, L]),
@@ -100,10 +116,10 @@ SIGNATURES = {
     "ctu_lp_conv3d_num_blocks": (I, [I, I, I, I, I, I]),
     "ctu_lp_pack_conv3d_weight": (I, [I, P, P, I, I, I, P, I, I, I, P]),
     "ctu_lp_pack_batch": (I, [I, P, I, P]),
-    "ctu_lp_conv3d_fwd": (I, [I, P, I, I, P, P, I, P, P, I, P, I, I, P, I, I, I, I, I, P]),
+    "ctu_lp_conv3d_fwd": (I, [I, P, I, I, P, P, I, P, P, I, P, I, I, P, I, I, I, I, I, P, P]),
     "ctu_lp_conv3d_wgrad_ws_floats": (Z, [I, I, I, I, I, I, I]),
     "ctu_lp_conv3d_wgrad": (I, [I, P, I, I, P, P, I, P, I, I, P, I, I, P, P, I, I, I, I, I, P]),
-    "ctu_lp_conv3d_first_fwd": (I, [I, P, I, P, P, I, P, I, I, P, I, I, I, I, P]),
+    "ctu_lp_conv3d_first_fwd": (I, [I, P, I, P, P, I, P, I, I, P, I, I, I, I, P, P]),
     "ctu_lp_conv3d_first_bwd_data": (I, [I, P, I, P, I, I, P, I, I, I, I, P]),
     "ctu_lp_conv3d_first_wgrad": (I, [I, P, I, P, I, P, I, P, I, I, I, I, P]),
     "ctu_lp_convt_packed_elems": (Z, [I, I, I]),
@@ -114,15 +130,15 @@ SIGNATURES = {
     "ctu_lp_convt2_wgrad": (I, [I, P, I, I, P, P, I, P, I, I, P, I, I, P, P, I, I, I, I, P]),
     "ctu_lp_ncdhw_to_ndhwc": (I, [I, P, P, I, I, I, I, I, I, I, P]),
     "ctu_lp_ndhwc_to_ncdhw": (I, [I, P, P, I, I, I, I, I, I, P]),
-    "ctu_lp_bn_relu_bwd_reduce": (I, [I, P, I, P, I, I, P, P, P, P, L, P, P]),
+    "ctu_lp_bn_relu_bwd_reduce": (I, [I, P, I, P, I, I, P, P, P, P, L, P, P, P]),
     "ctu_lp_bn_relu_bwd_apply": (I, [I, P, I, P, I, I, P, P, P, P, P, L, P]),
     "ctu_lp_maxpool2_fwd": (I, [I, P, I, I, P, P, I, P, I, I, I, I, I, P]),
     "ctu_lp_maxpool2_bwd": (I, [I, P, I, I, P, P, I, P, I, P, I, I, I, I, I, I, P]),
-    "ctu_lp_maxpool2_bwd_bn": (I, [I, P, I, I, P, P, P, P, P, I, P, I, I, I, I, I, I, P, P]),
+    "ctu_lp_maxpool2_bwd_bn": (I, [I, P, I, I, P, P, P, P, P, I, P, I, I, I, I, I, I, P, P, P]),
     "ctu_lp_skip_add": (I, [I, P, I, P, P, I, P, I, P, P, I, P, I, I, L, P]),
     "ctu_lp_channel_sum": (I, [I, P, I, I, L, P, P, I, P]),
     "ctu_lp_head_fwd": (I, [I, P, I, I, P, P, I, P, P, P, I, I, I, I, P, P, I, L, P]),
-    "ctu_lp_head_bwd_bn": (I, [I, P, I, I, P, P, I, P, P, P, I, I, I, I, P, P, P, I, P, P, P, I, L, P, P, I, P, P]),
+    "ctu_lp_head_bwd_bn": (I, [I, P, I, I, P, P, I, P, P, P, I, I, I, I, P, P, P, I, P, P, P, I, L, P, P, I, P, P, P]),
     "ctu_scale_tensors": (I, [P, P, I, F, P]),
     "ctu_comm_available": (I, []),
     "ctu_comm_unique_id": (I, [P]),
@@ -135,7 +151,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 4          # CTU_ABI_VERSION of the csrc/ this file mirrors (bumped on any signature change)
+ABI_VERSION = 5          # CTU_ABI_VERSION of the csrc/ this file mirrors (bumped on any signature change)
 
 
 class CtuError(RuntimeError):

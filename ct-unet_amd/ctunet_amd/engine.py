@@ -35,6 +35,9 @@ FUSE_UP_MAX_CO = int(os.environ.get("CTUNET_FUSE_UP_MAXCO", "16"))     # widest 
 # the max-pool backward also emits the BatchNorm-backward reduction of the layer it pools (CTUNET_POOL_BN=0: separate pass)
 POOL_BN = os.environ.get("CTUNET_POOL_BN", "1") != "0"
 BN_MOMENTUM = 0.1
+# the launch that writes a BatchNorm's partial rows also finalizes them (its last block: ctu_bn_tail / ctu_bn_bwd_tail)
+# instead of a separate ctu_bn_finalize / ctu_bn_bwd_finalize launch (CTUNET_BN_TAIL=0: the separate launches)
+BN_TAIL = os.environ.get("CTUNET_BN_TAIL", "0") != "0"
 # the generic UNet's dead centre block (models.py:241) runs on a forked stream beside the decoder (CTUNET_CENTER_SIDE=0: in line)
 CENTER_SIDE = os.environ.get("CTUNET_CENTER_SIDE", "0") != "0"
 
@@ -85,8 +88,23 @@ class UNetEngine:
         self._replay_stats = False
         self._up_cache: Dict[str, Tuple] = {}
         self._imaps: Dict[Tuple, torch.Tensor] = {}
+        self._tail_words: Dict[str, torch.Tensor] = {}      # device -> int32 ticket counters, one per (layer, direction)
+        self._tail_slots: Dict[Tuple[str, str], int] = {}
 
     # ------------------------------------------------------------------ small helpers
+    def _counter(self, layer: str, direction: str, device) -> Optional[torch.Tensor]:
+        """The zero-initialised ticket word of a BatchNorm layer's in-launch finalize (None: BN_TAIL off).  The tail puts
+        it back to zero itself, so the words are allocated once and live as long as the engine (graph replays included)."""
+        if not BN_TAIL:
+            return None
+        words = self._tail_words.get(str(device))
+        if words is None:
+            words = self._tail_words[str(device)] = torch.zeros(1024, dtype=torch.int32, device=device)
+        slot = self._tail_slots.setdefault((layer, direction), len(self._tail_slots))
+        if slot >= words.numel():
+            raise RuntimeError("ctunet_amd: more than 1024 BatchNorm tails in one engine")
+        return words[slot:slot + 1]
+
     def _maps(self, segs: Tuple[Tuple[int, int], ...], cp: int, device):
         """segs: ((n_logical, padded_start), ...).  Returns (imap, cinv) int32 device tensors:
         imap[logical] -> padded position, cinv[padded position] -> logical or -1; (None, None) = identity."""
@@ -150,6 +168,14 @@ class UNetEngine:
             ops.pack_batch(jobs)
 
     # ------------------------------------------------------------------ forward pieces
+    def _fwd_tail(self, P, bn: str, c: int, nvox: int, n_upd: int, vec4: torch.Tensor, device):
+        counter = self._counter(bn, "fwd", device)
+        if counter is None:
+            return None
+        return ops.make_bn_tail(c, nvox, P[bn + ".weight"], P[bn + ".bias"], P[bn + ".running_mean"], P[bn + ".running_var"],
+                                BN_MOMENTUM, BN_EPS, n_upd, vec4, P.get(bn + ".num_batches_tracked") if n_upd else None,
+                                counter)
+
     def _conv_bn(self, P, x: CL, conv: str, bn: str, cin: int, cout: int, imap, out: CL, vec4: torch.Tensor,
                  training: bool, n_upd: int, save: bool) -> Tuple[CL, Optional[_ConvRec]]:
         k = self.plan.k
@@ -163,10 +189,12 @@ class UNetEngine:
         if training:
             nblk = ops.conv_num_blocks(dims, out.cp, lay, k, self.dtype, x.cp)
             stats = torch.empty((nblk, 2, out.cp), dtype=torch.float32, device=x.buf.device)
-            ops.conv3d_fwd(x, wp, bias_p, out, k, stats, (cin, cout), lay)
-            ops.bn_finalize_into(stats, nblk, c, out.cp, x.nvox, P[bn + ".weight"], P[bn + ".bias"],
-                                 P[bn + ".running_mean"], P[bn + ".running_var"], BN_MOMENTUM, BN_EPS, n_upd, vec4,
-                                 P.get(bn + ".num_batches_tracked") if n_upd else None)
+            tail = self._fwd_tail(P, bn, c, x.nvox, n_upd, vec4, x.buf.device)
+            ops.conv3d_fwd(x, wp, bias_p, out, k, stats, (cin, cout), lay, tail)
+            if tail is None:
+                ops.bn_finalize_into(stats, nblk, c, out.cp, x.nvox, P[bn + ".weight"], P[bn + ".bias"],
+                                     P[bn + ".running_mean"], P[bn + ".running_var"], BN_MOMENTUM, BN_EPS, n_upd, vec4,
+                                     P.get(bn + ".num_batches_tracked") if n_upd else None)
         else:
             stats, nblk = None, 0
             ops.conv3d_fwd(x, wp, bias_p, out, k, None, (cin, cout), lay)
@@ -206,10 +234,12 @@ class UNetEngine:
         if training:
             nblk = ops.upconv_fused_num_blocks(x.dims, out.cp)
             stats = torch.empty((nblk, 2, out.cp), dtype=torch.float32, device=x.buf.device)
-            ops.upconv_fused_fwd(x, wp, beff, out, stats, (ct, cout))
-            ops.bn_finalize_into(stats, nblk, cout, out.cp, nvox, P[bn + ".weight"], P[bn + ".bias"],
-                                 P[bn + ".running_mean"], P[bn + ".running_var"], BN_MOMENTUM, BN_EPS, n_upd, vec4,
-                                 P.get(bn + ".num_batches_tracked") if n_upd else None)
+            tail = self._fwd_tail(P, bn, cout, nvox, n_upd, vec4, x.buf.device)
+            ops.upconv_fused_fwd(x, wp, beff, out, stats, (ct, cout), tail)
+            if tail is None:
+                ops.bn_finalize_into(stats, nblk, cout, out.cp, nvox, P[bn + ".weight"], P[bn + ".bias"],
+                                     P[bn + ".running_mean"], P[bn + ".running_var"], BN_MOMENTUM, BN_EPS, n_upd, vec4,
+                                     P.get(bn + ".num_batches_tracked") if n_upd else None)
         else:
             stats, nblk = None, 0
             ops.upconv_fused_fwd(x, wp, beff, out, None, (ct, cout))
@@ -235,10 +265,12 @@ class UNetEngine:
         if training:
             nblk = ops.conv_first_num_blocks(dims)
             stats = torch.empty((nblk, 2, out.cp), dtype=torch.float32, device=x.device)
-            ops.conv_first_fwd(x, w, bias_p, out, stats)
-            ops.bn_finalize_into(stats, nblk, cout, out.cp, nvox, P[bn + ".weight"], P[bn + ".bias"],
-                                 P[bn + ".running_mean"], P[bn + ".running_var"], BN_MOMENTUM, BN_EPS, n_upd, vec4,
-                                 P.get(bn + ".num_batches_tracked") if n_upd else None)
+            tail = self._fwd_tail(P, bn, cout, nvox, n_upd, vec4, x.device)
+            ops.conv_first_fwd(x, w, bias_p, out, stats, tail)
+            if tail is None:
+                ops.bn_finalize_into(stats, nblk, cout, out.cp, nvox, P[bn + ".weight"], P[bn + ".bias"],
+                                     P[bn + ".running_mean"], P[bn + ".running_var"], BN_MOMENTUM, BN_EPS, n_upd, vec4,
+                                     P.get(bn + ".num_batches_tracked") if n_upd else None)
         else:
             stats, nblk = None, 0
             ops.conv_first_fwd(x, w, bias_p, out, None)
@@ -391,16 +423,24 @@ class UNetEngine:
         return out0, out1, ctx
 
     # ------------------------------------------------------------------ backward pieces
+    def _replay(self, P, rec: _ConvRec):
+        # use_checkpoint=True: the recompute in backward repeats every live BN's running-stat update
+        # (models.py:232-255) -- folded into this BN's backward finalize
+        return ((P[rec.bn + ".running_mean"], P[rec.bn + ".running_var"], BN_MOMENTUM, BN_EPS,
+                 P.get(rec.bn + ".num_batches_tracked")) if self._replay_stats else None)
+
+    def _bwd_fin(self, P, rec: _ConvRec, device):
+        """fin= of ops.maxpool_bwd / ops.head_bwd: their launch also finalizes rec's BatchNorm backward (None: BN_TAIL off)."""
+        counter = self._counter(rec.bn, "bwd", device)
+        return None if counter is None else (P[rec.bn + ".weight"].detach(), rec.cout, self._replay(P, rec), counter)
+
     def _conv_bn_bwd(self, P, rec: _ConvRec, ga: CL, gin: Optional[CL], grads: Dict[str, torch.Tensor], ws, part,
-                     pre_reduced: Optional[int] = None):
+                     pre_reduced: Optional[int] = None, finalized=None):
         """ga: gradient w.r.t. the ACTIVATED output (overwritten with the raw-output gradient).
         gin: where to write the gradient w.r.t. this conv's activated input (None: not needed)."""
         k = self.plan.k
-        # use_checkpoint=True: the recompute in backward repeats every live BN's running-stat update
-        # (models.py:232-255; SURVEY K10) -- folded into this BN's backward finalize
-        replay = ((P[rec.bn + ".running_mean"], P[rec.bn + ".running_var"], BN_MOMENTUM, BN_EPS,
-                   P.get(rec.bn + ".num_batches_tracked")) if self._replay_stats else None)
-        dg, db = ops.bn_relu_bwd(rec.y, ga, rec.vec, P[rec.bn + ".weight"].detach(), rec.cout, part, replay, pre_reduced)
+        dg, db = ops.bn_relu_bwd(rec.y, ga, rec.vec, P[rec.bn + ".weight"].detach(), rec.cout, part, self._replay(P, rec),
+                                 pre_reduced, self._counter(rec.bn, "bwd", ga.buf.device), finalized)
         grads[rec.bn + ".weight"], grads[rec.bn + ".bias"] = dg, db
         if rec.first is not None:                  # direct C_in <= 2 kernels; gin is a request flag here
             grads[rec.conv + ".weight"] = ops.conv_first_wgrad(rec.first, ga, rec.cout, ws)
@@ -488,12 +528,14 @@ class UNetEngine:
         # the head's input gradient completes the activated-output gradient of the last decoder conv: its BatchNorm-backward
         # reduction rides on the head backward (as the encoder ones ride on the max-pool backward)
         r_last = recs[(plan.dec[-1].prefix, 2)]
-        head_rows = None
+        head_rows, head_fin = None, None
         if (POOL_BN and head_in.scale is not None and head_in.relu and head_in.scale.data_ptr() == r_last.vec[0].data_ptr()
                 and head_in.c0 == r_last.y.c0 and head_in.buf is r_last.y.buf):
-            dwl, dbl, head_rows = ops.head_bwd(head_in, w2, bl.detach(), ctx["imap_h"], plan.act, plan.head_mode,
-                                               g0.contiguous(), None if g1 is None else g1.contiguous(), g_skip_target(0),
-                                               (r_last.vec, part))
+            fin = self._bwd_fin(P, r_last, head_in.buf.device)
+            res = ops.head_bwd(head_in, w2, bl.detach(), ctx["imap_h"], plan.act, plan.head_mode, g0.contiguous(),
+                               None if g1 is None else g1.contiguous(), g_skip_target(0), (r_last.vec, part), fin)
+            dwl, dbl, head_rows = res[:3]
+            head_fin = res[3] if fin is not None else None
         else:
             dwl, dbl = ops.head_bwd(head_in, w2, bl.detach(), ctx["imap_h"], plan.act, plan.head_mode, g0.contiguous(),
                                     None if g1 is None else g1.contiguous(), g_skip_target(0))
@@ -509,7 +551,8 @@ class UNetEngine:
             r1, r2 = recs[(blk.prefix, 1)], recs[(blk.prefix, 2)]
             g_u2 = CL(gcat[i], 0, cp)
             g_u1 = CL(torch.empty_like(r1.y.buf), 0, cp)
-            self._conv_bn_bwd(P, r2, g_u2, g_u1, grads, ws, part, head_rows if j == nlev - 1 else None)
+            self._conv_bn_bwd(P, r2, g_u2, g_u1, grads, ws, part, head_rows if j == nlev - 1 else None,
+                              head_fin if j == nlev - 1 else None)
             x_in = ctx["dec_in"][j]
             ct = blk.cin
             if j > 0 and plan.skip == "cat":
@@ -564,9 +607,11 @@ class UNetEngine:
             dsk = ctx["dskip"][i]
             fuse = (POOL_BN and dsk.scale is not None and dsk.relu and dsk.scale.data_ptr() == r2.vec[0].data_ptr()
                     and ops.maxpool_bwd_bn_blocks(dsk.dims, dsk.cp) > 0)
-            nb = ops.maxpool_bwd(dsk, g_pool, g_d2, plan.skip != "none", (r2.vec, part) if fuse else None)
+            fin = self._bwd_fin(P, r2, dsk.buf.device) if fuse else None
+            nb = ops.maxpool_bwd(dsk, g_pool, g_d2, plan.skip != "none", (r2.vec, part) if fuse else None, fin)
+            nb, done = nb if fin is not None else (nb, None)
             g_d1 = CL(torch.empty_like(r1.y.buf), 0, cp)
-            self._conv_bn_bwd(P, r2, g_d2, g_d1, grads, ws, part, nb)
+            self._conv_bn_bwd(P, r2, g_d2, g_d1, grads, ws, part, nb, done)
             if i > 0:
                 g_pool = CL(torch.empty_like(ctx["pooled"][i - 1].buf), 0, ctx["pooled"][i - 1].cp)
                 self._conv_bn_bwd(P, r1, g_d1, g_pool, grads, ws, part)

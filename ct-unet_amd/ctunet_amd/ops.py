@@ -48,6 +48,42 @@ def _dual(code: int, name: str, *args) -> None:
         _lib.check(getattr(lib, "ctu_" + name)(*args), name)
 
 
+def _tail_arg(tail):
+    """ctypes argument of an optional ctu_bn_tail / ctu_bn_bwd_tail."""
+    import ctypes
+    return None if tail is None else ctypes.byref(tail)
+
+
+def make_bn_tail(c: int, count, gamma, beta, rmean, rvar, momentum: float, eps: float, n_updates: int, vec4, nbt, counter):
+    """ctu_bn_tail: the launch that writes the BatchNorm partial rows also finalizes them (no ctu_bn_finalize launch).
+    vec4: [4, cp] rows receiving scale, shift, mean, invstd; counter: one zeroed int32 device word owned by the layer."""
+    assert counter.dtype == torch.int32 and counter.is_cuda and counter.numel() == 1
+    assert nbt is None or (nbt.dtype == torch.int64 and nbt.is_cuda and nbt.numel() == 1)
+    t = _lib.BnTail()
+    t.gamma, t.beta = gamma.data_ptr(), beta.data_ptr()
+    t.running_mean, t.running_var = _ptr(rmean), _ptr(rvar)
+    t.scale, t.shift, t.mean, t.invstd = (vec4[i].data_ptr() for i in range(4))
+    t.num_batches_tracked = None if nbt is None else nbt.data_ptr()
+    t.counter = counter.data_ptr()
+    t.count, t.momentum, t.eps, t.C, t.n_updates = float(count), momentum, eps, c, n_updates
+    return t
+
+
+def make_bn_bwd_tail(c: int, count, gamma, vec4, dgb, coef, replay, counter):
+    """ctu_bn_bwd_tail (replaces the ctu_bn_bwd_finalize launch); replay as in bn_relu_bwd."""
+    assert counter is None or (counter.dtype == torch.int32 and counter.is_cuda and counter.numel() == 1)
+    rm, rv, mom, eps, nbt = (tuple(replay) + (None,))[:5] if replay is not None else (None, None, 0.0, 0.0, None)
+    assert nbt is None or (nbt.dtype == torch.int64 and nbt.is_cuda and nbt.numel() == 1)
+    t = _lib.BnBwdTail()
+    t.gamma, t.invstd, t.mean = gamma.data_ptr(), vec4[3].data_ptr(), vec4[2].data_ptr()
+    t.dgamma, t.dbeta, t.coef = dgb[0].data_ptr(), dgb[1].data_ptr(), coef.data_ptr()
+    t.running_mean, t.running_var = _ptr(rm), _ptr(rv)
+    t.num_batches_tracked = None if nbt is None else nbt.data_ptr()
+    t.counter = None if counter is None else counter.data_ptr()
+    t.count, t.momentum, t.eps, t.C = float(count), mom, eps, c
+    return t
+
+
 def lp(t_or_dtype) -> int:
     """dtype code of the ctu_lp_* entry points for a 16-bit activation tensor / dtype; 0 for float32."""
     dt = t_or_dtype if isinstance(t_or_dtype, torch.dtype) else t_or_dtype.dtype
@@ -263,8 +299,10 @@ def conv_num_blocks(dims, nout_p: int, layout: int = 0, k: int = 3, dtype=torch.
 
 
 def conv3d_fwd(x: CL, wp: torch.Tensor, bias: Optional[torch.Tensor], out: CL, k: int,
-               stats: Optional[torch.Tensor] = None, algo_ch: Optional[Tuple[int, int]] = None, layout: int = 0) -> None:
-    """algo_ch = (logical Cin, logical Cout) -- only used to count algorithmic FLOPs when timing."""
+               stats: Optional[torch.Tensor] = None, algo_ch: Optional[Tuple[int, int]] = None, layout: int = 0,
+               tail=None) -> None:
+    """algo_ch = (logical Cin, logical Cout) -- only used to count algorithmic FLOPs when timing.
+    tail: make_bn_tail(...) -- the launch finalizes the BatchNorm of its output itself."""
     n, d, h, w = x.dims
     assert out.dims == x.dims
     lib = _lib.load()
@@ -273,7 +311,7 @@ def conv3d_fwd(x: CL, wp: torch.Tensor, bias: Optional[torch.Tensor], out: CL, k
         t0 = TIMER.begin() if TIMER is not None else None
         _lib.check(lib.ctu_lp_conv3d_fwd(x.lp, x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), wp.data_ptr(),
                                          _ptr(bias), 0 if bias is None else bias.numel(), out.ptr, out.cs, out.cp,
-                                         _ptr(stats), n, d, h, w, k, _stream()), "lp_conv3d_fwd")
+                                         _ptr(stats), n, d, h, w, k, _tail_arg(tail), _stream()), "lp_conv3d_fwd")
         if t0 is not None:
             ci, co = algo_ch if algo_ch is not None else (x.cp, out.cp)
             vox = n * d * h * w
@@ -283,7 +321,7 @@ def conv3d_fwd(x: CL, wp: torch.Tensor, bias: Optional[torch.Tensor], out: CL, k
     t0 = TIMER.begin() if TIMER is not None else None
     _lib.check(lib.ctu_conv3d_fwd(x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), wp.data_ptr(),
                                   _ptr(bias), 0 if bias is None else bias.numel(), out.ptr, out.cs, out.cp, _ptr(stats),
-                                  n, d, h, w, k, layout, _stream()), "conv3d_fwd")
+                                  n, d, h, w, k, layout, _tail_arg(tail), _stream()), "conv3d_fwd")
     if t0 is not None:
         ci, co = algo_ch if algo_ch is not None else (x.cp, out.cp)
         vox = n * d * h * w
@@ -356,14 +394,14 @@ def conv_first_num_blocks(dims) -> int:
 
 
 def conv_first_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: CL,
-                   stats: Optional[torch.Tensor]) -> None:
+                   stats: Optional[torch.Tensor], tail=None) -> None:
     """x: NCDHW float32 on the GPU (read in place); w: torch Conv3d weight [Co, cin, 3, 3, 3]."""
     _need_cuda(x, "input")
     n, cin, d, h, w_ = x.shape
     lib = _lib.load()
     t0 = TIMER.begin() if TIMER is not None else None
     _dual(out.lp, "conv3d_first_fwd", x.data_ptr(), cin, w.data_ptr(), _ptr(bias), 0 if bias is None else bias.numel(),
-          out.ptr, out.cs, w.shape[0], _ptr(stats), n, d, h, w_, _stream())
+          out.ptr, out.cs, w.shape[0], _ptr(stats), n, d, h, w_, _tail_arg(tail), _stream())
     if t0 is not None:
         vox = n * d * h * w_
         TIMER.end(f"first_fwd_kernel<{cin}>", 2.0 * cin * w.shape[0] * 27 * vox, 4.0 * vox * (cin + w.shape[0]), t0)
@@ -430,27 +468,36 @@ def bn_eval_affine(gamma, beta, rmean, rvar, eps, c, cp):
 
 
 def bn_relu_bwd(y: CL, ga: CL, vec: torch.Tensor, gamma: torch.Tensor, c: int, partials: torch.Tensor,
-                replay=None, pre_reduced: Optional[int] = None):
+                replay=None, pre_reduced: Optional[int] = None, counter: Optional[torch.Tensor] = None, finalized=None):
     """In place: ga <- gradient w.r.t. the raw conv output y.  Returns (dgamma, dbeta).
     replay = (running_mean, running_var, momentum, eps[, num_batches_tracked]): also apply the running-stat update a
-    second time (the one torch.utils.checkpoint's recompute performs in backward, models.py:232-255)."""
+    second time (the one torch.utils.checkpoint's recompute performs in backward, models.py:232-255).
+    counter: the reduction launch finalizes itself (ctu_bn_bwd_tail) instead of a ctu_bn_bwd_finalize launch.
+    finalized = (dgb, coef): the kernel that produced ga already reduced AND finalized (maxpool_bwd / head_bwd with fin=)."""
     lib = _lib.load()
     nvox = y.nvox
     cp = y.cp
-    nb = lib.ctu_bn_bwd_num_blocks(nvox) if pre_reduced is None else pre_reduced
-    assert partials.numel() >= nb * 2 * cp
     sc, sh, mu, istd = (vec[i].data_ptr() for i in range(4))
     st = _stream()
-    if pre_reduced is None:       # (else: the kernel that produced ga wrote the nb reduction rows, maxpool_bwd(bn=...))
-        assert ga.dtype == y.dtype
-        _dual(y.lp, "bn_relu_bwd_reduce", y.ptr, y.cs, ga.ptr, ga.cs, cp, sc, sh, mu, istd, nvox, partials.data_ptr(), st)
+    if finalized is not None:
+        dgb, coef = finalized
+        _dual(y.lp, "bn_relu_bwd_apply", y.ptr, y.cs, ga.ptr, ga.cs, cp, sc, sh, mu, istd, coef.data_ptr(), nvox, st)
+        return dgb[0], dgb[1]
+    nb = lib.ctu_bn_bwd_num_blocks(nvox) if pre_reduced is None else pre_reduced
+    assert partials.numel() >= nb * 2 * cp
     dgb = torch.empty((2, c), dtype=torch.float32, device=y.buf.device)
     coef = torch.empty((3, cp), dtype=torch.float32, device=y.buf.device)
-    rm, rv, mom, eps, nbt = (tuple(replay) + (None,))[:5] if replay is not None else (None, None, 0.0, 0.0, None)
-    assert nbt is None or (nbt.dtype == torch.int64 and nbt.is_cuda and nbt.numel() == 1)
-    _lib.check(lib.ctu_bn_bwd_finalize(partials.data_ptr(), nb, c, cp, float(nvox), gamma.data_ptr(), istd,
-                                       dgb[0].data_ptr(), dgb[1].data_ptr(), coef.data_ptr(), mu, _ptr(rm), _ptr(rv),
-                                       mom, eps, None if nbt is None else nbt.data_ptr(), st), "bn_bwd_finalize")
+    tail = make_bn_bwd_tail(c, nvox, gamma, vec, dgb, coef, replay, counter) if (counter is not None and pre_reduced is None) else None
+    if pre_reduced is None:       # (else: the kernel that produced ga wrote the nb reduction rows, maxpool_bwd(bn=...))
+        assert ga.dtype == y.dtype
+        _dual(y.lp, "bn_relu_bwd_reduce", y.ptr, y.cs, ga.ptr, ga.cs, cp, sc, sh, mu, istd, nvox, partials.data_ptr(),
+              _tail_arg(tail), st)
+    if tail is None:
+        rm, rv, mom, eps, nbt = (tuple(replay) + (None,))[:5] if replay is not None else (None, None, 0.0, 0.0, None)
+        assert nbt is None or (nbt.dtype == torch.int64 and nbt.is_cuda and nbt.numel() == 1)
+        _lib.check(lib.ctu_bn_bwd_finalize(partials.data_ptr(), nb, c, cp, float(nvox), gamma.data_ptr(), istd,
+                                           dgb[0].data_ptr(), dgb[1].data_ptr(), coef.data_ptr(), mu, _ptr(rm), _ptr(rv),
+                                           mom, eps, None if nbt is None else nbt.data_ptr(), st), "bn_bwd_finalize")
     _dual(y.lp, "bn_relu_bwd_apply", y.ptr, y.cs, ga.ptr, ga.cs, cp, sc, sh, mu, istd, coef.data_ptr(), nvox, st)
     return dgb[0], dgb[1]
 
@@ -473,9 +520,11 @@ def maxpool_bwd_bn_blocks(dims, cp: int) -> int:
     return _lib.load().ctu_maxpool2_bwd_bn_num_blocks(n, d, h, w, cp)
 
 
-def maxpool_bwd(x: CL, gout: CL, gin: CL, accumulate: bool, bn=None) -> Optional[int]:
+def maxpool_bwd(x: CL, gout: CL, gin: CL, accumulate: bool, bn=None, fin=None):
     """bn = (vec [4, cp] scale/shift/mean/invstd of x's BatchNorm, partials): also emit that BatchNorm's backward
-    reduction rows into partials; returns their number (pass it to bn_relu_bwd(pre_reduced=...))."""
+    reduction rows into partials; returns their number (pass it to bn_relu_bwd(pre_reduced=...)).
+    fin = (gamma, c, replay, counter) with bn: the launch also finalizes that reduction (ctu_bn_bwd_tail); returns
+    (rows, (dgb, coef)) -- pass the pair to bn_relu_bwd(finalized=...)."""
     n, d, h, w = x.dims
     lib = _lib.load()
     if bn is not None:
@@ -483,9 +532,16 @@ def maxpool_bwd(x: CL, gout: CL, gin: CL, accumulate: bool, bn=None) -> Optional
         nb = lib.ctu_maxpool2_bwd_bn_num_blocks(n, d, h, w, x.cp)
         assert x.scale is not None and x.relu and partials.numel() >= nb * 2 * x.cp
         assert vec[0].data_ptr() == x.scale.data_ptr() and vec[1].data_ptr() == x.shift.data_ptr()
+        tail, done = None, None
+        if fin is not None:
+            gamma, c, replay, counter = fin
+            dgb = torch.empty((2, c), dtype=torch.float32, device=x.buf.device)
+            coef = torch.empty((3, x.cp), dtype=torch.float32, device=x.buf.device)
+            tail, done = make_bn_bwd_tail(c, x.nvox, gamma, vec, dgb, coef, replay, counter), (dgb, coef)
         _dual(x.lp, "maxpool2_bwd_bn", x.ptr, x.cs, x.cp, vec[0].data_ptr(), vec[1].data_ptr(), vec[2].data_ptr(),
-              vec[3].data_ptr(), gout.ptr, gout.cs, gin.ptr, gin.cs, int(accumulate), n, d, h, w, partials.data_ptr(), _stream())
-        return nb
+              vec[3].data_ptr(), gout.ptr, gout.cs, gin.ptr, gin.cs, int(accumulate), n, d, h, w, partials.data_ptr(),
+              _tail_arg(tail), _stream())
+        return nb if fin is None else (nb, done)
     _dual(x.lp, "maxpool2_bwd", x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), gout.ptr, gout.cs, gin.ptr,
           gin.cs, int(accumulate), n, d, h, w, _stream())
 
@@ -613,9 +669,10 @@ def head_fwd(x: CL, w: torch.Tensor, b: torch.Tensor, imap, act: int, head_mode:
 
 
 def head_bwd(x: CL, w: torch.Tensor, b: torch.Tensor, imap, act: int, head_mode: int, g0: torch.Tensor,
-             g1: Optional[torch.Tensor], gin: CL, bn=None):
+             g1: Optional[torch.Tensor], gin: CL, bn=None, fin=None):
     """bn = (vec [4, bn_cp] of the BatchNorm whose activated output is x's first bn_cp channels, partials): also emit
-    that BatchNorm's backward reduction rows; returns (dw, db, rows) then (rows -> bn_relu_bwd(pre_reduced=...))."""
+    that BatchNorm's backward reduction rows; returns (dw, db, rows) then (rows -> bn_relu_bwd(pre_reduced=...)).
+    fin = (gamma, c, replay) with bn: the launch pair also finalizes that reduction; returns (dw, db, rows, (dgb, coef))."""
     n, d, h, w_ = x.dims
     co, ci = w.shape[0], w.shape[1]
     v = d * h * w_
@@ -629,13 +686,19 @@ def head_bwd(x: CL, w: torch.Tensor, b: torch.Tensor, imap, act: int, head_mode:
         bn_cp = vec.shape[1]
         rows = lib.ctu_head_bwd_num_blocks(n, v)
         assert x.scale is not None and x.relu and vec[0].data_ptr() == x.scale.data_ptr() and partials.numel() >= rows * 2 * bn_cp
+        tail, done = None, None
+        if fin is not None:
+            gamma, c, replay = fin[:3]
+            dgb = torch.empty((2, c), dtype=torch.float32, device=dev)
+            coef = torch.empty((3, bn_cp), dtype=torch.float32, device=dev)
+            tail, done = make_bn_bwd_tail(c, n * v, gamma, vec, dgb, coef, replay, None), (dgb, coef)
         _dual(x.lp, "head_bwd_bn", x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), w.data_ptr(), b.data_ptr(),
               _ptr(imap), ci, co, act, head_mode, g0.data_ptr(), _ptr(g1), gin.ptr, gin.cs, dw.data_ptr(), db.data_ptr(),
-              ws.data_ptr(), n, v, vec[2].data_ptr(), vec[3].data_ptr(), bn_cp, partials.data_ptr(), _stream())
-        return dw, db, rows
+              ws.data_ptr(), n, v, vec[2].data_ptr(), vec[3].data_ptr(), bn_cp, partials.data_ptr(), _tail_arg(tail), _stream())
+        return (dw, db, rows) if fin is None else (dw, db, rows, done)
     _dual(x.lp, "head_bwd_bn", x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), w.data_ptr(), b.data_ptr(),
           _ptr(imap), ci, co, act, head_mode, g0.data_ptr(), _ptr(g1), gin.ptr, gin.cs, dw.data_ptr(), db.data_ptr(),
-          ws.data_ptr(), n, v, None, None, 0, None, _stream())
+          ws.data_ptr(), n, v, None, None, 0, None, None, _stream())
     return dw, db
 
 
@@ -727,14 +790,15 @@ def upconv_fused_num_blocks(dims, nout_p: int) -> int:
 
 
 def upconv_fused_fwd(x: CL, wp: torch.Tensor, beff: torch.Tensor, out: CL, stats: Optional[torch.Tensor],
-                     algo_ch: Optional[Tuple[int, int]] = None) -> None:
+                     algo_ch: Optional[Tuple[int, int]] = None, tail=None) -> None:
     """out (fine grid, raw) = conv3(convT(act(x))) in one kernel; x is the COARSE input."""
     n, d, h, w = x.dims
     assert out.dims == (n, 2 * d, 2 * h, 2 * w)
     lib = _lib.load()
     t0 = TIMER.begin() if TIMER is not None else None
     _lib.check(lib.ctu_upconv_fused_fwd(x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), wp.data_ptr(),
-                                        beff.data_ptr(), out.ptr, out.cs, out.cp, _ptr(stats), n, d, h, w, _stream()),
+                                        beff.data_ptr(), out.ptr, out.cs, out.cp, _ptr(stats), n, d, h, w, _tail_arg(tail),
+                                        _stream()),
                "upconv_fused_fwd")
     if t0 is not None:
         ci, co = algo_ch if algo_ch is not None else (x.cp, out.cp)

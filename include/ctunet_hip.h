@@ -47,6 +47,34 @@ extern "C" {
 #define CTU_BF16 1
 #define CTU_F16 2
 
+/* In-launch BatchNorm finalize ("tail"), optional on every entry point that writes BatchNorm partial rows: with a
+ * non-NULL tail the block of that launch that finishes last reduces the rows itself and writes what the separate
+ * ctu_bn_finalize (forward rows) / ctu_bn_bwd_finalize (backward rows) launch would have written, with the same
+ * arithmetic -- one launch less per BatchNorm layer and direction (34 per UNet() train step).  The fields are those
+ * calls' arguments.  counter: one zero-initialised 32-bit word in device memory per layer and direction; the tail leaves
+ * it zero, so a replayed graph needs no memset.  NULL tail = rows only (finalize with the separate call).
+ * Reference: nn.BatchNorm3d in train mode and its autograd (ctunet/pytorch/models.py:27-32,39-44). */
+typedef struct ctu_bn_tail {
+    const float* gamma; const float* beta;
+    float* running_mean; float* running_var;          /* NULL: no running-statistics update */
+    float* scale; float* shift; float* mean; float* invstd;
+    long long* num_batches_tracked;                   /* NULL: none */
+    unsigned int* counter;
+    double count;                                     /* N*D*H*W of the normalised tensor */
+    float momentum, eps;
+    int C, n_updates;
+} ctu_bn_tail;
+typedef struct ctu_bn_bwd_tail {
+    const float* gamma; const float* invstd;
+    float* dgamma; float* dbeta; float* coef;         /* coef [3][cp] as ctu_bn_bwd_finalize */
+    const float* mean; float* running_mean; float* running_var;   /* the replayed update; NULL running_mean: none */
+    long long* num_batches_tracked;
+    unsigned int* counter;
+    double count;
+    float momentum, eps;
+    int C;
+} ctu_bn_bwd_tail;
+
 const char* ctu_last_error(void);
 /* Library/ABI version (bumped on any signature change). */
 int ctu_abi_version(void);
@@ -117,7 +145,7 @@ int ctu_conv3d_fwd(const float* in, int in_cs, int rin_p,
                    const float* in_scale, const float* in_shift, int in_relu,
                    const float* wp, const float* bias, int nbias,
                    float* out, int out_cs, int nout_p, float* stats,
-                   int N, int D, int H, int W, int k, int layout, void* stream);
+                   int N, int D, int H, int W, int k, int layout, const ctu_bn_tail* tail, void* stream);
 
 /* Weight gradient of nn.Conv3d: dW[co,ci,tap] = sum_v A(in[v+tap, pos(ci)]) * gout[v, co],
  * pos = inverse of cinv.
@@ -144,7 +172,7 @@ int ctu_conv3d_first_supported(int k, int cin, int nout_p, int W);
 int ctu_conv3d_first_num_blocks(int N, int D, int H, int W);
 int ctu_conv3d_first_fwd(const float* x, int cin, const float* w, const float* bias, int nbias,
                          float* out, int out_cs, int Co, float* stats,
-                         int N, int D, int H, int W, void* stream);
+                         int N, int D, int H, int W, const ctu_bn_tail* tail, void* stream);
 int ctu_conv3d_first_bwd_data(const float* g, int g_cs, const float* w, int cin, int Co, float* dx,
                               int N, int D, int H, int W, void* stream);
 size_t ctu_conv3d_first_wgrad_ws_floats(int N, int D, int H, int W, int cin);
@@ -178,7 +206,7 @@ int ctu_bn_eval_affine(const float* gamma, const float* beta, const float* runni
 int ctu_bn_bwd_num_blocks(int64_t nvox);
 int ctu_bn_relu_bwd_reduce(const float* y, int y_cs, const float* ga, int g_cs, int cp,
                            const float* scale, const float* shift, const float* mean,
-                           const float* invstd, int64_t nvox, float* partials, void* stream);
+                           const float* invstd, int64_t nvox, float* partials, const ctu_bn_bwd_tail* tail, void* stream);
 /* running_mean/running_var non-NULL: additionally replay the running-statistics update once, with the batch
  * statistics saved by ctu_bn_finalize (mean, invstd) -- the second update torch.utils.checkpoint's recompute
  * performs in backward when use_checkpoint=True (models.py:232-255). */
@@ -212,7 +240,7 @@ int ctu_maxpool2_bwd(const float* in, int in_cs, int cp, const float* in_scale,
 int ctu_maxpool2_bwd_bn_num_blocks(int N, int D, int H, int W, int cp);
 int ctu_maxpool2_bwd_bn(const float* in, int in_cs, int cp, const float* in_scale, const float* in_shift,
                         const float* mean, const float* invstd, const float* gout, int gout_cs, float* gin,
-                        int gin_cs, int accumulate, int N, int D, int H, int W, float* partials, void* stream);
+                        int gin_cs, int accumulate, int N, int D, int H, int W, float* partials, const ctu_bn_bwd_tail* tail, void* stream);
 
 /* -------------------------------------------------- ConvTranspose3d k2 s2 ---- */
 /* nn.ConvTranspose3d(C, C, 2, 2) with bias (models.py:37,427-429):
@@ -268,7 +296,7 @@ int ctu_head_bwd_bn(const float* in, int in_cs, int cin_p, const float* in_scale
                     const int32_t* imap, int Ci, int Co, int act, int head_mode,
                     const float* g0, const float* g1, float* gin, int gin_cs,
                     float* dw, float* db, float* ws, int N, int64_t nvox_per_item,
-                    const float* bn_mean, const float* bn_invstd, int bn_cp, float* bn_partials, void* stream);
+                    const float* bn_mean, const float* bn_invstd, int bn_cp, float* bn_partials, const ctu_bn_bwd_tail* tail, void* stream);
 
 /* ------------------------------------------------------------------- loss ---- */
 /* Fused Dice + cross-entropy on one 2-channel NCDHW map (utilities.py:35-50,
@@ -313,7 +341,7 @@ int ctu_upconv_fused_pack(const float* wt, const float* bt, const float* w3, int
                           int cin_p, int nout_p, float* wp, float* beff, float* ws, void* stream);
 int ctu_upconv_fused_fwd(const float* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
                          int in_relu, const float* wp, const float* beff, float* out, int out_cs, int nout_p,
-                         float* stats, int N, int D, int H, int W, void* stream);
+                         float* stats, int N, int D, int H, int W, const ctu_bn_tail* tail, void* stream);
 
 /* Backward of the fused up-convolution w.r.t. the three parameter tensors (its data gradient: ctu_upconv_fused_bwd_data
  * below).  ctu_upconv_fused_wgrad: dweff [8 parities][8 taps][cin_p][nout_p] = sum_i x[i+d]^T dy[2i+p]
@@ -389,7 +417,7 @@ int ctu_lp_pack_batch(int dtype, const ctu_pack_job* jobs, int n, void* stream);
  * (the voxel box of a launch grows when rin_p is small, so the row count depends on it) */
 int ctu_lp_conv3d_fwd(int dtype, const void* in, int in_cs, int rin_p, const float* in_scale, const float* in_shift,
                       int in_relu, const void* wp, const float* bias, int nbias, void* out, int out_cs, int nout_p,
-                      float* stats, int N, int D, int H, int W, int k, void* stream);
+                      float* stats, int N, int D, int H, int W, int k, const ctu_bn_tail* tail, void* stream);
 /* weight gradient -> dw fp32 [Co,Ci,k,k,k] (torch layout); ws: ctu_lp_conv3d_wgrad_ws_floats() floats */
 size_t ctu_lp_conv3d_wgrad_ws_floats(int N, int D, int H, int W, int k, int cin_p, int cout_p);
 int ctu_lp_conv3d_wgrad(int dtype, const void* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
@@ -398,7 +426,7 @@ int ctu_lp_conv3d_wgrad(int dtype, const void* in, int in_cs, int cin_p, const f
 
 /* first encoder convolution (C_in <= 2): the input x and dx stay fp32 NCDHW, the 8-channel side tensor is 16-bit */
 int ctu_lp_conv3d_first_fwd(int dtype, const float* x, int cin, const float* w, const float* bias, int nbias, void* out,
-                            int out_cs, int Co, float* stats, int N, int D, int H, int W, void* stream);
+                            int out_cs, int Co, float* stats, int N, int D, int H, int W, const ctu_bn_tail* tail, void* stream);
 int ctu_lp_conv3d_first_bwd_data(int dtype, const void* g, int g_cs, const float* w, int cin, int Co, float* dx, int N,
                                  int D, int H, int W, void* stream);
 int ctu_lp_conv3d_first_wgrad(int dtype, const float* x, int cin, const void* g, int g_cs, float* dw, int Co, float* ws,
@@ -424,7 +452,7 @@ int ctu_lp_ndhwc_to_ncdhw(int dtype, const void* src, float* dst, int N, int C, 
                           void* stream);
 int ctu_lp_bn_relu_bwd_reduce(int dtype, const void* y, int y_cs, const void* ga, int g_cs, int cp, const float* scale,
                               const float* shift, const float* mean, const float* invstd, int64_t nvox,
-                              float* partials, void* stream);
+                              float* partials, const ctu_bn_bwd_tail* tail, void* stream);
 int ctu_lp_bn_relu_bwd_apply(int dtype, const void* y, int y_cs, void* ga, int g_cs, int cp, const float* scale,
                              const float* shift, const float* mean, const float* invstd, const float* coef,
                              int64_t nvox, void* stream);
@@ -435,7 +463,7 @@ int ctu_lp_maxpool2_bwd(int dtype, const void* in, int in_cs, int cp, const floa
                         int N, int D, int H, int W, void* stream);
 int ctu_lp_maxpool2_bwd_bn(int dtype, const void* in, int in_cs, int cp, const float* in_scale, const float* in_shift,
                            const float* mean, const float* invstd, const void* gout, int gout_cs, void* gin,
-                           int gin_cs, int accumulate, int N, int D, int H, int W, float* partials, void* stream);
+                           int gin_cs, int accumulate, int N, int D, int H, int W, float* partials, const ctu_bn_bwd_tail* tail, void* stream);
 int ctu_lp_skip_add(int dtype, const void* a, int a_cs, const float* a_scale, const float* a_shift, int a_relu,
                     const void* b, int b_cs, const float* b_scale, const float* b_shift, int b_relu,
                     void* out, int out_cs, int cp, int64_t nvox, void* stream);
@@ -449,7 +477,7 @@ int ctu_lp_head_bwd_bn(int dtype, const void* in, int in_cs, int cin_p, const fl
                        int in_relu, const float* w, const float* bias, const int32_t* imap, int Ci, int Co, int act,
                        int head_mode, const float* g0, const float* g1, void* gin, int gin_cs, float* dw,
                        float* db, float* ws, int N, int64_t nvox_per_item, const float* bn_mean,
-                       const float* bn_invstd, int bn_cp, float* bn_partials, void* stream);
+                       const float* bn_invstd, int bn_cp, float* bn_partials, const ctu_bn_bwd_tail* tail, void* stream);
 /* Every tensor of a list scaled in place by s (one launch): un-scaling of loss-scaled fp16 gradients.
  * ptrs: HOST array of n DEVICE float pointers, sizes: HOST int64[n]. */
 int ctu_scale_tensors(void* const* ptrs, const int64_t* sizes, int n, float s, void* stream);

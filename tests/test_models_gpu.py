@@ -289,7 +289,10 @@ def oracle_train_check(name, size, batch=1, seed=1234, want_fp64=True, lowp=None
             if err(got, r64) > max(5 * err(c32, r64), floor * scale) + 1e-7:
                 misses.append((n_, err(got, r64), err(c32, r64), scale))
             a, b = got.detach().cpu().double().flatten(), r64.flatten()
-            if b.norm() > 1e-3 * scale * b.numel() ** 0.5 and float(torch.dot(a, b) / (a.norm() * b.norm())) < 0.995:
+            w64 = g64.get(n_[:-4] + "weight") if n_.endswith(".bias") else None
+            if w64 is not None and w64.dim() == 5 and b.norm() < 1e-3 * w64.norm():
+                continue                                   # conv bias in front of a BatchNorm: the true gradient is zero
+            if float(torch.dot(a, b) / (a.norm() * b.norm())) < 0.995:
                 misses.append((n_, "cosine", float(torch.dot(a, b) / (a.norm() * b.norm()))))
         assert not misses, misses
     else:
@@ -717,3 +720,42 @@ def test_integer_targets_and_empty_loss_list():
     h0 = Holder(0.0, 0.0)
     PH.ProblemHandler.comp_losses_metrics(h0, out, oh, 0, 1)
     assert float(h0.pt_loss) == 0.0 and h0.losses_and_metrics == {"epoch_loss": [0.0]}
+
+
+@pytest.mark.parametrize("name,dtype", [("UNet", "fp32"), ("UNetSP", "fp32"), ("recAE_v2_fixed", "fp32"), ("UNet", "bf16")])
+def test_in_launch_bn_finalize_equals_the_separate_launches(name, dtype, monkeypatch):
+    """ctu_bn_tail / ctu_bn_bwd_tail (the last block of the launch that writes a BatchNorm's partial rows finalizes them)
+    against the separate ctu_bn_finalize / ctu_bn_bwd_finalize launches: same rows, same fp64 arithmetic, another
+    summation order of the doubles -> outputs, every gradient and every BatchNorm buffer agree to fp32 rounding; three
+    steps in a row, so a ticket counter that was not put back to zero would show."""
+    import ctunet_amd
+    from ctunet_amd import engine
+
+    def run(tail):
+        monkeypatch.setattr(engine, "BN_TAIL", tail)
+        torch.manual_seed(0)
+        net = getattr(ctunet_amd, name)().cuda().train().set_precision(dtype)
+        x = torch.randn(1, net._plan.in_ch, 32, 32, 32, generator=gen(5)).cuda()
+        outs = None
+        for _ in range(3):
+            for p in net.parameters():
+                p.grad = None
+            out = net(x)
+            outs = out if isinstance(out, tuple) else (out,)
+            sum((o ** 2).mean() for o in outs).backward()
+        return ([o.detach().cpu() for o in outs], {n_: p.grad.cpu() for n_, p in net.named_parameters() if p.grad is not None},
+                {k: v.cpu() for k, v in net.state_dict().items() if "running" in k or "num_batches" in k})
+
+    o1, g1, b1 = run(True)
+    o0, g0, b0 = run(False)
+    tol = 1e-6 if dtype == "fp32" else 2e-2            # 16-bit: a last-bit difference of a scale flips roundings downstream
+    for a, b in zip(o1, o0):
+        assert rel_err(a, b) < tol
+    assert g1.keys() == g0.keys()
+    for k in g1:
+        assert (g1[k] - g0[k]).abs().max().item() <= tol * 50 * max(g0[k].abs().max().item(), 1e-6), k
+    for k in b1:
+        if "num_batches" in k:
+            assert torch.equal(b1[k], b0[k]), k
+        else:
+            assert torch.allclose(b1[k], b0[k], rtol=1e-6, atol=1e-7), k
