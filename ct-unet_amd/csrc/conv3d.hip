@@ -703,9 +703,337 @@ __global__ __launch_bounds__(256, (NT == 1 && !PAIR) ? 3 : 2) void conv3d_fwd_k3
 }
 
 
+// ------------------------------------------------------------------ persistent k = 5 kernels (the legacy nets: recAE_v2_fixed,
+// UNet4_2IC; models.py:393-538).  Same structure as conv3d_fwd_k3_persist (contiguous box range per block, register prefetch
+// of the next stage's input, swapped operands, one stats row per block) with what 125 taps change:
+//  * halo 2: the LDS image of a 4x4x16 box is 8x8x20 voxels (61 KB), of the pair layout's 4x4x32 box 8x8x36 (92 KB); a whole
+//    chunk of weights (64 / 77 KB) does not fit beside it, so the weights stream through LDS ONE kd PLANE at a time (25 or 30
+//    taps, double-buffered, prefetched into registers during the previous plane's MFMAs): one extra barrier per plane;
+//  * one block (4 waves) per CU: a stage carries 1000-1200 MFMAs per wave (32-38 k cycles), so the exposed staging of a
+//    single resident wave per SIMD is a few percent (the k = 3 kernels need 2-3 waves per SIMD to hide theirs);
+//  * tap group = (kd, kw): the 8 input rows th' = 0..7 feed the 5 kh taps of the 4 M-tiles -- 8 + 5*NT fragment reads for
+//    40*NT MFMAs;
+//  * PAIR (C_out = 8): columns = (w-shift s, co) as for k = 3, 6 w-offsets -> 150 tile-taps instead of 250.
+template <int NT, bool PAIR>
+__global__ __launch_bounds__(256, 1) void conv3d_fwd_k5_persist(ConvP p, int ntiles, int tiles_per_block) {
+    constexpr int KS = 5, PAD = 2;
+    constexpr int MT = 4;
+    constexpr int TD = 4, TH = 4, TW = PAIR ? 32 : 16;
+    constexpr int HD = TD + 2 * PAD, HH = TH + 2 * PAD, HW = TW + 2 * PAD, HV = HD * HH * HW;
+    constexpr int NTHR = 256;
+    constexpr int KWN = PAIR ? KS + 1 : KS, PTAPS = KS * KWN, NTAP = KS * PTAPS;
+    constexpr int WPL = PTAPS * NT * 128;                                 // floats of one kd plane of this block's weights
+    constexpr int AITEMS = HV * 2, AITER = (AITEMS + NTHR - 1) / NTHR;
+    constexpr int WITER = (WPL / 4 + NTHR - 1) / NTHR;
+    static_assert(!PAIR || NT == 1, "pair layout has a single N tile");
+    constexpr int VSK = PAIR ? 10 : 12, VS2 = VSK / 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char k5_smem[];
+    v2f* sA2 = reinterpret_cast<v2f*>(k5_smem);                           // [HV * VS2]
+    v2f* sW2 = sA2 + HV * VS2;                                            // [2][WPL / 2]
+    float* sRed = reinterpret_cast<float*>(sW2 + WPL);                    // [4 * NT * 16 * 2]
+    typedef const volatile __attribute__((address_space(3))) v2f* lds_v2f_ptr;
+    lds_v2f_ptr vA = (lds_v2f_ptr)sA2;
+    lds_v2f_ptr vW = (lds_v2f_ptr)sW2;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, kq = lane >> 4;
+    const int by = blockIdx.y;
+    const int n16 = p.n16;
+    const int nchunk = p.rin_p >> 3;
+    const int half = tid & 1;
+    const bool has_xf = p.in_scale != nullptr;
+    const int rowbase = ((wave * HH) * HW + (PAIR ? 2 * m : m)) * VS2 + kq;                 // float2 units
+    const int bbase = kq * 16 + m;
+
+    unsigned hoff[AITER];
+    constexpr int FPW = 5, NFW = (AITER + FPW - 1) / FPW;
+    unsigned fw[NFW];
+#pragma unroll
+    for (int q = 0; q < NFW; ++q) fw[q] = 0;
+#pragma unroll
+    for (int it = 0; it < AITER; ++it) {
+        const int i = tid + it * NTHR;
+        const int v = (i < AITEMS) ? (i >> 1) : 0;
+        const int pw = v % HW, t2 = v / HW, ph = t2 % HH, pd = t2 / HH;
+        hoff[it] = (unsigned)(((pd * p.H + ph) * p.W + pw) * p.in_cs + half * 4) * 4u;
+        const unsigned face = (pd < PAD ? 1u : 0u) | (pd >= HD - PAD ? 2u : 0u) | (ph < PAD ? 4u : 0u) | (ph >= HH - PAD ? 8u : 0u) |
+                              (pw < PAD ? 16u : 0u) | (pw >= HW - PAD ? 32u : 0u);
+        fw[it / FPW] |= face << (6 * (it % FPW));
+    }
+    const unsigned safe_off = (unsigned)(((PAD * p.H + PAD) * p.W + PAD) * p.in_cs + half * 4) * 4u;
+
+    f32x4 acc[MT][NT];
+    float s1[NT][4], s2[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s1[nt][r] = 0.f; s2[nt][r] = 0.f; }
+    }
+
+    int tile = blockIdx.x * tiles_per_block;
+    const int tile_end = min(ntiles, tile + tiles_per_block);
+    int c = 0;
+
+    float4 va[AITER], vw[WITER];
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned vmask = 0;
+
+    struct Box { int tx, ty, tz, n; };
+    auto box_of = [&](int t) {
+        Box b;
+        b.tx = t % p.tiles_w; t /= p.tiles_w;
+        b.ty = t % p.tiles_h; t /= p.tiles_h;
+        b.tz = t % p.tiles_d; b.n = t / p.tiles_d;
+        return b;
+    };
+    auto box_next = [&](Box b) {
+        if (++b.tx == p.tiles_w) { b.tx = 0; if (++b.ty == p.tiles_h) { b.ty = 0; if (++b.tz == p.tiles_d) { b.tz = 0; ++b.n; } } }
+        return b;
+    };
+    bool a_interior = false;
+    auto load_a = [&](Box b, int cc) {
+        const int d0 = b.tz * TD, h0 = b.ty * TH, w0 = b.tx * TW;
+        if (has_xf) {
+            sc = *reinterpret_cast<const float4*>(p.in_scale + cc * 8 + half * 4);
+            sh = *reinterpret_cast<const float4*>(p.in_shift + cc * 8 + half * 4);
+        }
+        const long long org = (((long long)b.n * p.D + d0) * p.H + h0) * p.W + w0 - (long long)PAD * ((long long)p.H * p.W + p.W + 1);
+        const char* base = reinterpret_cast<const char*>(p.in + org * p.in_cs + cc * 8);      // halo origin of the box
+        a_interior = d0 >= PAD && h0 >= PAD && w0 >= PAD && d0 + TD + PAD <= p.D && h0 + TH + PAD <= p.H && w0 + TW + PAD <= p.W;
+        if (a_interior) {
+#pragma unroll
+            for (int it = 0; it < AITER; ++it) {
+                if ((it + 1) * NTHR <= AITEMS || tid + it * NTHR < AITEMS)
+                    va[it] = *reinterpret_cast<const float4*>(base + hoff[it]);
+                else
+                    va[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            return;
+        }
+        vmask = 0;
+        // full border box whose neighbours on the inner sides exist: the only out-of-volume items sit on halo faces that
+        // coincide with volume faces (a box origin is a multiple of 4 >= PAD away from the low faces, or on them)
+        if (d0 + TD <= p.D && h0 + TH <= p.H && w0 + TW <= p.W && (d0 + TD == p.D || d0 + TD + PAD <= p.D) &&
+            (h0 + TH == p.H || h0 + TH + PAD <= p.H) && (w0 + TW == p.W || w0 + TW + PAD <= p.W)) {
+            const unsigned bface = (d0 == 0 ? 1u : 0u) | (d0 + TD == p.D ? 2u : 0u) | (h0 == 0 ? 4u : 0u) |
+                                   (h0 + TH == p.H ? 8u : 0u) | (w0 == 0 ? 16u : 0u) | (w0 + TW == p.W ? 32u : 0u);
+#pragma unroll
+            for (int it = 0; it < AITER; ++it) {
+                const bool ok = (fw[it / FPW] & (bface << (6 * (it % FPW)))) == 0u && ((it + 1) * NTHR <= AITEMS || tid + it * NTHR < AITEMS);
+                va[it] = *reinterpret_cast<const float4*>(base + (ok ? hoff[it] : safe_off));
+                vmask |= ok ? (1u << it) : 0u;
+            }
+            return;
+        }
+#pragma unroll
+        for (int it = 0; it < AITER; ++it) {       // ragged box: per-item bounds
+            const int i = tid + it * NTHR, v = i >> 1;
+            const int pw = v % HW, t2 = v / HW, ph = t2 % HH, pd = t2 / HH;
+            const int gd = d0 + pd - PAD, gh = h0 + ph - PAD, gw = w0 + pw - PAD;
+            const bool ok = i < AITEMS && (unsigned)gd < (unsigned)p.D && (unsigned)gh < (unsigned)p.H && (unsigned)gw < (unsigned)p.W;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) {
+                val = *reinterpret_cast<const float4*>(base + hoff[it]);
+                vmask |= 1u << it;
+            }
+            va[it] = val;
+        }
+    };
+    const bool w_full = (by + 1) * NT <= n16;
+    // kd plane `kd` of chunk cc: PTAPS taps x NT tiles x 128 floats of this block's N range
+    auto load_w = [&](int cc, int kd) {
+        const float* wsrc = p.wp + ((size_t)cc * NTAP + (size_t)kd * PTAPS) * n16 * 128 + (size_t)by * NT * 128;
+#pragma unroll
+        for (int it = 0; it < WITER; ++it) {
+            const int i = (tid + it * NTHR) * 4;
+            const int ts = i / (NT * 128), r = i % (NT * 128);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (((it + 1) * NTHR * 4 <= WPL || i < WPL) && (w_full || by * NT * 128 + r < n16 * 128))
+                v = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(wsrc) + (unsigned)(ts * n16 * 128 + r) * 4u);
+            vw[it] = v;
+        }
+    };
+    auto store_w = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < WITER; ++it) {
+            const int i = (tid + it * NTHR) * 4;
+            if ((it + 1) * NTHR * 4 <= WPL || i < WPL) *reinterpret_cast<float4*>(&sW2[buf * (WPL / 2) + (i >> 1)]) = vw[it];
+        }
+    };
+
+    Box box = box_of(tile);
+    load_a(box, 0);
+    load_w(0, 0);
+
+    while (true) {
+        __syncthreads();                       // the previous stage's readers are done with sA and both sW buffers
+        {
+            auto put = [&](int it, float4 val) {
+                const int i = tid + it * NTHR;
+                if ((it + 1) * NTHR <= AITEMS || i < AITEMS) {
+                    if (PAIR) {
+                        sA2[(i >> 1) * VS2 + half * 2] = v2f{val.x, val.y};
+                        sA2[(i >> 1) * VS2 + half * 2 + 1] = v2f{val.z, val.w};
+                    } else {
+                        *reinterpret_cast<float4*>(&sA2[(i >> 1) * VS2 + half * 2]) = val;
+                    }
+                }
+            };
+            if (a_interior) {
+#pragma unroll
+                for (int it = 0; it < AITER; ++it) put(it, has_xf ? xform4(va[it], sc, sh, p.in_relu) : va[it]);
+            } else if (has_xf) {
+#pragma unroll
+                for (int it = 0; it < AITER; ++it) {
+                    const float4 t = xform4(va[it], sc, sh, p.in_relu);
+                    const bool ok = (vmask >> it) & 1u;
+                    put(it, make_float4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f));
+                }
+            } else {
+#pragma unroll
+                for (int it = 0; it < AITER; ++it) {
+                    const bool ok = (vmask >> it) & 1u;
+                    put(it, make_float4(ok ? va[it].x : 0.f, ok ? va[it].y : 0.f, ok ? va[it].z : 0.f, ok ? va[it].w : 0.f));
+                }
+            }
+        }
+        store_w(0);
+        __syncthreads();
+        // ---- prefetch the next stage's input while this one computes
+        int ntile = tile, nc = c + 1;
+        Box nbox = box;
+        if (nc == nchunk) { nc = 0; ntile = tile + 1; nbox = box_next(box); }
+        const bool has_next = ntile < tile_end;
+        if (has_next) load_a(nbox, nc);
+#pragma unroll 1
+        for (int kd = 0; kd < KS; ++kd) {
+            // next plane of weights (or plane 0 of the next stage) into registers under this plane's MFMAs
+            if (kd + 1 < KS) load_w(c, kd + 1);
+            else if (has_next) load_w(nc, 0);
+            const int wb = (kd & 1) * (WPL / 2);
+            v2f ar[2][TH + KS - 1], br[2][KS][NT];
+            auto load_group = [&](int kw, v2f (&aa)[TH + KS - 1], v2f (&bb)[KS][NT]) {
+#pragma unroll
+                for (int r = 0; r < TH + KS - 1; ++r) aa[r] = vA[rowbase + ((kd * HH + r) * HW + kw) * VS2];
+#pragma unroll
+                for (int kh = 0; kh < KS; ++kh)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) bb[kh][nt] = vW[wb + ((kh * KWN + kw) * NT + nt) * 64 + bbase];
+            };
+            load_group(0, ar[0], br[0]);
+#pragma unroll
+            for (int kw = 0; kw < KWN; ++kw) {
+                if (kw + 1 < KWN) load_group(kw + 1, ar[(kw + 1) & 1], br[(kw + 1) & 1]);
+                v2f (&aa)[TH + KS - 1] = ar[kw & 1];
+                v2f (&bb)[KS][NT] = br[kw & 1];
+#pragma unroll
+                for (int kh = 0; kh < KS; ++kh) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bb[kh][nt].x, aa[mt + kh].x, acc[mt][nt], 0, 0, 0);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bb[kh][nt].y, aa[mt + kh].y, acc[mt][nt], 0, 0, 0);
+                }
+            }
+            if (kd + 1 < KS) {
+                store_w((kd + 1) & 1);         // (its last readers finished before the barrier that ended plane kd - 1)
+                __syncthreads();
+            }
+        }
+        if (c == nchunk - 1) {
+            const int n_img = box.n, d0 = box.tz * TD, h0 = box.ty * TH, w0 = box.tx * TW;
+            const int gw = PAIR ? (w0 + 2 * m + (kq >> 1)) : (w0 + m);
+            const bool box_full = d0 + TD <= p.D && h0 + TH <= p.H && w0 + TW <= p.W;
+            float* obase = p.out + ((((size_t)n_img * p.D + d0 + wave) * p.H + h0) * p.W + gw) * p.out_cs;
+            const int orow = p.W * p.out_cs;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int co = PAIR ? (kq & 1) * 4 : (by * NT + nt) * 16 + kq * 4;
+                const bool cok = co < p.nout_p;
+                float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.bias) {
+                    bv.x = co + 0 < p.nbias ? p.bias[co + 0] : 0.f; bv.y = co + 1 < p.nbias ? p.bias[co + 1] : 0.f;
+                    bv.z = co + 2 < p.nbias ? p.bias[co + 2] : 0.f; bv.w = co + 3 < p.nbias ? p.bias[co + 3] : 0.f;
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    if (cok && (box_full || (d0 + wave < p.D && h0 + mt < p.H && gw < p.W))) {
+                        float4 o;
+                        o.x = acc[mt][nt][0] + bv.x; o.y = acc[mt][nt][1] + bv.y;
+                        o.z = acc[mt][nt][2] + bv.z; o.w = acc[mt][nt][3] + bv.w;
+                        *reinterpret_cast<float4*>(obase + mt * orow + co) = o;
+                        s1[nt][0] += o.x; s1[nt][1] += o.y; s1[nt][2] += o.z; s1[nt][3] += o.w;
+                        s2[nt][0] += o.x * o.x; s2[nt][1] += o.y * o.y; s2[nt][2] += o.z * o.z; s2[nt][3] += o.w * o.w;
+                    }
+                    acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        }
+        if (!has_next) break;
+        tile = ntile; c = nc; box = nbox;
+    }
+    if (p.stats) {
+        __syncthreads();
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float a1 = s1[nt][r], a2 = s2[nt][r];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { a1 += __shfl_xor(a1, o); a2 += __shfl_xor(a2, o); }
+                if (PAIR) { a1 += __shfl_xor(a1, 32); a2 += __shfl_xor(a2, 32); }
+                const int ch = PAIR ? (kq & 1) * 4 + r : nt * 16 + kq * 4 + r;
+                if (m == 0 && (!PAIR || kq < 2)) {
+                    sRed[(wave * NT * 16 + ch) * 2 + 0] = a1;
+                    sRed[(wave * NT * 16 + ch) * 2 + 1] = a2;
+                }
+            }
+        __syncthreads();
+        const int nch = PAIR ? 8 : NT * 16;
+        if (tid < nch) {
+            const int co = (PAIR ? 0 : by * NT * 16) + tid;
+            if (co < p.nout_p) {
+                float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    a1 += sRed[(w * NT * 16 + tid) * 2 + 0];
+                    a2 += sRed[(w * NT * 16 + tid) * 2 + 1];
+                }
+                float* row = p.stats + (size_t)blockIdx.x * 2 * p.nout_p;
+                st_sc1(row + co, a1);
+                st_sc1(row + p.nout_p + co, a2);
+            }
+        }
+        if (p.tail.counter) bn_fwd_tail(p.tail, p.stats, gridDim.x, p.nout_p, gridDim.x * gridDim.y);
+    }
+}
+
+// LDS bytes of conv3d_fwd_k5_persist<NT, PAIR>
+template <int NT, bool PAIR>
+constexpr size_t k5_persist_lds() {
+    return (size_t)(8 * 8 * ((PAIR ? 32 : 16) + 4)) * (PAIR ? 10 : 12) * 4 + (size_t)2 * 5 * (PAIR ? 6 : 5) * NT * 128 * 4 +
+           (size_t)4 * NT * 16 * 2 * 4;
+}
+// raise the kernel's dynamic-LDS limit once (above the 64 KB default)
+template <int NT, bool PAIR>
+static hipError_t k5_attr() {
+    static hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_fwd_k5_persist<NT, PAIR>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)k5_persist_lds<NT, PAIR>());
+    return rc;
+}
+
+
+template <int KS>
 __global__ void pack_conv_w_pair8_kernel(const float* __restrict__ w, float* __restrict__ wp, int Co, int Ci,
                                          const int32_t* __restrict__ cinv, int nchunk, int mode) {
-    pack_conv_w_pair8_elem(blockIdx.x * blockDim.x + threadIdx.x, w, wp, Co, Ci, cinv, nchunk, mode);
+    pack_conv_w_pair8_elem<KS>(blockIdx.x * blockDim.x + threadIdx.x, w, wp, Co, Ci, cinv, nchunk, mode);
 }
 
 // ---- every weight tensor of the network in ONE launch: job table by value in the kernel arguments
@@ -719,7 +1047,8 @@ __global__ void pack_batch_kernel(PackTable tb) {
         const int n16 = (q.nout_p + 15) / 16;
         pack_convt_w_elem(idx, q.w, q.wp, q.Ci, q.Co, q.cinv, q.rin_p, n16 <= 1 ? 1 : (n16 <= 2 ? 2 : (n16 <= 4 ? 4 : 8)), q.mode);
     } else if (q.layout == 1) {
-        pack_conv_w_pair8_elem(idx, q.w, q.wp, q.Co, q.Ci, q.cinv, q.rin_p / 8, q.mode);
+        if (q.k == 3) pack_conv_w_pair8_elem<3>(idx, q.w, q.wp, q.Co, q.Ci, q.cinv, q.rin_p / 8, q.mode);
+        else pack_conv_w_pair8_elem<5>(idx, q.w, q.wp, q.Co, q.Ci, q.cinv, q.rin_p / 8, q.mode);
     } else if (q.k == 3) {
         pack_conv_w_elem<3>(idx, q.w, q.wp, q.Co, q.Ci, q.cinv, q.rin_p / 8, (q.nout_p + 15) / 16, q.mode);
     } else {
@@ -746,7 +1075,7 @@ inline void pick_launch(int N, int D, int H, int W, int k, int nout_p, int* nt, 
     auto blocks = [&](int nt_, int td_, int th_, int tw_) {
         return (long)N * ceil_div(D, td_) * ceil_div(H, th_) * ceil_div(W, tw_) * ceil_div(n16, nt_);
     };
-    if (k == 3 && *tw == 16 && *nt > 2) *nt = 2;    // k = 3 at this width runs the persistent kernel (at most 2 N-tiles)
+    if (*tw == 16 && *nt > 2) *nt = 2;              // this width runs the persistent kernels (at most 2 N-tiles)
     while (blocks(*nt, *td, *th, *tw) < 256 && *nt > 1) *nt >>= 1;
     if (blocks(*nt, *td, *th, *tw) < 256 && *tw > 4) { *td = 4; *th = 4; *tw = 4; }
 }
@@ -1327,6 +1656,395 @@ static int launch_wgrad_k3s(WgP p, float* dw, int Co, int Ci, const int32_t* cin
     return CTU_OK;
 }
 
+// ------------------------------------------------------------------ weight gradient, narrow layers (k = 5: the legacy nets)
+// conv3d_wgrad_k3s_kernel's scheme -- (w-shift, channel) tile axes for 8-channel sides, persistent blocks, two LDS stages, the
+// A-fragment register ring -- with what 125 taps change: ONE kd plane of taps per block (blockIdx.z; 5 x QN accumulators
+// instead of 25 x QN: the staged input box is the 4 planes d0 + kd - 2 .. d0 + kd + 1 with an (h, w) halo of 2), and per kh
+// row the w offsets t0 (kw = t0 + s + s'):
+//   SM = SN = 2 (8 -> 8):    t0 = 0 -> kw 0,1 (s' = 0);  t0 = 2 -> kw 2,3,4                        10 MFMAs per K-step (25)
+//   SM = 1, SN = 2 (C -> 8): t0 = 0,1,2,3 -> kw 0, 1, (2,3), 4                                     20
+//   SM = 2, SN = 1 (8 -> C): t0 = 0,2,3 -> kw (0,1), (2,3), 4 (s = 1 of t0 = 3)                    15
+//   SM = SN = 1:             t0 = kw                                                               25
+// An entry that uses the gradient shift s' = 1 misses the term of the volume's last w column (the box decomposition of v
+// never reaches u_w = W - 1), which multiplies a_in at w = W - 1 + kw - 2: zero padding only for kw >= 3 -- so kw <= 2 always
+// come from s' = 0 entries (with pad 1 the k = 3 kernel needs that for kw <= 1 only).
+template <int SM, int SN>
+__global__ __launch_bounds__(256, 2) void conv3d_wgrad_k5s_kernel(WgP p, int tiles_per_block) {
+    constexpr int UP = 0, PAD = 2;
+    const int kd = blockIdx.z;                     // the kd plane of taps this block accumulates
+    // box: 4 x 4 x 16 voxels; 4 x 4 x 8 for the full 16 x 16 channel tile, whose 27 accumulators leave fewer staging registers
+    constexpr int TD = 4, TH = 4, TW = (SM == 2 && SN == 2) ? 16 : 8, HD = TD, HH = TH + 2 * PAD, HW = TW + 2 * PAD, HV = HD * HH * HW;
+    constexpr int KPR = TW / 4, NKS = TH * KPR;       // K-steps (4 voxels) per row / per plane
+    constexpr int CM = 16 / SM, CN = 16 / SN;        // channels per block on the input / output side
+    constexpr int GW = TW + (SN - 1), GV = TD * TH * GW;
+    constexpr int QN = (SM == 2 && SN == 2) ? 2 : ((SM == 1 && SN == 1) ? 5 : (SN == 2 ? 4 : 3));     // w positions t0 per kh row
+    constexpr int NMF = 5 * QN;
+    constexpr int AQ = CM / 4, GQ = CN / 4;
+    constexpr int AITEMS = HV * AQ, AITER = (AITEMS + 255) / 256;
+    constexpr int GITEMS = GV * GQ, GITER = (GITEMS + 255) / 256;
+
+    // two LDS stages: while the MFMAs read stage cur, the prefetched next box is transformed and written into stage
+    // cur ^ 1 between them (ONE barrier per box, no exposed write phase).  Every thread stores every item slot
+    // (the slots beyond the box are padding), so the MFMA loop is a single basic block.
+    constexpr int SAF = AITER * 256 * 4, SGF = GITER * 256 * 4;     // floats per stage
+    static_assert(SAF >= HV * CM && SGF >= GV * CN, "stage size");
+    __shared__ __attribute__((aligned(16))) float sA[2 * SAF];
+    __shared__ __attribute__((aligned(16))) float sG[2 * SGF];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, kq = lane >> 4;
+    const int cig = blockIdx.y % p.n_ci_t, cog = UP ? (blockIdx.y / p.n_ci_t) % p.n_co_t : blockIdx.y / p.n_ci_t;
+    const int par = UP ? blockIdx.y / (p.n_ci_t * p.n_co_t) : 0;          // output parity (pz, py, px) = bits 2, 1, 0
+    const int pz = UP == 2 ? (par >> 1) & 1 : (par >> 2) & 1, py = UP == 2 ? par & 1 : (par >> 1) & 1, px = UP == 2 ? 0 : par & 1;
+    const int gH = UP ? 2 * p.H : p.H, gW = UP ? 2 * p.W : p.W, gs = UP ? 2 : 1;      // gradient grid: row strides, voxel step
+    const int ci0 = cig * CM, co0 = cog * CN;
+    const bool has_xf = p.in_scale != nullptr;
+
+    f32x4 acc[NMF];
+#pragma unroll
+    for (int t = 0; t < NMF; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int aq = tid % AQ, gq = tid % GQ;          // 256 % AQ == 0: a thread keeps its channel quad
+    const bool a_ok = (ci0 + aq * 4) < p.cin_p, g_ok = (co0 + gq * 4) < p.cout_p;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);      // identity without transform
+    if (has_xf && a_ok) {
+        sc = *reinterpret_cast<const float4*>(p.in_scale + ci0 + aq * 4);
+        sh = *reinterpret_cast<const float4*>(p.in_shift + ci0 + aq * 4);
+    }
+    const int xf_relu = has_xf ? p.in_relu : 0;
+    const int boff = (SN == 2) ? ((i < 8) ? i : i - 16) : i;
+
+    int tile = blockIdx.x * tiles_per_block;
+    const int tile_end = min(p.ntiles, tile + tiles_per_block);
+    float4 va[AITER], vg[GITER];
+
+    // staging items: BYTE offsets relative to the box's halo origin (non-negative, so the loads take the
+    // scalar-base + 32-bit-offset addressing form and cost no VALU address arithmetic)
+    unsigned aoff[AITER], goff[GITER];
+    constexpr int FPW = 5;                         // 6-bit halo-face codes per 32-bit word
+    unsigned fw[(AITER + FPW - 1) / FPW], gw0 = 0; // gw0 bit it: gradient item it is the w-shift column (SN = 2)
+#pragma unroll
+    for (int q = 0; q < (AITER + FPW - 1) / FPW; ++q) fw[q] = 0;
+#pragma unroll
+    for (int it = 0; it < AITER; ++it) {
+        const int e = tid + it * 256, v = (e < AITEMS) ? e / AQ : 0;
+        const int pw = v % HW, t2 = v / HW, ph = t2 % HH, pd = t2 / HH;
+        aoff[it] = (unsigned)((((pd + kd) * p.H + ph) * p.W + pw) * p.in_cs + ci0 + aq * 4) * 4u;      // (halo origin of kd = 0)
+        // plane pd of this block is volume plane d0 + pd + kd - PAD: outside below for a box on the low d face when
+        // pd + kd < PAD, outside above for a box on the high face when pd + kd >= TD + PAD
+        const unsigned face = (pd + kd < PAD ? 1u : 0u) | (pd + kd >= TD + PAD ? 2u : 0u) | (ph < PAD ? 4u : 0u) |
+                              (ph >= HH - PAD ? 8u : 0u) | (pw < PAD ? 16u : 0u) | (pw >= HW - PAD ? 32u : 0u);
+        fw[it / FPW] |= face << (6 * (it % FPW));
+    }
+#pragma unroll
+    for (int it = 0; it < GITER; ++it) {
+        const int e = tid + it * 256, v = (e < GITEMS) ? e / GQ : 0;
+        const int tw = v % GW, th = (v / GW) % TH, td = v / (GW * TH);
+        goff[it] = (unsigned)(((gs * td * gH + gs * th) * gW + gs * tw) * p.g_cs + co0 + gq * 4) * 4u;
+        if (SN == 2 && tw == 0) gw0 |= 1u << it;
+    }
+    // a full box's only out-of-volume items sit on halo faces that coincide with volume faces: a load from the box
+    // origin (always inside) stands in for them and the LDS write zeroes them
+    // (UP: channel quads beyond the tensors -- 8 padded output channels in a 16-wide tile -- are masked per thread
+    //  instead of sending the whole block down the ragged path)
+    const unsigned safe_a = (unsigned)(((PAD * p.H + PAD) * p.W + PAD) * p.in_cs + ci0 + aq * 4) * 4u;
+    const unsigned safe_g = (unsigned)((SN - 1) * p.g_cs + co0 + ((UP && !g_ok) ? 0 : gq * 4)) * 4u;
+    const bool ch_full = UP || (ci0 + CM <= p.cin_p && co0 + CN <= p.cout_p);       // uniform
+
+    // box coordinates advance incrementally (no div/mod per box)
+    struct Box { int tx, ty, tz, n; };
+    Box box;
+    {
+        int t = tile;
+        box.tx = t % p.tiles_w; t /= p.tiles_w;
+        box.ty = t % p.tiles_h; t /= p.tiles_h;
+        box.tz = t % p.tiles_d; box.n = t / p.tiles_d;
+    }
+    auto box_next = [&](Box b) {
+        if (++b.tx == p.tiles_w) { b.tx = 0; if (++b.ty == p.tiles_h) { b.ty = 0; if (++b.tz == p.tiles_d) { b.tz = 0; ++b.n; } } }
+        return b;
+    };
+
+    // The loads only FETCH (raw values + a validity bit per item); the lazy-BatchNorm transform happens when the
+    // values are written to LDS one stage later, so no wave ever waits for global memory inside load().
+    unsigned amask = 0, gmask = 0;                 // bit it: item it of va[] / vg[] lies inside the volume
+    const char* pf_abase = nullptr;                // uniform state of the box being fetched
+    const char* pf_gbase = nullptr;
+    unsigned pf_bface = 0;
+    // prep(): scalar part of a fetch.  Returns whether the box is full (inside the volume up to its halo faces), the
+    // precondition of the branch-free per-item forms below; ragged boxes go through load_ragged().
+    auto prep = [&](Box b) -> bool {
+        const int d0 = b.tz * TD, h0 = b.ty * TH, w0 = b.tx * TW;
+        const long long org = (((long long)b.n * p.D + d0) * p.H + h0) * p.W + w0;
+        pf_abase = reinterpret_cast<const char*>(p.in + (org - (long long)PAD * ((long long)p.H * p.W + p.W + 1)) * p.in_cs);
+        if (UP) {
+            const long long gorg = (((long long)b.n * 2 * p.D + 2 * d0 + pz) * gH + 2 * h0 + py) * gW + 2 * w0 + px;
+            pf_gbase = reinterpret_cast<const char*>(p.g + gorg * p.g_cs);
+        } else {
+            pf_gbase = reinterpret_cast<const char*>(p.g + (org - (SN - 1)) * p.g_cs);
+        }
+        pf_bface = (d0 == 0 ? 1u : 0u) | (d0 + TD == p.D ? 2u : 0u) | (h0 == 0 ? 4u : 0u) | (h0 + TH == p.H ? 8u : 0u) |
+                   (w0 == 0 ? 16u : 0u) | (w0 + TW == p.W ? 32u : 0u);
+        amask = 0; gmask = 0;
+        // (the two halo layers beyond a full box's inner sides must exist as a whole: true for volumes that are multiples of the box)
+        return ch_full && d0 + TD <= p.D && h0 + TH <= p.H && w0 + TW <= p.W && (d0 + TD == p.D || d0 + TD + PAD <= p.D) &&
+               (h0 + TH == p.H || h0 + TH + PAD <= p.H) && (w0 + TW == p.W || w0 + TW + PAD <= p.W);
+    };
+    // a full box's only out-of-volume items sit on halo faces that coincide with volume faces: they fetch the box
+    // origin instead (no branch) and are zeroed when written to LDS
+    auto fetch_a = [&](int it) {
+        const bool ok = (fw[it / FPW] & (pf_bface << (6 * (it % FPW)))) == 0u && (!UP || a_ok);
+        va[it] = *reinterpret_cast<const float4*>(pf_abase + (ok ? aoff[it] : safe_a));
+        amask |= ok ? (1u << it) : 0u;
+    };
+    auto fetch_g = [&](int it) {
+        const bool ok = !((pf_bface & 16u) && ((gw0 >> it) & 1u)) && (!UP || g_ok);
+        vg[it] = *reinterpret_cast<const float4*>(pf_gbase + (ok ? goff[it] : safe_g));
+        gmask |= ok ? (1u << it) : 0u;
+    };
+    auto load_ragged = [&](Box b) {                // per-item bounds checks (volume not a multiple of the box, channel tails)
+        const int d0 = b.tz * TD, h0 = b.ty * TH, w0 = b.tx * TW;
+#pragma unroll
+        for (int it = 0; it < AITER; ++it) {
+            const int e = tid + it * 256, v = e / AQ;
+            const int pw = v % HW, t2 = v / HW, ph = t2 % HH, pd = t2 / HH;
+            const int gd = d0 + pd + kd - PAD, gh = h0 + ph - PAD, gw = w0 + pw - PAD;
+            const bool ok = e < AITEMS && a_ok && (unsigned)gd < (unsigned)p.D && (unsigned)gh < (unsigned)p.H &&
+                            (unsigned)gw < (unsigned)p.W;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) {
+                val = *reinterpret_cast<const float4*>(pf_abase + aoff[it]);
+                amask |= 1u << it;
+            }
+            va[it] = val;
+        }
+#pragma unroll
+        for (int it = 0; it < GITER; ++it) {
+            const int e = tid + it * 256, v = e / GQ;
+            const int tw = v % GW, th = (v / GW) % TH, td = v / (GW * TH);
+            const int gd = d0 + td, gh = h0 + th, gw = w0 + tw - (SN - 1);
+            const bool ok = e < GITEMS && g_ok && gd < p.D && gh < p.H && (unsigned)gw < (unsigned)p.W;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) {
+                val = *reinterpret_cast<const float4*>(pf_gbase + goff[it]);
+                gmask |= 1u << it;
+            }
+            vg[it] = val;
+        }
+    };
+
+    // fragment reads: one ds_read_b32 each at a compile-time offset from two per-lane bases, issued one K-step ahead
+    typedef const volatile __attribute__((address_space(3))) float* lds_f_ptr;
+    lds_f_ptr vA = (lds_f_ptr)sA + (((wave + pz) * HH + py) * HW + kq + px) * CM + i;      // (+ the parity's sub-cube origin)
+    lds_f_ptr vG = (lds_f_ptr)sG + ((wave * TH * GW + kq + (SN - 1)) * CN + boff);
+
+    // one staged item -> LDS stage st: transform (identity scale/shift without BatchNorm), zero what lies outside
+    auto put_a = [&](int it, int st) {
+        const float4 t = xform4(va[it], sc, sh, xf_relu);
+        const bool ok = (amask >> it) & 1u;
+        *reinterpret_cast<float4*>(&sA[st * SAF + (tid + it * 256) * 4]) =
+            make_float4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f);
+    };
+    auto put_g = [&](int it, int st) {
+        const bool ok = (gmask >> it) & 1u;
+        *reinterpret_cast<float4*>(&sG[st * SGF + (tid + it * 256) * 4]) =
+            make_float4(ok ? vg[it].x : 0.f, ok ? vg[it].y : 0.f, ok ? vg[it].z : 0.f, ok ? vg[it].w : 0.f);
+    };
+
+    // One box: NKS K-steps of 4 voxels per wave (plane td = wave, row th = ks / KPR, columns (ks % KPR) * 4 + kq).
+    // The NKS * NMF (K-step, tap) MFMAs form one flat stream; their A fragments go through a ring of R registers
+    // refilled R entries ahead (the slot an MFMA has just consumed), the B fragment one K-step ahead.  Between the
+    // MFMAs of the first half of the K-steps the next box's global loads are issued (FETCH), between those of the
+    // second half that box is transformed and written to the other LDS stage -- no phase of its own for either.
+    constexpr bool INLOOP_FETCH = (SM == 2 && SN == 2);      // (the wider tiles run out of registers)
+    int cur = 0;
+    auto stage = [&](auto fetch_tag) {
+        constexpr bool FETCH = decltype(fetch_tag)::value;
+        constexpr int R = 12, NJ = NKS * NMF;
+        constexpr int KW0 = NKS / 2, NIT = AITER + GITER;
+        constexpr int IPF = (NIT + KW0 - 1) / KW0, IPK = (NIT + (NKS - KW0) - 1) / (NKS - KW0);
+        lds_f_ptr cA = vA + cur * SAF;
+        lds_f_ptr cG = vG + cur * SGF;
+        float ar[R], br[2];
+        auto a_read = [&](int j) -> float {
+            const int ks = j / NMF, t = j % NMF;
+            const int th = ks / KPR, tw4 = (ks % KPR) * 4;
+            const int kh = t / QN, q = t % QN;
+            // w offsets t0 of the MFMAs of one kh row: kw = t0 + s + s' (see the reduce kernel for the entries kept)
+            const int t0 = (SM == 1) ? q : ((SN == 1 && q == 2) ? 3 : 2 * q);
+            return cA[((th + kh) * HW + tw4 + t0) * CM];
+        };
+        auto b_read = [&](int ks) -> float { return cG[((ks / KPR) * GW + (ks % KPR) * 4) * CN]; };
+        br[0] = b_read(0);
+#pragma unroll
+        for (int j = 0; j < R; ++j) ar[j] = a_read(j);
+        // the whole ring is in flight before the first MFMA (one exposed LDS latency per box): a fake use of
+        // every slot keeps the scheduler from trickling the fill reads in between the first MFMAs
+        static_assert(R == 12, "fake-use list");
+        asm volatile("" : "+v"(ar[0]), "+v"(ar[1]), "+v"(ar[2]), "+v"(ar[3]), "+v"(ar[4]), "+v"(ar[5]), "+v"(ar[6]),
+                     "+v"(ar[7]), "+v"(ar[8]), "+v"(ar[9]), "+v"(ar[10]), "+v"(ar[11]), "+v"(br[0]));
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            if (ks + 1 < NKS) {
+                br[(ks + 1) & 1] = b_read(ks + 1);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < NMF; ++t) {
+                const int j = ks * NMF + t;
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[j % R], br[ks & 1], acc[t], 0, 0, 0);
+                if (j + R < NJ) ar[j % R] = a_read(j + R);
+                // pin the order: MFMA, then the refill of the slot it consumed
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (j + R < NJ) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            if (FETCH && ks < KW0) {
+#pragma unroll
+                for (int q = 0; q < IPF; ++q) {
+                    const int it = ks * IPF + q;
+                    if (it < AITER) fetch_a(it);
+                    else if (it < NIT) fetch_g(it - AITER);
+                }
+            }
+            if (ks >= KW0) {
+#pragma unroll
+                for (int q = 0; q < IPK; ++q) {
+                    const int it = (ks - KW0) * IPK + q;
+                    if (it < AITER) put_a(it, cur ^ 1);
+                    else if (it < NIT) put_g(it - AITER, cur ^ 1);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    if (tile < tile_end) {
+        if (prep(box)) {
+#pragma unroll
+            for (int it = 0; it < AITER; ++it) fetch_a(it);
+#pragma unroll
+            for (int it = 0; it < GITER; ++it) fetch_g(it);
+        } else {
+            load_ragged(box);
+        }
+#pragma unroll
+        for (int it = 0; it < AITER; ++it) put_a(it, 0);
+#pragma unroll
+        for (int it = 0; it < GITER; ++it) put_g(it, 0);
+    }
+    __syncthreads();
+    while (tile < tile_end) {
+        box = box_next(box);
+        bool full = false;
+        if (tile + 1 < tile_end) {
+            full = prep(box);
+            if (!full) load_ragged(box);
+        }
+        // (after the last box the second half rewrites stale registers into the unread stage)
+        if (INLOOP_FETCH && full) {
+            stage(std::true_type{});
+        } else {
+            if (INLOOP_FETCH == false && full) {
+#pragma unroll
+                for (int it = 0; it < AITER; ++it) fetch_a(it);
+#pragma unroll
+                for (int it = 0; it < GITER; ++it) fetch_g(it);
+            }
+            stage(std::false_type{});
+        }
+        __syncthreads();                           // stage cur fully read, stage cur ^ 1 fully written
+        cur ^= 1;
+        ++tile;
+    }
+    // 4 waves -> one slab [NMF][16][16] per block (through sA, 4 * NMF * 256 floats <= HV * CM for CM = 8 needs rounds)
+    constexpr int RT = (2 * SAF / 1024) < NMF ? (2 * SAF / 1024) : NMF;
+    static_assert(RT >= 1, "reduction scratch");
+    const size_t slab = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    float* dst = p.ws + slab * (NMF * 256);
+    for (int t0 = 0; t0 < NMF; t0 += RT) {
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < NMF; ++t)
+            if (t >= t0 && t < t0 + RT) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sA[(wave * RT + (t - t0)) * 256 + (kq * 4 + r) * 16 + i] = acc[t][r];
+            }
+        __syncthreads();
+        const int nt = (NMF - t0) < RT ? (NMF - t0) : RT;
+        for (int e = tid; e < nt * 256; e += 256)
+            dst[t0 * 256 + e] = (sA[e] + sA[RT * 256 + e]) + (sA[2 * RT * 256 + e] + sA[3 * RT * 256 + e]);
+    }
+}
+
+template <int SM, int SN>
+__global__ __launch_bounds__(1024) void conv3d_wgrad_k5s_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
+                                                                      int Co, int Ci, const int32_t* __restrict__ cinv,
+                                                                      int cin_p, int n_ci_g, int gx) {
+    constexpr int QN = (SM == 2 && SN == 2) ? 2 : ((SM == 1 && SN == 1) ? 5 : (SN == 2 ? 4 : 3));
+    constexpr int NMF = 5 * QN;
+    constexpr int CM = 16 / SM, CN = 16 / SN;
+    __shared__ float red[RPARTS][64];
+    const int e = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int el = blockIdx.x * 64 + e;
+    const int pair = blockIdx.y, kd = blockIdx.z;
+    float s = 0.f;
+    if (el < NMF * 256) {
+        const float* src = ws + ((size_t)kd * gridDim.y + pair) * gx * (NMF * 256) + el;
+        for (int k = part; k < gx; k += RPARTS) s += src[(size_t)k * (NMF * 256)];
+    }
+    red[part][e] = s;
+    __syncthreads();
+    if (part != 0 || el >= NMF * 256) return;
+    const float tot = red_total(red, e);
+    const int t = el >> 8, i = (el >> 4) & 15, j = el & 15;
+    const int kh = t / QN, q = t % QN;
+    const int sm = (SM == 2) ? i / 8 : 0, cil = (SM == 2) ? i % 8 : i;
+    const int sn = (SN == 2) ? j / 8 : 0, col = (SN == 2) ? j % 8 : j;
+    int kw;
+    bool ok = true;
+    if (SM == 1 && SN == 1) kw = q;
+    else if (SM == 2 && SN == 2) {
+        kw = 2 * q + sm + sn;
+        ok = q == 0 ? sn == 0 : !(sm == 0 && sn == 1);        // t0 = 0: kw 0, 1 (s' = 0);  t0 = 2: kw 2, 3 (from s = 1), 4
+    } else if (SN == 2) { kw = q + sn; ok = sn == 0 ? q <= 2 : q >= 2; }     // t0 = q: kw 0, 1, 2 from s' = 0; 3, 4 from s' = 1
+    else { kw = (q == 2 ? 3 : 2 * q) + sm; ok = q < 2 || sm == 1; }      // t0 = 0, 2, 3
+    const int cig = pair % n_ci_g, cog = pair / n_ci_g;
+    const int cip = cig * CM + cil, co = cog * CN + col;
+    const int ci = (cip < cin_p) ? (cinv ? cinv[cip] : (cip < Ci ? cip : -1)) : -1;
+    if (ok && ci >= 0 && co < Co) dw[((size_t)co * Ci + ci) * 125 + (kd * 5 + kh) * 5 + kw] = tot;
+}
+
+// k = 5 layers with an 8-channel side (W >= 16) take the (w-shift, channel) tiles too
+inline bool use_k5s(int k, int W, int cin_p, int cout_p) { return k == 5 && W >= 16 && (cin_p == 8 || cout_p == 8); }
+
+static K3sGeom k5s_geom(int N, int D, int H, int W, int cin_p, int cout_p) {
+    K3sGeom g;
+    g.sm = cin_p == 8 ? 2 : 1; g.sn = cout_p == 8 ? 2 : 1;
+    g.tw = (g.sm == 2 && g.sn == 2) ? 16 : 8;
+    g.nmf = 5 * ((g.sm == 2 && g.sn == 2) ? 2 : ((g.sm == 1 && g.sn == 1) ? 5 : (g.sn == 2 ? 4 : 3)));
+    g.ntiles = N * ceil_div(D, 4) * ceil_div(H, 4) * ceil_div(W, g.tw);
+    g.n_ci_g = ceil_div(cin_p, 16 / g.sm);
+    g.pairs = g.n_ci_g * ceil_div(cout_p, 16 / g.sn);
+    g.gx = wgrad_gx(g.ntiles, g.pairs * 5);
+    g.tpb = ceil_div(g.ntiles, g.gx);
+    g.gx = ceil_div(g.ntiles, g.tpb);
+    return g;
+}
+
+template <int SM, int SN>
+static int launch_wgrad_k5s(WgP p, float* dw, int Co, int Ci, const int32_t* cinv, hipStream_t st) {
+    const K3sGeom g = k5s_geom(p.N, p.D, p.H, p.W, p.cin_p, p.cout_p);
+    p.tiles_d = ceil_div(p.D, 4); p.tiles_h = ceil_div(p.H, 4); p.tiles_w = ceil_div(p.W, g.tw);
+    p.ntiles = g.ntiles;
+    p.n_ci_t = g.n_ci_g;
+    conv3d_wgrad_k5s_kernel<SM, SN><<<dim3(g.gx, g.pairs, 5), 256, 0, st>>>(p, g.tpb);
+    CTU_CHECK_LAUNCH("conv3d_wgrad_k5s");
+    conv3d_wgrad_k5s_reduce_kernel<SM, SN><<<dim3(ceil_div(g.nmf * 256, 64), g.pairs, 5), 64 * RPARTS, 0, st>>>(
+        p.ws, dw, Co, Ci, cinv, p.cin_p, p.n_ci_t, g.gx);
+    CTU_CHECK_LAUNCH("conv3d_wgrad_k5s_reduce");
+    return CTU_OK;
+}
+
 // dW_eff[parity 8][tap 8][cin_p][nout_p] from the slabs of the UP kernel (fixed-order parallel reduction)
 __global__ __launch_bounds__(1024) void upconv_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dweff,
                                                                   int cin_p, int nout_p, int n_ci_g, int n_co_g, int gx) {
@@ -1399,17 +2117,23 @@ static UpWgGeom upwg_geom(int N, int D, int H, int W, int cin_p, int nout_p, boo
 
 }  // namespace
 
+// k == 5: the same boxes, one block per CU -- when the boxes fill the chip (a block owns one whole box per stage)
+static bool use_persist5(int k, int nt, int tw, int N, int D, int H, int W) {
+    return k == 5 && tw == 16 && nt <= 2 && (long)N * ceil_div(D, 4) * ceil_div(H, 4) * ceil_div(W, 16) >= 256;
+}
+
 // =================================================================== C ABI
 extern "C" int ctu_conv3d_layout(int k, int nout_p, int W) {
-    return (k == 3 && nout_p == 8 && W >= 32) ? 1 : 0;
+    return ((k == 3 || k == 5) && nout_p == 8 && W >= 32) ? 1 : 0;
 }
 
 extern "C" const char* ctu_conv3d_fwd_kernel_name(int N, int D, int H, int W, int k, int nout_p, int layout) {
     static thread_local char buf[64];
-    if (layout == 1) return "conv3d_fwd_k3_persist<1, true>";
+    if (layout == 1) return k == 3 ? "conv3d_fwd_k3_persist<1, true>" : "conv3d_fwd_k5_persist<1, true>";
     int nt, td, th, tw;
     pick_launch(N, D, H, W, k, nout_p, &nt, &td, &th, &tw);
-    if (k == 3 && tw == 16 && nt <= 2) snprintf(buf, sizeof(buf), "conv3d_fwd_k3_persist<%d, false>", nt);
+    if (use_persist5(k, nt, tw, N, D, H, W)) snprintf(buf, sizeof(buf), "conv3d_fwd_k5_persist<%d, false>", nt);
+    else if (k == 3 && tw == 16 && nt <= 2) snprintf(buf, sizeof(buf), "conv3d_fwd_k3_persist<%d, false>", nt);
     else snprintf(buf, sizeof(buf), "conv3d_fwd_kernel<%d, %d, %d, %d, %d>", k, nt, td, th, tw);
     return buf;
 }
@@ -1418,6 +2142,8 @@ extern "C" const char* ctu_conv3d_wgrad_kernel_name(int W, int k, int cin_p, int
     static thread_local char buf[64];
     if (use_k3s(k, W, cin_p, cout_p))
         snprintf(buf, sizeof(buf), "conv3d_wgrad_k3s_kernel<%d, %d>", cin_p == 8 ? 2 : 1, cout_p == 8 ? 2 : 1);
+    else if (use_k5s(k, W, cin_p, cout_p))
+        snprintf(buf, sizeof(buf), "conv3d_wgrad_k5s_kernel<%d, %d>", cin_p == 8 ? 2 : 1, cout_p == 8 ? 2 : 1);
     else {
         int td, th, tw;
         pick_tile(W, &td, &th, &tw);
@@ -1428,7 +2154,7 @@ extern "C" const char* ctu_conv3d_wgrad_kernel_name(int W, int k, int cin_p, int
 
 extern "C" size_t ctu_conv3d_packed_floats(int k, int rin_p, int nout_p, int layout) {
     if ((k != 3 && k != 5) || rin_p <= 0 || nout_p <= 0) return 0;
-    if (layout == 1) return (k == 3 && nout_p == 8) ? (size_t)(rin_p / 8) * 36 * 128 : 0;
+    if (layout == 1) return nout_p == 8 ? (size_t)(rin_p / 8) * k * k * (k + 1) * 128 : 0;
     return (size_t)(rin_p / 8) * k * k * k * ceil_div(nout_p, 16) * 128;
 }
 
@@ -1447,12 +2173,16 @@ static bool use_persist(int k, int nt, int tw) { return k == 3 && tw == 16 && nt
 extern "C" int ctu_conv3d_num_blocks(int N, int D, int H, int W, int k, int nout_p, int layout) {
     int gx, tpb;
     if (layout == 1) {
-        persist_grid(N * ceil_div(D, 4) * ceil_div(H, 4) * ceil_div(W, 32), 1, 2, &gx, &tpb);
+        persist_grid(N * ceil_div(D, 4) * ceil_div(H, 4) * ceil_div(W, 32), 1, k == 3 ? 2 : 1, &gx, &tpb);
         return gx;                                   // the persistent kernels write ONE stats row per block
     }
     int nt, td, th, tw;
     pick_launch(N, D, H, W, k, nout_p, &nt, &td, &th, &tw);
     const int ntiles = N * ceil_div(D, td) * ceil_div(H, th) * ceil_div(W, tw);
+    if (use_persist5(k, nt, tw, N, D, H, W)) {
+        persist_grid(ntiles, ceil_div(ceil_div(nout_p, 16), nt), 1, &gx, &tpb);
+        return gx;
+    }
     if (use_persist(k, nt, tw)) {
         persist_grid(ntiles, ceil_div(ceil_div(nout_p, 16), nt), nt == 1 ? 3 : 2, &gx, &tpb);
         return gx;
@@ -1465,12 +2195,12 @@ extern "C" int ctu_pack_conv3d_weight(const float* w, float* wp, int Co, int Ci,
     CTU_REQUIRE(k == 3 || k == 5, "pack_conv3d_weight: k=%d unsupported (3 or 5)", k);
     CTU_REQUIRE(rin_p % 8 == 0 && nout_p % 8 == 0, "pack_conv3d_weight: padded channels must be multiples of 8");
     CTU_REQUIRE(w && wp && Co > 0 && Ci > 0, "pack_conv3d_weight: null/empty argument");
-    CTU_REQUIRE(layout == 0 || (layout == 1 && k == 3 && nout_p == 8), "pack_conv3d_weight: layout %d needs k=3, nout_p=8",
-                layout);
+    CTU_REQUIRE(layout == 0 || (layout == 1 && nout_p == 8), "pack_conv3d_weight: layout %d needs nout_p=8", layout);
     hipStream_t st = (hipStream_t)stream;
     if (layout == 1) {
-        const int tot = (rin_p / 8) * 36 * 128;
-        pack_conv_w_pair8_kernel<<<ceil_div(tot, 256), 256, 0, st>>>(w, wp, Co, Ci, cinv, rin_p / 8, mode);
+        const int tot = (int)ctu_conv3d_packed_floats(k, rin_p, nout_p, 1);
+        if (k == 3) pack_conv_w_pair8_kernel<3><<<ceil_div(tot, 256), 256, 0, st>>>(w, wp, Co, Ci, cinv, rin_p / 8, mode);
+        else pack_conv_w_pair8_kernel<5><<<ceil_div(tot, 256), 256, 0, st>>>(w, wp, Co, Ci, cinv, rin_p / 8, mode);
         CTU_CHECK_LAUNCH("pack_conv3d_weight(pair8)");
         return CTU_OK;
     }
@@ -1500,7 +2230,7 @@ extern "C" int ctu_pack_batch(const ctu_pack_job* jobs, int n, void* stream) {
                 CTU_REQUIRE(q.nout_p <= 128, "pack_batch: convT nout_p=%d", q.nout_p);
                 tot = ctu_convt_packed_floats(q.rin_p, q.nout_p);
             } else {
-                CTU_REQUIRE(q.kind == 0 && (q.k == 3 || q.k == 5) && (q.layout == 0 || (q.layout == 1 && q.k == 3 && q.nout_p == 8)),
+                CTU_REQUIRE(q.kind == 0 && (q.k == 3 || q.k == 5) && (q.layout == 0 || (q.layout == 1 && q.nout_p == 8)),
                             "pack_batch: bad conv job %d", j0 + j);
                 tot = ctu_conv3d_packed_floats(q.k, q.rin_p, q.nout_p, q.layout);
             }
@@ -1553,11 +2283,18 @@ extern "C" int ctu_conv3d_fwd(const float* in, int in_cs, int rin_p, const float
     p.N = N; p.D = D; p.H = H; p.W = W;
     hipStream_t st = (hipStream_t)stream;
     if (layout == 1) {
-        CTU_REQUIRE(k == 3 && nout_p == 8, "conv3d_fwd: layout 1 needs k=3 and nout_p=8");
+        CTU_REQUIRE(nout_p == 8, "conv3d_fwd: layout 1 needs nout_p=8");
         p.n16 = 1;
         p.tiles_d = ceil_div(D, 4); p.tiles_h = ceil_div(H, 4); p.tiles_w = ceil_div(W, 32);
         const int ntiles = N * p.tiles_d * p.tiles_h * p.tiles_w;
         int gx, tpb;
+        if (k == 5) {
+            persist_grid(ntiles, 1, 1, &gx, &tpb);     // 1 resident block per CU (123 KB of LDS)
+            { const hipError_t arc = k5_attr<1, true>(); CTU_REQUIRE(arc == hipSuccess, "conv3d_fwd: cannot raise the dynamic LDS limit of the k=5 kernel"); }
+            conv3d_fwd_k5_persist<1, true><<<gx, 256, k5_persist_lds<1, true>(), st>>>(p, ntiles, tpb);
+            CTU_CHECK_LAUNCH("conv3d_fwd_k5_persist<1, pair>");
+            return CTU_OK;
+        }
         persist_grid(ntiles, 1, 2, &gx, &tpb);         // 2 resident blocks per CU (LDS)
         conv3d_fwd_k3_persist<1, true><<<gx, 256, 0, st>>>(p, ntiles, tpb);
         CTU_CHECK_LAUNCH("conv3d_fwd_k3_persist<1, pair>");
@@ -1566,6 +2303,23 @@ extern "C" int ctu_conv3d_fwd(const float* in, int in_cs, int rin_p, const float
     CTU_REQUIRE(layout == 0, "conv3d_fwd: unknown layout %d", layout);
     int NT, td, th, tw;
     pick_launch(N, D, H, W, k, nout_p, &NT, &td, &th, &tw);
+    if (use_persist5(k, NT, tw, N, D, H, W)) {
+        p.n16 = ceil_div(p.nout_p, 16);
+        p.tiles_d = ceil_div(D, 4); p.tiles_h = ceil_div(H, 4); p.tiles_w = ceil_div(W, 16);
+        const int ntiles = N * p.tiles_d * p.tiles_h * p.tiles_w;
+        const int ny = ceil_div(p.n16, NT);
+        int gx, tpb;
+        persist_grid(ntiles, ny, 1, &gx, &tpb);
+        if (NT == 1) {
+            { const hipError_t arc = k5_attr<1, false>(); CTU_REQUIRE(arc == hipSuccess, "conv3d_fwd: cannot raise the dynamic LDS limit of the k=5 kernel"); }
+            conv3d_fwd_k5_persist<1, false><<<dim3(gx, ny), 256, k5_persist_lds<1, false>(), st>>>(p, ntiles, tpb);
+        } else {
+            { const hipError_t arc = k5_attr<2, false>(); CTU_REQUIRE(arc == hipSuccess, "conv3d_fwd: cannot raise the dynamic LDS limit of the k=5 kernel"); }
+            conv3d_fwd_k5_persist<2, false><<<dim3(gx, ny), 256, k5_persist_lds<2, false>(), st>>>(p, ntiles, tpb);
+        }
+        CTU_CHECK_LAUNCH("conv3d_fwd_k5_persist");
+        return CTU_OK;
+    }
     if (use_persist(k, NT, tw)) {
         // large layers: persistent, register-prefetching kernel
         p.n16 = ceil_div(p.nout_p, 16);
@@ -1611,6 +2365,10 @@ extern "C" size_t ctu_conv3d_wgrad_ws_floats(int N, int D, int H, int W, int k, 
     if (use_k3s(k, W, cin_p, cout_p)) {
         const K3sGeom g = k3s_geom(N, D, H, W, cin_p, cout_p);
         slabs = (size_t)g.pairs * g.gx * g.nmf * 256;
+    }
+    if (use_k5s(k, W, cin_p, cout_p)) {
+        const K3sGeom g = k5s_geom(N, D, H, W, cin_p, cout_p);
+        slabs = (size_t)5 * g.pairs * g.gx * g.nmf * 256;
     }
     const size_t bsum = (size_t)ctu_channel_sum_num_blocks((int64_t)N * D * H * W) * cout_p;
     return slabs > bsum ? slabs : bsum;
@@ -1659,6 +2417,16 @@ extern "C" int ctu_conv3d_wgrad(const float* in, int in_cs, int cin_p, const flo
         else if (cout_p == 8) rc2 = launch_wgrad_k3s<1, 2>(p, dw, Co, Ci, cinv, st);
         else if (cin_p == 8) rc2 = launch_wgrad_k3s<2, 1>(p, dw, Co, Ci, cinv, st);
         else rc2 = launch_wgrad_k3s<1, 1>(p, dw, Co, Ci, cinv, st);
+        if (rc2 != CTU_OK) return rc2;
+        if (dbias) return ctu_channel_sum(gout, g_cs, cout_p, (int64_t)N * D * H * W, ws, dbias, Co, stream);
+        return CTU_OK;
+    }
+    if (use_k5s(k, W, cin_p, cout_p)) {
+        CTU_REQUIRE((int64_t)((4 + 2 * 2) * H + 8) * W * in_cs * 4 < (int64_t)1 << 31, "conv3d_wgrad: volume too large for 32-bit offsets");
+        int rc2;
+        if (cin_p == 8 && cout_p == 8) rc2 = launch_wgrad_k5s<2, 2>(p, dw, Co, Ci, cinv, st);
+        else if (cout_p == 8) rc2 = launch_wgrad_k5s<1, 2>(p, dw, Co, Ci, cinv, st);
+        else rc2 = launch_wgrad_k5s<2, 1>(p, dw, Co, Ci, cinv, st);
         if (rc2 != CTU_OK) return rc2;
         if (dbias) return ctu_channel_sum(gout, g_cs, cout_p, (int64_t)N * D * H * W, ws, dbias, Co, stream);
         return CTU_OK;

@@ -49,29 +49,31 @@ __device__ __forceinline__ void pack_conv_w_elem(int idx, const float* __restric
     wp[idx] = v;
 }
 
-// pair layout packing: [chunk][kd][kh][kw' (4)][kq][n = s*8+o][j]; gather, every element written
+// pair layout packing: [chunk][kd][kh][kw' (KS + 1)][kq][n = s*8+o][j]; gather, every element written
+template <int KS>
 __device__ __forceinline__ void pack_conv_w_pair8_elem(int idx, const float* __restrict__ w, float* __restrict__ wp, int Co,
                                                        int Ci, const int32_t* __restrict__ cinv, int nchunk, int mode) {
-    if (idx >= nchunk * 36 * 128) return;
+    constexpr int KWN = KS + 1, TAPS = KS * KS * KS;
+    if (idx >= nchunk * KS * KS * KWN * 128) return;
     int r = idx;
     const int j = r & 1; r >>= 1;
     const int n = r & 15; r >>= 4;
     const int kq = r & 3; r >>= 2;
-    const int kwp = r & 3; r >>= 2;
-    const int kh = r % 3; r /= 3;
-    const int kd = r % 3; r /= 3;
+    const int kwp = r % KWN; r /= KWN;
+    const int kh = r % KS; r /= KS;
+    const int kd = r % KS; r /= KS;
     const int c = r;
     const int s = n >> 3, o = n & 7, kw = kwp - s;
     const int rp = c * 8 + kq * 2 + j;
     float v = 0.f;
-    if (kw >= 0 && kw <= 2) {
-        const int t = (kd * 3 + kh) * 3 + kw;
+    if (kw >= 0 && kw < KS) {
+        const int t = (kd * KS + kh) * KS + kw;
         if (mode == 0) {
             const int ci = cinv ? cinv[rp] : (rp < Ci ? rp : -1);
-            if (ci >= 0 && o < Co) v = w[((size_t)o * Ci + ci) * 27 + t];
+            if (ci >= 0 && o < Co) v = w[((size_t)o * Ci + ci) * TAPS + t];
         } else {
             const int ci = cinv ? cinv[o] : (o < Ci ? o : -1);
-            if (ci >= 0 && rp < Co) v = w[((size_t)rp * Ci + ci) * 27 + (26 - t)];
+            if (ci >= 0 && rp < Co) v = w[((size_t)rp * Ci + ci) * TAPS + (TAPS - 1 - t)];
         }
     }
     wp[idx] = v;

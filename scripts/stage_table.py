@@ -96,4 +96,5 @@ lines += ["", f"conv / ConvTranspose kernels total: {tot:.3f} ms/step"]
 text = "\n".join(lines)
 print(text)
 if a.out:
+    os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
     open(a.out, "w").write(text + "\n")

@@ -61,6 +61,11 @@ CONV_CASES = [
     (1, 8, 8, 8, 8, 16, 5, False, True),       # legacy k5 + bias
     (1, 2, 7, 6, 10, 18, 5, True, True),
     (1, 16, 64, 4, 4, 8, 5, True, True),
+    (1, 8, 8, 8, 8, 32, 5, True, True),        # k5 pair layout (conv3d_fwd_k5_persist<1, true>): W >= 32, C_out 8
+    (2, 32, 7, 6, 5, 40, 5, True, True),       # k5 pair layout, ragged boxes, 4 chunks, 7 real channels
+    (1, 16, 16, 32, 32, 64, 5, True, False),   # k5 persistent kernel, one N tile (>= 256 boxes), 2 chunks
+    (1, 8, 32, 32, 32, 64, 5, False, True),    # k5 persistent kernel, two N tiles per block
+    (1, 16, 24, 30, 34, 70, 5, True, False),   # k5 persistent kernel, ragged boxes, half-empty second N tile
 ]
 
 
