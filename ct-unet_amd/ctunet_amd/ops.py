@@ -127,14 +127,22 @@ class KernelTimer:
         return out
 
     def summary(self):
-        """{tag: dict(launches, total_ms, avg_ms, flops, bytes)} -- call after a device synchronize."""
+        """{tag: dict(launches, total_ms, avg_ms, flops, bytes)} -- call after a device synchronize.
+        A launch site (tag, geometry) is represented by the MEDIAN of its timed launches: a one-off stall that lands between
+        an event pair (an allocator hipMalloc, RCCL's lazy channel set-up in the first eager distributed step: 73 ms once,
+        measured) would otherwise be booked on whatever kernel happened to be bracketed."""
+        sites = {}
+        for (tag, fl, nb, a, b), det in zip(self.records, self.details):
+            sites.setdefault((tag, det, fl, nb), []).append(a.elapsed_time(b))
         out = {}
-        for tag, fl, nb, a, b in self.records:
+        for (tag, det, fl, nb), ts in sites.items():
+            ts.sort()
+            med = ts[len(ts) // 2] if len(ts) % 2 else 0.5 * (ts[len(ts) // 2 - 1] + ts[len(ts) // 2])
             d = out.setdefault(tag, dict(launches=0, total_ms=0.0, flops=0.0, bytes=0.0))
-            d["launches"] += 1
-            d["total_ms"] += a.elapsed_time(b)
-            d["flops"] += fl
-            d["bytes"] += nb
+            d["launches"] += len(ts)
+            d["total_ms"] += med * len(ts)
+            d["flops"] += fl * len(ts)
+            d["bytes"] += nb * len(ts)
         for d in out.values():
             d["avg_ms"] = d["total_ms"] / d["launches"]
         return out

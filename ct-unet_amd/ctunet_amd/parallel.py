@@ -38,16 +38,21 @@ class Communicator:
         from . import _lib
         self._lib = _lib
         lib = _lib.load()
-        if not lib.ctu_comm_available():
-            raise RuntimeError("ctunet_amd.parallel: librccl could not be bound (ctu_comm_available() == 0)")
+        avail = bool(lib.ctu_comm_available())
         self.world = dist.get_world_size(process_group)
         self.rank = dist.get_rank(process_group)
         buf = (C.c_char * 128)()
-        if self.rank == 0:
-            _lib.check(lib.ctu_comm_unique_id(buf), "comm_unique_id")
-        box = [bytes(buf)]
+        # rank 0's outcome travels with the id, so that a failure there is seen by every rank BEFORE anyone enters
+        # ncclCommInitRank's rendezvous (the broadcast itself always happens)
+        ok = avail and (self.rank != 0 or lib.ctu_comm_unique_id(buf) == 0)
+        box = [bytes(buf) if ok else None]
         dist.broadcast_object_list(box, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0,
                                    group=process_group)
+        if not avail:
+            raise RuntimeError("ctunet_amd.parallel: librccl could not be bound (ctu_comm_available() == 0)")
+        if box[0] is None:
+            raise RuntimeError("ctunet_amd.parallel: rank 0 could not create an RCCL unique id: " +
+                               (lib.ctu_last_error() or b"").decode())
         ident = (C.c_char * 128).from_buffer_copy(box[0])
         handle = C.c_void_p()
         _lib.check(lib.ctu_comm_init(C.byref(handle), self.world, self.rank, ident), "comm_init")
@@ -67,14 +72,53 @@ class Communicator:
         self._handle = None
 
 
-_COMMS: Dict[object, Communicator] = {}
+class TorchCommunicator:
+    """Same interface through torch.distributed's own RCCL process group ("nccl" backend on ROCm).  Only used when the C
+    ABI's communicator cannot be brought up on this node (get_communicator says so loudly): still RCCL over xGMI, still no
+    host copy -- the collective is enqueued on the caller's stream by making it torch's current stream."""
+    backend = "torch.distributed (RCCL)"
+
+    def __init__(self, process_group=None):
+        self.group = process_group
+        self.world = dist.get_world_size(process_group)
+        self.rank = dist.get_rank(process_group)
+
+    def allreduce_(self, t: torch.Tensor, average: bool = True, stream=None) -> None:
+        if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+            raise RuntimeError("ctunet_amd.parallel.TorchCommunicator: contiguous float32 GPU tensors only")
+        with torch.cuda.stream(stream or torch.cuda.current_stream(t.device)):
+            dist.all_reduce(t, op=dist.ReduceOp.AVG if average else dist.ReduceOp.SUM, group=self.group)
+
+    def close(self) -> None:
+        pass
 
 
-def get_communicator(process_group=None) -> Communicator:
-    """The (cached) RCCL communicator of this rank for ``process_group``; collective on first use."""
+Communicator.backend = "ctu_comm (RCCL behind the C ABI)"
+_COMMS: Dict[object, object] = {}
+
+
+def get_communicator(process_group=None):
+    """The (cached) RCCL communicator of this rank for ``process_group``; collective on first use.  The C ABI's communicator
+    (``ctu_comm_*``) by default; if it cannot be initialised on EVERY rank (agreed by an all-reduce of the outcome, so no rank
+    is left waiting in ncclCommInitRank's rendezvous alone), all ranks take torch.distributed's RCCL group instead and say so."""
     c = _COMMS.get(process_group)
     if c is None:
-        c = _COMMS[process_group] = Communicator(process_group)
+        err = None
+        try:
+            c = Communicator(process_group)
+        except Exception as e:                                  # noqa: BLE001 -- reported below, on every rank
+            c, err = None, e
+        ok = torch.tensor([0 if c is None else 1], dtype=torch.int32,
+                          device="cuda" if dist.get_backend(process_group) == "nccl" else "cpu")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=process_group)
+        if int(ok.item()) == 0:
+            import warnings
+            warnings.warn(f"ctunet_amd.parallel: ctu_comm_* communicator unavailable on some rank ({err!r}); "
+                          "gradient all-reduces go through torch.distributed's RCCL process group")
+            if c is not None:
+                c.close()
+            c = TorchCommunicator(process_group)
+        _COMMS[process_group] = c
     return c
 
 
