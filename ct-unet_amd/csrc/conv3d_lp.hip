@@ -149,22 +149,29 @@ struct LpConvP {
 // Box TD = 4 x TH x BW voxels, one plane (td) per wave, CT = TH * BW / 16 column tiles of 16 voxels per wave.  The box grows
 // when a voxel is small (few input channels): 4x8x32 for one 8-channel chunk, 4x8x16 for two, 4x4x16 otherwise -- a block
 // then moves 16-32 KB instead of 4 KB and the per-block latency chain (global -> LDS -> barrier -> MFMA) amortises.
-template <class T, int KS, int NT, int TH, int BW>
+template <class T, int KS, int NT, int TH, int BW, bool WG>
 __global__ __launch_bounds__(256) void lp_conv_fwd_kernel(LpConvP p) {
     typedef typename Vec<T>::v8 v8;
     constexpr int TAPS = KS * KS * KS, PK = (KS - 1) / 2;
     constexpr int TD = 4, CT = TH * BW / 16;
     constexpr int HD = TD + 2 * PK, HH = TH + 2 * PK, HW = BW + 2 * PK, HV = HD * HH * HW;
-    constexpr int PF = 4;                                           // weight-fragment ring depth (K-steps ahead)
     constexpr int UB = 12;                                          // staging loads in flight per thread
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int* sK = reinterpret_cast<int*>(smem);                         // [TAPS * 4 padded to 512] byte offsets of the (tap, chunk) pairs
     float* sXf = reinterpret_cast<float*>(smem + 2048);             // [2][32] scale / shift of the stage
     float* sRed = reinterpret_cast<float*>(smem + 2048 + 256);      // [4 waves][NT][2][16]
     unsigned char* sIn = smem + 2048 + 256 + 4 * NT * 32 * 4;       // haloed input box of the stage
-    // k = 3: the stage's weight fragments sit in LDS behind the box (<= 27 NT KB); a K-step then waits for LDS, not for L2.
-    // k = 5 (125 K-steps per full stage) keeps reading them from global through the register ring.
-    constexpr bool WLDS = KS == 3;
+    // The weight fragments of GK K-steps at a time sit in LDS behind the box (GK * NT KB); a K-step then waits for LDS, not for
+    // L2.  k = 3: GK = the whole stage (<= 27 K-steps).  k = 5 (up to 125 K-steps per stage): groups of 25; the next group is
+    // fetched into registers under the current group's MFMAs and written behind a barrier.  (Reading them from global through
+    // a register ring inside the K loop waited vmcnt(0) every K-step: 32 -> 8 at 192^3 took 5.5 ms against 0.5 ms for 8 -> 32.)
+    // WG = false (k = 5 with one 8-channel chunk, or two out tiles per block: 8-16 MFMAs per K-step and up to 4 blocks per CU
+    // hide the L2 latency): the fragments come straight from global through a register ring PF K-steps deep, no LDS copy.
+    // Measured at 192^3 / 96^3 (bf16, k = 5): 32->8 5537 -> 3136 us, 64->16 1580 -> 793 with groups; 8->32 519 vs 1249,
+    // 8->8 435 vs 519 without.
+    constexpr int GK = KS == 3 ? 27 : 25;
+    constexpr int NWR = (WG && KS != 3) ? (GK * NT * 64 + 255) / 256 : 1;      // 16-byte pieces of one weight group per thread (k = 5)
+    constexpr int PF = 4;                                           // weight-fragment ring depth (K-steps ahead), WG = false
     unsigned char* sW = sIn + (size_t)HV * p.S;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 15, kg = lane >> 4;
     const int S = p.S;
@@ -209,28 +216,41 @@ __global__ __launch_bounds__(256) void lp_conv_fwd_kernel(LpConvP p) {
             const int c = st * LP_SC + (tid & 31);
             sXf[tid] = (c < p.rin_p) ? ((tid < 32) ? p.scale[c] : p.shift[c]) : 0.f;
         }
-        // first weight fragments of the stage (independent of LDS)
+        // weight fragments of K-step group g of this stage -> registers (independent of LDS; L2-resident, clamped index)
         const int kbase = st * TAPS;
+        const int ngroups = KS == 3 ? 1 : (ks + GK - 1) / GK;      // (k = 3: one group, known at compile time)
+        uint4 wreg[NWR];
+        auto load_wgroup = [&](int g) {
+            const int s0 = g * GK, pieces = min(GK, ks - s0) * NT * 64;
+#pragma unroll
+            for (int u = 0; u < NWR; ++u) {
+                const int i = min(tid + u * 256, pieces - 1);
+                const int ln = i & 63, fr = i >> 6, nt = fr % NT, s_ = fr / NT;
+                const int tile = min(nt0 + nt, n16 - 1);
+                wreg[u] = *reinterpret_cast<const uint4*>(wp + ((size_t)((kbase + s0 + s_) * n16 + tile) * 64 + ln) * 8);
+            }
+        };
+        auto store_wgroup = [&](int g) {
+            const int pieces = min(GK, ks - g * GK) * NT * 64;
+#pragma unroll
+            for (int u = 0; u < NWR; ++u) {
+                const int i = tid + u * 256;
+                if (i < pieces) *reinterpret_cast<uint4*>(sW + (size_t)i * 16) = wreg[u];
+            }
+        };
         v8 ring[PF][NT];
-        if constexpr (!WLDS) {
-#pragma unroll
-            for (int u = 0; u < PF; ++u)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const int tile = min(nt0 + nt, n16 - 1), s = min(u, ks - 1);
-                    ring[u][nt] = *reinterpret_cast<const v8*>(wp + ((size_t)((kbase + s) * n16 + tile) * 64 + lane) * 8);
-                }
-        } else {
-            // ks * NT fragments of 1 KB: 16-byte pieces, batched branch-free loads (clamped index), L2-resident
+        if constexpr (WG && KS == 3) {
+            // the whole stage (ks * NT fragments of 1 KB) in batches of 8 pieces per thread: all of them in flight at once
+            // would cost 56 registers for two out tiles and an occupancy step of the small-volume launches
             const int pieces = ks * NT * 64;
             for (int i0 = tid; i0 < pieces; i0 += 256 * 8) {
                 uint4 w8[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int i = min(i0 + u * 256, pieces - 1);
-                    const int ln = i & 63, fr = i >> 6, nt = fr % NT, s = fr / NT;
+                    const int ln = i & 63, fr = i >> 6, nt = fr % NT, s_ = fr / NT;
                     const int tile = min(nt0 + nt, n16 - 1);
-                    w8[u] = *reinterpret_cast<const uint4*>(wp + ((size_t)((kbase + s) * n16 + tile) * 64 + ln) * 8);
+                    w8[u] = *reinterpret_cast<const uint4*>(wp + ((size_t)((kbase + s_) * n16 + tile) * 64 + ln) * 8);
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
@@ -238,6 +258,17 @@ __global__ __launch_bounds__(256) void lp_conv_fwd_kernel(LpConvP p) {
                     if (i < pieces) *reinterpret_cast<uint4*>(sW + (size_t)i * 16) = w8[u];
                 }
             }
+        } else if constexpr (WG) {
+            load_wgroup(0);
+            store_wgroup(0);                                        // (sW is free: the previous stage ended behind the barrier above)
+        } else {
+#pragma unroll
+            for (int u = 0; u < PF; ++u)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int tile = min(nt0 + nt, n16 - 1), s_ = min(u, ks - 1);
+                    ring[u][nt] = *reinterpret_cast<const v8*>(wp + ((size_t)((kbase + s_) * n16 + tile) * 64 + lane) * 8);
+                }
         }
         if (xf) __syncthreads();                                    // sXf visible
         // ---- stage the haloed box: 16-byte items (halo voxel, chunk), up to UB loads in flight per thread
@@ -282,29 +313,32 @@ __global__ __launch_bounds__(256) void lp_conv_fwd_kernel(LpConvP p) {
             }
         }
         __syncthreads();
-        // ---- K loop
-        if constexpr (WLDS) {
-            // A compiler-scheduled "read, wait, MFMA" chain pays one LDS latency (~100 cycles) per 16-cycle MFMA.  Instead: the
-            // fragments of half a K-step (CT / 2 column tiles) are read as one batch while the other half's MFMAs run.
-            constexpr int HB = CT / 2;
-            auto read_b = [&](int koff, int half, v8 (&bb)[HB]) {
+        // ---- K loop, one weight group at a time
+        // A compiler-scheduled "read, wait, MFMA" chain pays one LDS latency (~100 cycles) per 16-cycle MFMA.  Instead: the
+        // fragments of half a K-step (CT / 2 column tiles) are read as one batch while the other half's MFMAs run.
+        constexpr int HB = CT / 2;
+        auto read_b = [&](int koff, int half, v8 (&bb)[HB]) {
 #pragma unroll
-                for (int j = 0; j < HB; ++j) {
-                    const int ct = half * HB + j;
-                    const int cto = (BW == 32) ? ((ct >> 1) * HW + (ct & 1) * 16) * S : ct * CT_ROWSTEP * HW * S;
-                    bb[j] = *reinterpret_cast<const v8*>(sIn + koff + cto);
-                }
-            };
+            for (int j = 0; j < HB; ++j) {
+                const int ct = half * HB + j;
+                const int cto = (BW == 32) ? ((ct >> 1) * HW + (ct & 1) * 16) * S : ct * CT_ROWSTEP * HW * S;
+                bb[j] = *reinterpret_cast<const v8*>(sIn + koff + cto);
+            }
+        };
+        if constexpr (WG)
+        for (int g = 0; g < ngroups; ++g) {
+            if constexpr (KS != 3) { if (g + 1 < ngroups) load_wgroup(g + 1); }     // lands under this group's MFMAs
+            const int s0 = g * GK, s1e = min(ks, s0 + GK);           // K-steps [s0, s1e) of the stage; their weights: sW[s - s0]
             v8 b0[HB], b1[HB], a[NT];
-            int koff = sK[kg] + hb0;
-            int koff_n = sK[4 * min(1, ks - 1) + kg] + hb0;         // the offset table is read TWO K-steps ahead: its (in-order)
+            int koff = sK[4 * s0 + kg] + hb0;
+            int koff_n = sK[4 * min(s0 + 1, ks - 1) + kg] + hb0;    // the offset table is read TWO K-steps ahead: its (in-order)
 #pragma unroll                                                      // LDS read is then the oldest in flight when it is needed
             for (int nt = 0; nt < NT; ++nt) a[nt] = *reinterpret_cast<const v8*>(sW + ((size_t)nt * 64 + lane) * 16);
             read_b(koff, 0, b0);
-            for (int s = 0; s < ks; ++s) {
+            for (int s = s0; s < s1e; ++s) {
                 const int koff_nn = sK[4 * min(s + 2, ks - 1) + kg] + hb0;
                 read_b(koff, 1, b1);                                // second half of K-step s: lands under the first half's MFMAs
-                const int sn = min(s + 1, ks - 1);
+                const int sn = min(s + 1, s1e - 1) - s0;
                 v8 an[NT];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) an[nt] = *reinterpret_cast<const v8*>(sW + ((size_t)(sn * NT + nt) * 64 + lane) * 16);
@@ -326,7 +360,15 @@ __global__ __launch_bounds__(256) void lp_conv_fwd_kernel(LpConvP p) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) a[nt] = an[nt];
             }
-        } else
+            if constexpr (KS != 3) {
+                if (g + 1 < ngroups) {
+                    __syncthreads();                                // every wave is done with this group's weights
+                    store_wgroup(g + 1);
+                    __syncthreads();
+                }
+            }
+        }
+        else
         for (int s0 = 0; s0 < ks; s0 += PF) {
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
@@ -732,12 +774,14 @@ void lp_persist_grid(int ntiles, int* gx, int* tpb) {
 
 int lp_voxel_stride(int rin_p) { return rin_p >= 16 ? (rin_p >= LP_SC ? LP_SC : rin_p) * 2 + 16 : 16; }
 
-template <class T, int KS, int NT, int TH, int BW>
-int lp_conv_launch_box(LpConvP& p, int ntiles, hipStream_t st) {
+template <class T, int KS, int NT, int TH, int BW, bool WG>
+int lp_conv_launch_box_wg(LpConvP& p, int ntiles, hipStream_t st) {
     constexpr int PK = (KS - 1) / 2;
     const int hv = (4 + 2 * PK) * (TH + 2 * PK) * (BW + 2 * PK);
     const int nch_max = (p.rin_p >= LP_SC ? LP_SC : p.rin_p) >> 3;
-    const size_t wlds = KS == 3 ? (size_t)lp_ksteps(27, nch_max) * NT * 1024 : 0;
+    const int ks_max = lp_ksteps(KS * KS * KS, nch_max);
+    // one weight group (GK K-steps) behind the box; none when the fragments come through the register ring
+    const size_t wlds = WG ? (size_t)(KS == 3 ? ks_max : (ks_max < 25 ? ks_max : 25)) * NT * 1024 : 0;
     const size_t lds = 2048 + 256 + 4 * NT * 32 * 4 + (size_t)hv * p.S + wlds;
     CTU_REQUIRE(lds <= 160 * 1024, "lp_conv3d_fwd: LDS box of %zu bytes", lds);
     const int n16 = (p.nout_p + 15) >> 4;
@@ -745,13 +789,25 @@ int lp_conv_launch_box(LpConvP& p, int ntiles, hipStream_t st) {
     // the dynamic-LDS limit is raised only for launches that need more than the default 64 KB, and only to what they need
     static size_t raised = 64 * 1024;
     if (lds > raised) {
-        CTU_REQUIRE(hipFuncSetAttribute((const void*)lp_conv_fwd_kernel<T, KS, NT, TH, BW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess,
+        CTU_REQUIRE(hipFuncSetAttribute((const void*)lp_conv_fwd_kernel<T, KS, NT, TH, BW, WG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess,
                     "lp_conv3d_fwd: cannot raise the dynamic LDS limit");
         raised = lds;
     }
-    lp_conv_fwd_kernel<T, KS, NT, TH, BW><<<grid, 256, lds, st>>>(p);
+    lp_conv_fwd_kernel<T, KS, NT, TH, BW, WG><<<grid, 256, lds, st>>>(p);
     CTU_CHECK_LAUNCH("lp_conv3d_fwd");
     return CTU_OK;
+}
+
+// k = 3: the stage's weights always sit in LDS.  k = 5: weight groups through LDS when a K-step carries few MFMAs and the box
+// already limits the block to one or two per CU (one out tile per block, >= 2 chunks per voxel); the register ring otherwise.
+template <class T, int KS, int NT, int TH, int BW>
+int lp_conv_launch_box(LpConvP& p, int ntiles, hipStream_t st) {
+    if constexpr (KS == 3) return lp_conv_launch_box_wg<T, KS, NT, TH, BW, true>(p, ntiles, st);
+    else {
+        const int nch_max = (p.rin_p >= LP_SC ? LP_SC : p.rin_p) >> 3;
+        if (NT == 1 && nch_max >= 2) return lp_conv_launch_box_wg<T, KS, NT, TH, BW, true>(p, ntiles, st);
+        return lp_conv_launch_box_wg<T, KS, NT, TH, BW, false>(p, ntiles, st);
+    }
 }
 
 template <class T, int NT, int TH, int BW>
