@@ -858,13 +858,43 @@ struct LpWgP {
 
 constexpr int WG_SX = 32;      // LDS bytes per voxel of the 16-channel images
 
+// (w-shift, channel) tiles for 8-channel sides (SM / SN = 2), as conv3d_wgrad_k3s_kernel / _k5s_kernel of the fp32 path: the
+// second 8-channel half of the 16-channel LDS image holds the NEIGHBOUR voxel's channels -- X image half 1 = x(v + e_w),
+// G image half 1 = g(u - e_w) -- so the unchanged 16 x 16 MFMA tile carries rows (s, ci), columns (s', co) and entry
+// [(s, ci), (s', co)] of the accumulator of w offset t0 is dW[kw = t0 + s + s'].  Per (kd, kh) row QN offsets t0 instead of KS
+// taps.  An entry with s' = 1 misses the term of the volume's last w column, which multiplies x at w = W - 1 + kw - pad: zero
+// padding only for kw >= pad + 1, so smaller kw always come from s' = 0 entries.
+__host__ __device__ constexpr int lp_wg_qn(int KS, int SM, int SN) {
+    return KS == 3 ? ((SM == 2 && SN == 2) ? 1 : ((SM == 1 && SN == 1) ? 3 : 2))
+                   : ((SM == 2 && SN == 2) ? 2 : ((SM == 1 && SN == 1) ? 5 : (SN == 2 ? 4 : 3)));
+}
+__host__ __device__ constexpr int lp_wg_t0(int KS, int SM, int SN, int q) {
+    return (SM == 1 && SN == 1) ? q : (KS == 3 ? q : (SM == 2 && SN == 2 ? 2 * q : (SN == 2 ? q : (q == 2 ? 3 : 2 * q))));
+}
+// which (q, s, s') entry supplies tap kw (exactly one per kw): returns kw or -1
+__host__ __device__ constexpr int lp_wg_entry_kw(int KS, int SM, int SN, int q, int sm, int sn) {
+    const int pad = (KS - 1) / 2, kw = lp_wg_t0(KS, SM, SN, q) + sm + sn;
+    if (kw >= KS) return -1;
+    if (sn == 1 && kw < pad + 1) return -1;
+    if (SM == 1 && SN == 1) return kw;
+    if (KS == 3) {
+        if (SM == 2 && SN == 2) return (sm == 0 && sn == 1) ? -1 : kw;              // t0 = 0: kw 0, 1 (s = 1), 2
+        if (SN == 2) return kw;                                                     // t0 = 0: kw 0; t0 = 1: kw 1, 2
+        return (q == 1 && sm == 0) ? -1 : kw;                                       // t0 = 0: kw 0, 1; t0 = 1: kw 2
+    }
+    if (SM == 2 && SN == 2) return (sm == 0 && sn == 1) ? -1 : kw;                  // t0 = 0: kw 0, 1; t0 = 2: kw 2, 3 (s = 1), 4
+    if (SN == 2) return (sn == 0 && q == 3) ? -1 : kw;                              // t0 = q: kw 0, 1, 2 from s' = 0; 3, 4 from s' = 1
+    return (q == 2 && sm == 0) ? -1 : kw;                                           // t0 = 0, 2, 3: kw (0, 1), (2, 3), 4
+}
+
 // Block (x, y = (ci tile, co tile), z = kd plane for k = 5): accumulates dW[tap][16 ci][16 co] over a contiguous range of
 // boxes (4 x TH x BW voxels, 16 K-steps of 32 voxels, 4 per wave) and writes ONE slab.
-template <class T, int KS, int BW>
+template <class T, int KS, int BW, int SM, int SN>
 __global__ __launch_bounds__(256) void lp_conv_wgrad_kernel(LpWgP p, int tiles_per_block) {
     typedef typename Vec<T>::v8 v8;
     constexpr int PK = (KS - 1) / 2;
-    constexpr int NTAP = (KS == 3) ? 27 : KS * KS;                  // taps per block (k = 5: one kd plane)
+    constexpr int QN = lp_wg_qn(KS, SM, SN), ROWS = (KS == 3) ? 9 : KS;
+    constexpr int NTAP = ROWS * QN;                                 // accumulators per block (k = 5: one kd plane)
     constexpr int RPK = 32 / BW, TD = 4, TH = 4 * RPK;
     constexpr int HD = (KS == 3) ? TD + 2 : TD, HH = TH + 2 * PK, HW = BW + 2 * PK, HV = HD * HH * HW, NV = TD * TH * BW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -895,7 +925,8 @@ __global__ __launch_bounds__(256) void lp_conv_wgrad_kernel(LpWgP p, int tiles_p
     f32x4 acc[NTAP];
 #pragma unroll
     for (int t = 0; t < NTAP; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int nchx = min(2, (p.cin_p - cit * 16) >> 3), nchg = min(2, (p.cout_p - cot * 16) >> 3);
+    // live 8-channel halves of the two images (a shifted half is always live)
+    const int nchx = SM == 2 ? 2 : min(2, (p.cin_p - cit * 16) >> 3), nchg = SN == 2 ? 2 : min(2, (p.cout_p - cot * 16) >> 3);
     int tile = blockIdx.x * tiles_per_block;
     const int tile_end = min(p.ntiles, tile + tiles_per_block);
     // software pipeline: the NEXT box's global loads are in flight (in registers) while this box's taps run
@@ -905,14 +936,17 @@ __global__ __launch_bounds__(256) void lp_conv_wgrad_kernel(LpWgP p, int tiles_p
     // per-thread item offsets (bytes, relative to the box's halo origin / first voxel), computed ONCE per block: an interior
     // box then costs one 32-bit add per load instead of ~50 VALU instructions of index arithmetic (the 8-channel layers
     // are VALU-bound otherwise: 16 bytes per voxel leave no room for per-voxel address math)
-    unsigned xoff[NX], goff[NG], xlive = 0, glive = 0;
+    unsigned xoff[NX], xlive = 0, glive = 0;
+    int goff[NG];                                                   // (signed: the shifted half of the first column sits at w0 - 1)
 #pragma unroll
     for (int u = 0; u < NX; ++u) {
         const int it = tid + u * 256, v = it >> 1, c = it & 1;
-        const bool live = it < HV * 2 && c < nchx;
         const int vv = it < HV * 2 ? v : 0;
         const int pw = vv % HW, t2 = vv / HW, ph = t2 % HH, pd = t2 / HH;
-        xoff[u] = (unsigned)((((pd * p.H + ph) * p.W + pw) * p.x_cs + cit * 16 + (live ? c : 0) * 8) * (int)sizeof(T));
+        // SM = 2: half 1 = channels 0..7 of the voxel one step further in w (the last halo column's is never read)
+        const bool live = it < HV * 2 && c < nchx && (SM == 1 || c == 0 || pw + 1 < HW);
+        const int sw = (SM == 2 && c == 1 && live) ? 1 : 0, cc = (SM == 2 || !live) ? 0 : c;
+        xoff[u] = (unsigned)((((pd * p.H + ph) * p.W + pw + sw) * p.x_cs + cit * 16 + cc * 8) * (int)sizeof(T));
         xlive |= live ? (1u << u) : 0u;
     }
 #pragma unroll
@@ -920,7 +954,9 @@ __global__ __launch_bounds__(256) void lp_conv_wgrad_kernel(LpWgP p, int tiles_p
         const int it = tid + u * 256, v = it >> 1, c = it & 1;
         const bool live = c < nchg;
         const int tw = v % BW, t2 = v / BW, th = t2 % TH, td = t2 / TH;
-        goff[u] = (unsigned)((((td * p.H + th) * p.W + tw) * p.g_cs + cot * 16 + (live ? c : 0) * 8) * (int)sizeof(T));
+        // SN = 2: half 1 = channels 0..7 of the voxel one step BACK in w
+        const int sw = (SN == 2 && c == 1) ? -1 : 0, cc = (SN == 2 || !live) ? 0 : c;
+        goff[u] = (((td * p.H + th) * p.W + tw + sw) * p.g_cs + cot * 16 + cc * 8) * (int)sizeof(T);
         glive |= live ? (1u << u) : 0u;
     }
     auto load_box = [&](int tl) {
@@ -939,7 +975,7 @@ __global__ __launch_bounds__(256) void lp_conv_wgrad_kernel(LpWgP p, int tiles_p
             for (int u = 0; u < NX; ++u) rx[u] = *reinterpret_cast<const uint4*>(xb + xoff[u]);
 #pragma unroll
             for (int u = 0; u < NG; ++u) {
-                const uint4 r = *reinterpret_cast<const uint4*>(gb + goff[u]);
+                const uint4 r = *reinterpret_cast<const uint4*>(gb + (ptrdiff_t)goff[u]);
                 rg[u] = ((glive >> u) & 1u) ? r : make_uint4(0u, 0u, 0u, 0u);
             }
             okx = xlive;
@@ -950,24 +986,24 @@ __global__ __launch_bounds__(256) void lp_conv_wgrad_kernel(LpWgP p, int tiles_p
         for (int u = 0; u < NX; ++u) {
             const int it = tid + u * 256, v = it >> 1, c = it & 1;
             const int pw = v % HW, t2 = v / HW, ph = t2 % HH, pd = t2 / HH;
-            const int gd = d0 + pd + ((KS == 3) ? -1 : kd - PK), gh = h0 + ph - PK, gw = w0 + pw - PK;
-            const bool ok = it < HV * 2 && c < nchx && (unsigned)gd < (unsigned)p.D && (unsigned)gh < (unsigned)p.H &&
-                            (unsigned)gw < (unsigned)p.W;
+            const int gd = d0 + pd + ((KS == 3) ? -1 : kd - PK), gh = h0 + ph - PK, gw = w0 + pw - PK + ((SM == 2 && c == 1) ? 1 : 0);
+            const bool ok = it < HV * 2 && c < nchx && (SM == 1 || c == 0 || pw + 1 < HW) && (unsigned)gd < (unsigned)p.D &&
+                            (unsigned)gh < (unsigned)p.H && (unsigned)gw < (unsigned)p.W;
             // branch-free loads from clamped addresses (see lp_conv_fwd_kernel); zeroed at the LDS write
             const int cd = min(max(gd, 0), p.D - 1), chh = min(max(gh, 0), p.H - 1), cw = min(max(gw, 0), p.W - 1);
             rx[u] = *reinterpret_cast<const uint4*>(x + ((((size_t)n * p.D + cd) * p.H + chh) * p.W + cw) * p.x_cs + cit * 16 +
-                                                    (c < nchx ? c : 0) * 8);
+                                                    ((SM == 1 && c < nchx) ? c : 0) * 8);
             okx |= ok ? (1u << u) : 0u;
         }
 #pragma unroll
         for (int u = 0; u < NG; ++u) {
             const int it = tid + u * 256, v = it >> 1, c = it & 1;
             const int tw = v % BW, t2 = v / BW, th = t2 % TH, td = t2 / TH;
-            const int gd = d0 + td, gh = h0 + th, gw = w0 + tw;
-            const bool ok = c < nchg && gd < p.D && gh < p.H && gw < p.W;
-            const int cd = min(gd, p.D - 1), chh = min(gh, p.H - 1), cw = min(gw, p.W - 1);
+            const int gd = d0 + td, gh = h0 + th, gw = w0 + tw - ((SN == 2 && c == 1) ? 1 : 0);
+            const bool ok = c < nchg && gd < p.D && gh < p.H && gw >= 0 && gw < p.W;
+            const int cd = min(gd, p.D - 1), chh = min(gh, p.H - 1), cw = min(max(gw, 0), p.W - 1);
             const uint4 r = *reinterpret_cast<const uint4*>(gr + ((((size_t)n * p.D + cd) * p.H + chh) * p.W + cw) * p.g_cs + cot * 16 +
-                                                            (c < nchg ? c : 0) * 8);
+                                                            ((SN == 1 && c < nchg) ? c : 0) * 8);
             rg[u] = ok ? r : make_uint4(0u, 0u, 0u, 0u);
         }
     };
@@ -982,7 +1018,7 @@ __global__ __launch_bounds__(256) void lp_conv_wgrad_kernel(LpWgP p, int tiles_p
             uint4 r = rx[u];
             if (!((okx >> u) & 1u)) r = make_uint4(0u, 0u, 0u, 0u);
             else if (xf) {
-                const int c8 = (it & 1) * 8;
+                const int c8 = SM == 2 ? 0 : (it & 1) * 8;         // (a shifted half holds channels 0..7 again)
                 const f32x8 f = __builtin_convertvector(*reinterpret_cast<v8*>(&r), f32x8);
                 f32x8 o;
 #pragma unroll
@@ -1015,13 +1051,14 @@ __global__ __launch_bounds__(256) void lp_conv_wgrad_kernel(LpWgP p, int tiles_p
             }
             // taps in groups (k = 3: the 9 taps of one kd plane, k = 5: the 5 of one kh row): the NEXT group's transposed
             // fragment reads are issued before this group's MFMAs, so a tap no longer pays its own LDS latency
-            constexpr int GT = (KS == 3) ? 9 : KS, NGRP = NTAP / GT;
+            constexpr int GT = (KS == 3) ? (QN == 3 ? 9 : 3 * QN) : KS, NGRP = NTAP / GT;
+            static_assert(NTAP % GT == 0, "tap groups");
             typedef short s16x8 __attribute__((ext_vector_type(8)));
             auto read_grp = [&](int grp, s16x8 (&fr)[GT]) {
 #pragma unroll
                 for (int j = 0; j < GT; ++j) {
-                    const int t = grp * GT + j;
-                    const int kdd = (KS == 3) ? t / 9 : 0, kh = (KS == 3) ? (t / 3) % 3 : t / KS, kw = (KS == 3) ? t % 3 : t % KS;
+                    const int t = grp * GT + j, row = t / QN, kw = lp_wg_t0(KS, SM, SN, t % QN);     // (kw = the w offset t0)
+                    const int kdd = (KS == 3) ? row / 3 : 0, kh = (KS == 3) ? row % 3 : row;
                     const int to = ((kdd * HH + kh) * HW + kw) * WG_SX;
                     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sX + xa[0] + xo + to));
                     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sX + xa[1] + xo + to));
@@ -1063,10 +1100,11 @@ __global__ __launch_bounds__(256) void lp_conv_wgrad_kernel(LpWgP p, int tiles_p
 }
 
 // dw[co][ci][tap] (torch layout) = sum over the gx slabs of (pair, plane); 16 slab groups x 64 elements per block
-template <int KS>
+template <int KS, int SM, int SN>
 __global__ __launch_bounds__(1024) void lp_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Co, int Ci,
                                                               const int32_t* __restrict__ cinv, int cin_p, int cout_p, int gx) {
-    constexpr int TAPS = KS * KS * KS, NTAP = (KS == 3) ? 27 : KS * KS, NPL = TAPS / NTAP;
+    constexpr int TAPS = KS * KS * KS, QN = lp_wg_qn(KS, SM, SN), ROWS = (KS == 3) ? 9 : KS, NTAP = ROWS * QN;
+    constexpr int NPL = (KS == 3) ? 1 : KS;
     __shared__ float red[16][64];
     const int e = threadIdx.x & 63, part = threadIdx.x >> 6;
     const int nco = (cout_p + 15) >> 4, nci = (cin_p + 15) >> 4;
@@ -1097,9 +1135,12 @@ __global__ __launch_bounds__(1024) void lp_wgrad_reduce_kernel(const float* __re
     const int grp = el / per_pair, within = el % per_pair;
     const int plane = grp / (nci * nco), pair = grp % (nci * nco);
     const int t = within >> 8, row = (within >> 4) & 15, col = within & 15;
-    const int cpos = (pair / nco) * 16 + row, co = (pair % nco) * 16 + col;
+    // (shift, channel) tiles: row = (s, ci), col = (s', co); entry (q, s, s') of tap row r is tap kw = t0(q) + s + s' (or unused)
+    const int sm = SM == 2 ? row >> 3 : 0, cil = SM == 2 ? row & 7 : row, sn = SN == 2 ? col >> 3 : 0, col_ = SN == 2 ? col & 7 : col;
+    const int kw = lp_wg_entry_kw(KS, SM, SN, t % QN, sm, sn), r = t / QN;
+    const int cpos = (pair / nco) * 16 + cil, co = (pair % nco) * 16 + col_;
     const int ci = (cpos < cin_p) ? (cinv ? cinv[cpos] : (cpos < Ci ? cpos : -1)) : -1;
-    if (ci >= 0 && co < Co) dw[((size_t)co * Ci + ci) * TAPS + plane * NTAP + t] = tot;
+    if (kw >= 0 && ci >= 0 && co < Co) dw[((size_t)co * Ci + ci) * TAPS + (plane * ROWS + r) * KS + kw] = tot;
 }
 
 int lp_wg_box_w(int W) { return W >= 32 ? 32 : (W >= 16 ? 16 : 8); }
@@ -1121,31 +1162,46 @@ void lp_wg_grid(int ntiles, int groups, int* gx, int* tpb) {
     *gx = ceil_div(ntiles, *tpb);
 }
 
-template <class T, int KS, int BW>
+template <class T, int KS, int BW, int SM, int SN>
 int lp_wgrad_launch(LpWgP& p, int gx, int tpb, int pairs, hipStream_t st) {
     constexpr int PK = (KS - 1) / 2, RPK = 32 / BW, TH = 4 * RPK;
     constexpr int HD = (KS == 3) ? 6 : 4, HV = HD * (TH + 2 * PK) * (BW + 2 * PK), NV = 4 * TH * BW;
-    constexpr int NTAP = (KS == 3) ? 27 : KS * KS;
+    constexpr int NTAP = ((KS == 3) ? 9 : KS) * lp_wg_qn(KS, SM, SN);
     size_t lds = 128 + (size_t)(HV + NV) * WG_SX;
     if (lds < 128 + (size_t)NTAP * 1024) lds = 128 + (size_t)NTAP * 1024;
     // the dynamic-LDS limit is raised only for launches that need more than the default 64 KB, and only to what they need
     static size_t raised = 64 * 1024;
     if (lds > raised) {
-        CTU_REQUIRE(hipFuncSetAttribute((const void*)lp_conv_wgrad_kernel<T, KS, BW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess,
+        CTU_REQUIRE(hipFuncSetAttribute((const void*)lp_conv_wgrad_kernel<T, KS, BW, SM, SN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess,
                     "lp_conv3d_wgrad: cannot raise the dynamic LDS limit");
         raised = lds;
     }
-    lp_conv_wgrad_kernel<T, KS, BW><<<dim3(gx, pairs, KS == 3 ? 1 : KS), 256, lds, st>>>(p, tpb);
+    lp_conv_wgrad_kernel<T, KS, BW, SM, SN><<<dim3(gx, pairs, KS == 3 ? 1 : KS), 256, lds, st>>>(p, tpb);
     CTU_CHECK_LAUNCH("lp_conv3d_wgrad");
     return CTU_OK;
+}
+
+// 8-channel sides of volumes at least 16 wide take the (w-shift, channel) tiles
+inline int lp_wg_sm(int W, int cin_p) { return (W >= 16 && cin_p == 8) ? 2 : 1; }
+inline int lp_wg_sn(int W, int cout_p) { return (W >= 16 && cout_p == 8) ? 2 : 1; }
+
+template <class T, int KS, int BW>
+int lp_wgrad_launch_s(LpWgP& p, int gx, int tpb, int pairs, hipStream_t st) {
+    if constexpr (BW >= 16) {
+        const int sm = lp_wg_sm(p.W, p.cin_p), sn = lp_wg_sn(p.W, p.cout_p);
+        if (sm == 2 && sn == 2) return lp_wgrad_launch<T, KS, BW, 2, 2>(p, gx, tpb, pairs, st);
+        if (sm == 2) return lp_wgrad_launch<T, KS, BW, 2, 1>(p, gx, tpb, pairs, st);
+        if (sn == 2) return lp_wgrad_launch<T, KS, BW, 1, 2>(p, gx, tpb, pairs, st);
+    }
+    return lp_wgrad_launch<T, KS, BW, 1, 1>(p, gx, tpb, pairs, st);
 }
 
 template <class T, int KS>
 int lp_wgrad_dispatch(LpWgP& p, int gx, int tpb, int pairs, hipStream_t st) {
     const int bw = lp_wg_box_w(p.W);
-    if (bw == 32) return lp_wgrad_launch<T, KS, 32>(p, gx, tpb, pairs, st);
-    if (bw == 16) return lp_wgrad_launch<T, KS, 16>(p, gx, tpb, pairs, st);
-    return lp_wgrad_launch<T, KS, 8>(p, gx, tpb, pairs, st);
+    if (bw == 32) return lp_wgrad_launch_s<T, KS, 32>(p, gx, tpb, pairs, st);
+    if (bw == 16) return lp_wgrad_launch_s<T, KS, 16>(p, gx, tpb, pairs, st);
+    return lp_wgrad_launch_s<T, KS, 8>(p, gx, tpb, pairs, st);
 }
 
 }  // namespace
@@ -1220,7 +1276,8 @@ extern "C" size_t ctu_lp_conv3d_wgrad_ws_floats(int N, int D, int H, int W, int 
     const int pairs = ((cin_p + 15) >> 4) * ((cout_p + 15) >> 4), planes = k == 3 ? 1 : k;
     int gx, tpb;
     lp_wg_grid(ntiles, pairs * planes, &gx, &tpb);
-    return (size_t)gx * pairs * planes * (k == 3 ? 27 : k * k) * 256;
+    const int ntap = (k == 3 ? 9 : k) * lp_wg_qn(k, lp_wg_sm(W, cin_p), lp_wg_sn(W, cout_p));
+    return (size_t)gx * pairs * planes * ntap * 256;
 }
 
 extern "C" int ctu_lp_conv3d_wgrad(int dtype, const void* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
@@ -1246,9 +1303,18 @@ extern "C" int ctu_lp_conv3d_wgrad(int dtype, const void* in, int in_cs, int cin
         else rc = lp_wgrad_dispatch<T, 5>(p, gx, tpb, pairs, st);
     });
     if (rc != CTU_OK) return rc;
-    const int total = planes * pairs * (k == 3 ? 27 : k * k) * 256;
-    if (k == 3) lp_wgrad_reduce_kernel<3><<<ceil_div(total, 64), 1024, 0, st>>>(ws, dw, Co, Ci, cinv, cin_p, cout_p, gx);
-    else lp_wgrad_reduce_kernel<5><<<ceil_div(total, 64), 1024, 0, st>>>(ws, dw, Co, Ci, cinv, cin_p, cout_p, gx);
+    const int sm = lp_wg_box_w(W) >= 16 ? lp_wg_sm(W, cin_p) : 1, sn = lp_wg_box_w(W) >= 16 ? lp_wg_sn(W, cout_p) : 1;
+    const int total = planes * pairs * (k == 3 ? 9 : k) * lp_wg_qn(k, sm, sn) * 256;
+    const dim3 rg(ceil_div(total, 64));
+#define CTU_LP_WG_REDUCE(K_, SM_, SN_) lp_wgrad_reduce_kernel<K_, SM_, SN_><<<rg, 1024, 0, st>>>(ws, dw, Co, Ci, cinv, cin_p, cout_p, gx)
+    if (k == 3) {
+        if (sm == 2 && sn == 2) CTU_LP_WG_REDUCE(3, 2, 2); else if (sm == 2) CTU_LP_WG_REDUCE(3, 2, 1);
+        else if (sn == 2) CTU_LP_WG_REDUCE(3, 1, 2); else CTU_LP_WG_REDUCE(3, 1, 1);
+    } else {
+        if (sm == 2 && sn == 2) CTU_LP_WG_REDUCE(5, 2, 2); else if (sm == 2) CTU_LP_WG_REDUCE(5, 2, 1);
+        else if (sn == 2) CTU_LP_WG_REDUCE(5, 1, 2); else CTU_LP_WG_REDUCE(5, 1, 1);
+    }
+#undef CTU_LP_WG_REDUCE
     CTU_CHECK_LAUNCH("lp_conv3d_wgrad reduce");
     return CTU_OK;
 }

@@ -28,11 +28,14 @@ timeout -k 10 300 $B --model UNet4_2IC --no-cpu-baseline --steps 10 --warmup 3 >
 timeout -k 10 300 $B --model UNetSP --size 192 --dtype bf16 --no-cpu-baseline --steps 10 --warmup 3 > $O/r02_bench_UNetSP_192_bf16.json 2> $O/bench_sp192.err
 timeout -k 10 300 $B --model recAE_v2_fixed --size 192 --dtype bf16 --no-cpu-baseline --steps 5 --warmup 2 > $O/r02_bench_recAE_192_bf16.json 2> $O/bench_recae192.err
 timeout -k 10 300 $B --model UNetSP --size 256 --dtype f16 --no-cpu-baseline --steps 5 --warmup 2 > $O/r02_bench_UNetSP_256_f16.json 2> $O/bench_sp256.err
+timeout -k 10 300 $B --model UNetSP --size 192 --no-cpu-baseline --steps 5 --warmup 2 > $O/r02_bench_UNetSP_192_f32.json 2> $O/bench_sp192f.err
+timeout -k 10 300 $B --model UNetSP --size 256 --no-cpu-baseline --steps 5 --warmup 2 > $O/r02_bench_UNetSP_256_f32.json 2> $O/bench_sp256f.err
 echo "[8] per-stage tables"
 timeout -k 10 200 python scripts/stage_table.py --traffic $O/r02_hbm_traffic.json --out $O/r02_stage_table_f32.md > /dev/null
 timeout -k 10 200 python scripts/stage_table.py --dtype bf16 --out $O/r02_stage_table_bf16.md > /dev/null
 timeout -k 10 200 python scripts/stage_table.py --mode infer --batch 2 --out $O/r02_stage_table_infer_b2.md > /dev/null
 timeout -k 10 200 python scripts/stage_table.py --model recAE_v2_fixed --out $O/r02_stage_table_recAE_f32.md > /dev/null
+timeout -k 10 200 python scripts/stage_table.py --model recAE_v2_fixed --size 192 --dtype bf16 --steps 2 --out $O/r02_stage_table_recAE_192_bf16.md > /dev/null
 echo "[9] SQ counters: fp32 roofline kernel, 16-bit conv kernels"
 bash scripts/pmc_roofline_kernel.sh > $O/r02_pmc_roofline_kernel.txt 2> $O/pmc_roof.err
 bash scripts/pmc_lp.sh > $O/r02_pmc_lp.txt 2> $O/pmc_lp.err

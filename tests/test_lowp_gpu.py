@@ -49,6 +49,10 @@ CONV_CASES = [  # (k, ci, co, shape NDHW, transform)
     (3, 8, 8, (1, 8, 8, 16), True), (3, 16, 16, (2, 5, 9, 17), True), (3, 32, 8, (1, 4, 8, 32), False),
     (3, 7, 14, (1, 8, 8, 8), True), (3, 56, 28, (1, 6, 8, 8), True), (3, 128, 32, (1, 4, 4, 8), False),
     (3, 40, 64, (1, 4, 8, 16), True), (5, 8, 16, (1, 6, 7, 16), True), (5, 64, 16, (1, 4, 4, 8), False),
+    # 8-channel sides at >= 16-wide volumes: the weight gradient's (w-shift, channel) tiles (k = 3 and 5; both sides, either
+    # side; 16- and 32-wide boxes; volumes that are not multiples of the box), the k = 5 forward's weight groups in LDS
+    (5, 8, 8, (1, 8, 8, 32), True), (5, 32, 8, (1, 4, 9, 20), True), (3, 8, 16, (2, 5, 9, 40), True),
+    (3, 8, 8, (1, 4, 8, 40), False), (5, 8, 8, (1, 5, 6, 18), False), (3, 16, 8, (1, 8, 8, 16), True),
 ]
 
 
