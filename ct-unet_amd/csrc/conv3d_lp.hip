@@ -746,8 +746,11 @@ __global__ __launch_bounds__(256) void lp_conv_fwd_p1_kernel(LpConvP p, int ntil
 struct LpBox { int th, bw; };
 
 // box of a forward / data-gradient launch: bigger boxes for thin voxels (see lp_conv_fwd_kernel)
-LpBox lp_box(int W, int rin_p) {
+LpBox lp_box(int W, int rin_p, int64_t nvox) {
     const int nch = (rin_p >= LP_SC ? LP_SC : rin_p) >> 3;
+    // the deep levels (<= 16^3 voxels): 4x4x8 boxes -- twice the blocks of the 4x8x8 / 4x4x16 boxes (a 16^3 layer with 64
+    // output channels: 128 blocks instead of 64) and half the per-block latency chain; these launches never fill the chip
+    if (nvox <= 4096) return {4, 8};
     if (W < 16) return {8, 8};
     // (a 4x8x32 box for single-chunk layers was tried: 16 column tiles per wave cost 277 registers = one wave per SIMD, and
     //  the stamps showed every phase serialised in that one wave: 17.6 k cycles per box against 1.8 k of MFMA work)
@@ -756,7 +759,7 @@ LpBox lp_box(int W, int rin_p) {
 }
 
 int lp_fill(LpConvP& p, int N, int D, int H, int W, int rin_p) {
-    const LpBox bx = lp_box(W, rin_p);
+    const LpBox bx = lp_box(W, rin_p, (int64_t)N * D * H * W);
     p.N = N; p.D = D; p.H = H; p.W = W;
     p.tiles_d = ceil_div(D, 4); p.tiles_h = ceil_div(H, bx.th); p.tiles_w = ceil_div(W, bx.bw);
     return N * p.tiles_d * p.tiles_h * p.tiles_w;
@@ -831,7 +834,7 @@ int lp_conv_launch_persist(LpConvP& p, int ntiles, hipStream_t st) {
 
 template <class T, int KS, int NT>
 int lp_conv_launch(LpConvP& p, int ntiles, hipStream_t st) {
-    const LpBox bx = lp_box(p.W, p.rin_p);
+    const LpBox bx = lp_box(p.W, p.rin_p, (int64_t)p.N * p.D * p.H * p.W);
     if constexpr (KS == 3) {
         if (lp_use_persist(3, p.rin_p, ntiles)) {
             if (bx.bw == 32) return lp_conv_launch_persist<T, NT, 8, 32>(p, ntiles, st);
@@ -840,6 +843,7 @@ int lp_conv_launch(LpConvP& p, int ntiles, hipStream_t st) {
         }
     }
     if (bx.bw == 32) return lp_conv_launch_box<T, KS, NT, 8, 32>(p, ntiles, st);
+    if (bx.bw == 8 && bx.th == 4) return lp_conv_launch_box<T, KS, NT, 4, 8>(p, ntiles, st);
     if (bx.bw == 8) return lp_conv_launch_box<T, KS, NT, 8, 8>(p, ntiles, st);
     if (bx.th == 8) return lp_conv_launch_box<T, KS, NT, 8, 16>(p, ntiles, st);
     return lp_conv_launch_box<T, KS, NT, 4, 16>(p, ntiles, st);
@@ -1215,7 +1219,7 @@ extern "C" size_t ctu_lp_conv3d_packed_elems(int k, int rin_p, int nout_p) {
 extern "C" int ctu_lp_conv3d_num_blocks(int N, int D, int H, int W, int k, int rin_p) {
     LpConvP p;
     const int ntiles = lp_fill(p, N, D, H, W, rin_p);
-    if (lp_use_persist(k, rin_p, ntiles) && lp_box(W, rin_p).bw >= 16) {
+    if (lp_use_persist(k, rin_p, ntiles) && lp_box(W, rin_p, (int64_t)N * D * H * W).bw >= 16) {
         int gx, tpb;
         lp_persist_grid(ntiles, &gx, &tpb);
         return gx;
