@@ -457,6 +457,213 @@ __global__ __launch_bounds__(256) void lp_conv_fwd_kernel(LpConvP p) {
     }
 }
 
+// ---- deep-level k = 3 variant (<= 16^3 voxels, 4x4x8 boxes): these launches have 16-128 blocks on 256 CUs, so a block's own
+// latency chain is the kernel's duration; in the box kernel above every 32-channel stage pays two exposed global round trips
+// (weights, input box) before its 54 MFMAs.  Here the NEXT stage's weights, input items and BatchNorm vectors are fetched into
+// registers while this stage's K loop runs: a stage costs LDS writes, three barriers and the K loop
+// (128 -> 128 at 8^3: 4 stages).  Same packed weights, same stats rows (one per box) as lp_conv_fwd_kernel<.., 4, 8, ..>.
+template <class T, int NT>
+__global__ __launch_bounds__(256) void lp_conv_fwd_small_kernel(LpConvP p) {
+    typedef typename Vec<T>::v8 v8;
+    constexpr int TAPS = 27, PK = 1, TD = 4, TH = 4, BW = 8, CT = 2;
+    constexpr int HD = TD + 2, HH = TH + 2, HW = BW + 2, HV = HD * HH * HW;
+    constexpr int NI = (HV * 4 + 255) / 256;                         // input items (halo voxel, chunk slot) per thread
+    constexpr int NW = (TAPS * NT * 64 + 255) / 256;                 // 16-byte weight pieces of a stage per thread
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int* sK = reinterpret_cast<int*>(smem);
+    float* sXf = reinterpret_cast<float*>(smem + 2048);
+    float* sRed = reinterpret_cast<float*>(smem + 2048 + 256);
+    unsigned char* sIn = smem + 2048 + 256 + 4 * NT * 32 * 4;
+    unsigned char* sW = sIn + (size_t)HV * p.S;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 15, kg = lane >> 4;
+    const int S = p.S;
+    int t = blockIdx.x;
+    const int tx = t % p.tiles_w; t /= p.tiles_w;
+    const int ty = t % p.tiles_h; t /= p.tiles_h;
+    const int tz = t % p.tiles_d;
+    const int n = t / p.tiles_d;
+    const int d0 = tz * TD, h0 = ty * TH, w0 = tx * BW;
+    const int n16 = (p.nout_p + 15) >> 4, nt0 = blockIdx.y * NT;
+    const T* in = reinterpret_cast<const T*>(p.in);
+    const T* wp = reinterpret_cast<const T*>(p.wp);
+    const int ns = lp_nstage(p.rin_p);
+    const bool xf = p.scale != nullptr;
+    // per-thread input items: (halo voxel v, chunk slot c of 4); clamped global element offset, validity, LDS destination
+    size_t goff[NI];
+    int dst[NI];
+    unsigned inb = 0;                                               // bit u: the voxel of item u lies inside the volume
+#pragma unroll
+    for (int u = 0; u < NI; ++u) {
+        const int i = tid + u * 256, v = min(i >> 2, HV - 1), c = i & 3;
+        const int pw = v % HW, t2 = v / HW, ph = t2 % HH, pd = t2 / HH;
+        const int gd = d0 + pd - PK, gh = h0 + ph - PK, gw = w0 + pw - PK;
+        const bool ok = i < HV * 4 && (unsigned)gd < (unsigned)p.D && (unsigned)gh < (unsigned)p.H && (unsigned)gw < (unsigned)p.W;
+        const int cd = min(max(gd, 0), p.D - 1), chh = min(max(gh, 0), p.H - 1), cw = min(max(gw, 0), p.W - 1);
+        goff[u] = ((((size_t)n * p.D + cd) * p.H + chh) * p.W + cw) * p.in_cs;
+        dst[u] = i < HV * 4 ? v * S + c * 16 : -1;
+        inb |= ok ? (1u << u) : 0u;
+    }
+    uint4 araw[NI], wq[NW];
+    float xfv = 0.f;
+    auto load_stage = [&](int st) {
+        const int nch = lp_stage_nch(p.rin_p, st), pieces = lp_ksteps(TAPS, nch) * NT * 64, kbase = st * TAPS;
+#pragma unroll
+        for (int u = 0; u < NW; ++u) {
+            const int i = min(tid + u * 256, pieces - 1);
+            const int ln = i & 63, fr = i >> 6, nt = fr % NT, s_ = fr / NT;
+            const int tile = min(nt0 + nt, n16 - 1);
+            wq[u] = *reinterpret_cast<const uint4*>(wp + ((size_t)((kbase + s_) * n16 + tile) * 64 + ln) * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+            const int c = (tid + u * 256) & 3;
+            araw[u] = *reinterpret_cast<const uint4*>(in + goff[u] + st * LP_SC + (c < nch ? c : 0) * 8);
+        }
+        if (xf && tid < 64) {
+            const int c = st * LP_SC + (tid & 31);
+            xfv = (c < p.rin_p) ? ((tid < 32) ? p.scale[c] : p.shift[c]) : 0.f;
+        }
+    };
+    f32x4 acc[CT][NT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[ct][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // this lane's voxel of column tile ct: rows th = 2 ct + (m >> 3), column tw = m & 7
+    const int hb0 = ((wave * HH + (m >> 3)) * HW + (m & 7)) * S;
+    load_stage(0);
+    for (int st = 0; st < ns; ++st) {
+        const int nch = lp_stage_nch(p.rin_p, st), ks = lp_ksteps(TAPS, nch);
+        __syncthreads();                                            // the previous stage's K loop is done with sK, sW, sIn
+        for (int i = tid; i < ks * 4; i += 256) {
+            const int tap = i / nch, ch = i % nch;
+            sK[i] = tap < TAPS ? (((tap / 9) * HH + (tap / 3) % 3) * HW + tap % 3) * S + ch * 16 : 0;
+        }
+        if (tid < 64) sXf[tid] = xfv;
+        {
+            const int pieces = ks * NT * 64;
+#pragma unroll
+            for (int u = 0; u < NW; ++u) {
+                const int i = tid + u * 256;
+                if (i < pieces) *reinterpret_cast<uint4*>(sW + (size_t)i * 16) = wq[u];
+            }
+        }
+        __syncthreads();                                            // sXf visible
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+            const int c = (tid + u * 256) & 3;
+            if (dst[u] < 0 || c >= nch) continue;
+            uint4 r = araw[u];
+            if (!((inb >> u) & 1u)) r = make_uint4(0u, 0u, 0u, 0u);     // the ACTIVATED input is zero padded
+            else if (xf) {
+                const f32x8 f = __builtin_convertvector(*reinterpret_cast<v8*>(&r), f32x8);
+                f32x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float a = fmaf(f[j], sXf[c * 8 + j], sXf[32 + c * 8 + j]);
+                    o[j] = p.relu ? fmaxf(a, 0.f) : a;
+                }
+                *reinterpret_cast<v8*>(&r) = __builtin_convertvector(o, v8);
+            }
+            *reinterpret_cast<uint4*>(sIn + dst[u]) = r;
+        }
+        __syncthreads();
+        if (st + 1 < ns) load_stage(st + 1);                        // in flight under this stage's K loop
+        // ---- K loop, U K-steps per batch: every fragment of the batch (2 U input + U NT weight reads, U offset-table
+        // reads for the NEXT batch) is in flight before its 2 U NT MFMAs -- with two column tiles per wave a K-step alone
+        // carries too few MFMAs to hide an LDS round trip (one K-step at a time: 27 dependent round trips per stage)
+        {
+            constexpr int U = 3;
+            int ko[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) ko[u] = sK[4 * min(u, ks - 1) + kg] + hb0;
+            for (int s0 = 0; s0 < ks; s0 += U) {
+                v8 bb[U][2], aa[U][NT];
+                int kn[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int su = min(s0 + u, ks - 1);
+                    bb[u][0] = *reinterpret_cast<const v8*>(sIn + ko[u]);
+                    bb[u][1] = *reinterpret_cast<const v8*>(sIn + ko[u] + 2 * HW * S);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) aa[u][nt] = *reinterpret_cast<const v8*>(sW + ((size_t)(su * NT + nt) * 64 + lane) * 16);
+                    kn[u] = sK[4 * min(s0 + U + u, ks - 1) + kg] + hb0;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (s0 + u < ks) {
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            acc[0][nt] = Mfma<T>::run(aa[u][nt], bb[u][0], acc[0][nt]);
+                            acc[1][nt] = Mfma<T>::run(aa[u][nt], bb[u][1], acc[1][nt]);
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < U; ++u) ko[u] = kn[u];
+            }
+        }
+    }
+    // ---- epilogue: lane holds out channels 4 kg .. 4 kg + 3 of tile nt for its voxel of column tile ct
+    T* out = reinterpret_cast<T*>(p.out);
+    float s1[NT][4], s2[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s1[nt][r] = 0.f; s2[nt][r] = 0.f; }
+    const int gd = d0 + wave;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int cb = (nt0 + nt) * 16 + 4 * kg;
+        if (cb >= p.nout_p) continue;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias) {
+            bv.x = cb + 0 < p.nbias ? p.bias[cb + 0] : 0.f; bv.y = cb + 1 < p.nbias ? p.bias[cb + 1] : 0.f;
+            bv.z = cb + 2 < p.nbias ? p.bias[cb + 2] : 0.f; bv.w = cb + 3 < p.nbias ? p.bias[cb + 3] : 0.f;
+        }
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int gh = h0 + ct * 2 + (m >> 3), gw = w0 + (m & 7);
+            if (gd < p.D && gh < p.H && gw < p.W) {
+                const float4 o = rnd4<T>(make_float4(acc[ct][nt][0] + bv.x, acc[ct][nt][1] + bv.y, acc[ct][nt][2] + bv.z,
+                                                     acc[ct][nt][3] + bv.w));
+                st4<T>(out + ((((size_t)n * p.D + gd) * p.H + gh) * p.W + gw) * p.out_cs + cb, o);
+                s1[nt][0] += o.x; s1[nt][1] += o.y; s1[nt][2] += o.z; s1[nt][3] += o.w;
+                s2[nt][0] += o.x * o.x; s2[nt][1] += o.y * o.y; s2[nt][2] += o.z * o.z; s2[nt][3] += o.w * o.w;
+            }
+        }
+    }
+    if (p.stats) {                                                  // one BatchNorm partial row [2][nout_p] per spatial block
+        __syncthreads();
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float a1 = s1[nt][r], a2 = s2[nt][r];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { a1 += __shfl_xor(a1, o); a2 += __shfl_xor(a2, o); }
+                if (m == 0) {
+                    sRed[((wave * NT + nt) * 2 + 0) * 16 + 4 * kg + r] = a1;
+                    sRed[((wave * NT + nt) * 2 + 1) * 16 + 4 * kg + r] = a2;
+                }
+            }
+        __syncthreads();
+        if (tid < NT * 32) {
+            const int nt = tid >> 5, which = (tid >> 4) & 1, c = tid & 15;
+            const int ch = (nt0 + nt) * 16 + c;
+            if (ch < p.nout_p) {
+                float sx = 0.f;
+#pragma unroll
+                for (int wv = 0; wv < 4; ++wv) sx += sRed[((wv * NT + nt) * 2 + which) * 16 + c];
+                st_sc1(p.stats + (size_t)blockIdx.x * 2 * p.nout_p + which * p.nout_p + ch, sx);
+            }
+        }
+        if (p.tail.counter) bn_fwd_tail(p.tail, p.stats, gridDim.x, p.nout_p, gridDim.x * gridDim.y);
+    }
+}
+
 // ---- persistent single-stage k = 3 variant (rin_p <= 32: every 128^3 / 64^3 layer of the shipped nets).  With 16-byte voxels
 // the box kernel above is VALU-bound on index arithmetic (SQ counters: ~2000 vector instructions per wave for 112 MFMAs), so:
 //   * a block walks a contiguous range of boxes; tap-offset table, BatchNorm vectors and ALL weight fragments are staged once;
@@ -843,7 +1050,22 @@ int lp_conv_launch(LpConvP& p, int ntiles, hipStream_t st) {
         }
     }
     if (bx.bw == 32) return lp_conv_launch_box<T, KS, NT, 8, 32>(p, ntiles, st);
-    if (bx.bw == 8 && bx.th == 4) return lp_conv_launch_box<T, KS, NT, 4, 8>(p, ntiles, st);
+    if (bx.bw == 8 && bx.th == 4) {
+        if constexpr (KS == 3) {
+            const size_t lds = 2048 + 256 + 4 * NT * 32 * 4 + (size_t)(6 * 6 * 10) * p.S + (size_t)27 * NT * 1024;
+            const int n16 = (p.nout_p + 15) >> 4;
+            static size_t raised = 64 * 1024;
+            if (lds > raised) {
+                CTU_REQUIRE(hipFuncSetAttribute((const void*)lp_conv_fwd_small_kernel<T, NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                (int)lds) == hipSuccess, "lp_conv3d_fwd: cannot raise the dynamic LDS limit");
+                raised = lds;
+            }
+            lp_conv_fwd_small_kernel<T, NT><<<dim3(ntiles, ceil_div(n16, NT)), 256, lds, st>>>(p);
+            CTU_CHECK_LAUNCH("lp_conv3d_fwd (deep level)");
+            return CTU_OK;
+        }
+        return lp_conv_launch_box<T, KS, NT, 4, 8>(p, ntiles, st);
+    }
     if (bx.bw == 8) return lp_conv_launch_box<T, KS, NT, 8, 8>(p, ntiles, st);
     if (bx.th == 8) return lp_conv_launch_box<T, KS, NT, 8, 16>(p, ntiles, st);
     return lp_conv_launch_box<T, KS, NT, 4, 16>(p, ntiles, st);
