@@ -12,11 +12,13 @@ timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 
 echo "[3] rocprof kernel stats of the default command"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o r -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_prof.json 2> $O/bench_prof.err
 cp $O/prof/r_kernel_stats.csv $O/r02_kernel_stats.csv
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bf16 -o r -- python bench.py --dtype bf16 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_prof_bf16.json 2> $O/bench_prof_bf16.err
+cp $O/prof_bf16/r_kernel_stats.csv $O/r02_kernel_stats_bf16.csv
 echo "[4] FETCH_SIZE / WRITE_SIZE passes (eager, separate)"
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o r -- python bench.py --eager --steps 5 --warmup 2 --no-cpu-baseline > $O/pmc_fetch.json 2> $O/pmc_fetch.err
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o r -- python bench.py --eager --steps 5 --warmup 2 --no-cpu-baseline > $O/pmc_write.json 2> $O/pmc_write.err
 python scripts/collect_traffic.py $O/pmc_fetch $O/pmc_write $O/r02_hbm_traffic.json > /dev/null
-rm -f $O/*/*kernel_trace.csv $O/prof/*trace.csv $O/pmc_fetch/*counter_collection.csv $O/pmc_write/*counter_collection.csv
+rm -f $O/*/*kernel_trace.csv $O/prof/*trace.csv $O/prof_bf16/*trace.csv $O/pmc_fetch/*counter_collection.csv $O/pmc_write/*counter_collection.csv
 echo "[5] inference leg (cfg 2: 128^3, batch 2, eval)"
 timeout -k 10 300 $B --mode infer --batch 2 --no-cpu-baseline --steps 30 --warmup 5 > $O/r02_bench_infer_b2.json 2> $O/bench_infer.err
 echo "[6] 16-bit legs"
