@@ -81,6 +81,13 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stats, int nblocks,
                                    long long* __restrict__ nbt) {
     const int c = blockIdx.x;
     if (nbt && c == 0 && threadIdx.x == 0 && n_updates > 0) nbt[0] += n_updates;     // num_batches_tracked
+    // the channel's parameters are fetched BEFORE the row reduction (this kernel is one dependent chain of memory round
+    // trips on the step's critical path: rows -> block sum -> parameters -> stores; the parameter trip now overlaps the rows)
+    float g_ = 0.f, b_ = 0.f, rm0 = 0.f, rv0 = 0.f;
+    if (threadIdx.x == 0 && c < C) {
+        g_ = gamma[c]; b_ = beta[c];
+        if (rmean && n_updates > 0) { rm0 = rmean[c]; rv0 = rvar[c]; }
+    }
     double s1 = 0.0, s2 = 0.0;
     if (c < C) {
 #pragma unroll 4
@@ -96,14 +103,14 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stats, int nblocks,
             double var = s2 / count - mean * mean;
             if (var < 0.0) var = 0.0;
             const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-            const float sc = gamma[c] * invstd;
+            const float sc = g_ * invstd;
             scale[c] = sc;
-            shift[c] = beta[c] - (float)mean * sc;
+            shift[c] = b_ - (float)mean * sc;
             mean_out[c] = (float)mean;
             invstd_out[c] = invstd;
             if (rmean && n_updates > 0) {
                 const float unb = (float)(var * (count / (count > 1.0 ? count - 1.0 : 1.0)));
-                float rm = rmean[c], rv = rvar[c];
+                float rm = rm0, rv = rv0;
                 for (int u = 0; u < n_updates; ++u) {
                     rm = (1.f - momentum) * rm + momentum * (float)mean;
                     rv = (1.f - momentum) * rv + momentum * unb;
@@ -183,6 +190,11 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int n
                                        long long* __restrict__ nbt) {
     const int c = blockIdx.x;
     if (nbt && rmean && c == 0 && threadIdx.x == 0) nbt[0] += 1;                      // the replayed update counts too
+    float g_ = 0.f, is_ = 0.f, mu_ = 0.f, rm0 = 0.f, rv0 = 0.f;                      // (prefetched: see bn_finalize_kernel)
+    if (threadIdx.x == 0 && c < C) {
+        g_ = gamma[c]; is_ = invstd[c];
+        if (rmean) { mu_ = mean[c]; rm0 = rmean[c]; rv0 = rvar[c]; }
+    }
     double s1 = 0.0, s2 = 0.0;
     if (c < C) {
 #pragma unroll 4
@@ -196,18 +208,18 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int n
         if (c < C) {
             dbeta[c] = (float)s1;
             dgamma[c] = (float)s2;
-            coef[c] = gamma[c] * invstd[c];
+            coef[c] = g_ * is_;
             coef[cp + c] = (float)(s1 / count);
             coef[2 * cp + c] = (float)(s2 / count);
             if (rmean) {
                 // the running-stat update torch.utils.checkpoint's recompute repeats in backward (models.py:232-255):
                 // same batch statistics as the forward update; the biased variance is recovered from invstd
-                const double istd = (double)invstd[c];
+                const double istd = (double)is_;
                 double var = 1.0 / (istd * istd) - (double)eps;
                 if (var < 0.0) var = 0.0;
                 const float unb = (float)(var * (count / (count > 1.0 ? count - 1.0 : 1.0)));
-                rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean[c];
-                rvar[c] = (1.f - momentum) * rvar[c] + momentum * unb;
+                rmean[c] = (1.f - momentum) * rm0 + momentum * mu_;
+                rvar[c] = (1.f - momentum) * rv0 + momentum * unb;
             }
         } else {
             coef[c] = 0.f; coef[cp + c] = 0.f; coef[2 * cp + c] = 0.f;
