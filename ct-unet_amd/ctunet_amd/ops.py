@@ -104,6 +104,14 @@ class KernelTimer:
     def __init__(self):
         self.records = []
         self.details = []
+        self._empty = []           # event pairs around NOTHING, interleaved with the timed launches: the bracket's own cost
+
+    def _overhead_ms(self) -> float:
+        """Median elapsed time of the empty event pairs (recorded every 16th launch): what an event pair measures when
+        there is no kernel between the two records (2-5 us on this stack) -- subtracted from every bracketed launch, so the
+        per-launch figures agree with the kernel-trace durations of rocprofv3."""
+        ts = sorted(a.elapsed_time(b) for a, b in self._empty)
+        return ts[len(ts) // 2] if ts else 0.0
 
     def begin(self):
         ev = torch.cuda.Event(enable_timing=True)
@@ -115,14 +123,21 @@ class KernelTimer:
         ev.record()
         self.records.append((tag, flops, nbytes, start, ev))
         self.details.append(detail)
+        if len(self.records) % 16 == 1:
+            a = torch.cuda.Event(enable_timing=True)
+            b = torch.cuda.Event(enable_timing=True)
+            a.record()
+            b.record()
+            self._empty.append((a, b))
 
     def by_layer(self):
         """{(tag, detail): dict(launches, total_ms, flops)} -- per-geometry split of ``summary`` (dev tool)."""
         out = {}
+        ovh = self._overhead_ms()
         for (tag, fl, nb, a, b), det in zip(self.records, self.details):
             d = out.setdefault((tag, det), dict(launches=0, total_ms=0.0, flops=0.0))
             d["launches"] += 1
-            d["total_ms"] += a.elapsed_time(b)
+            d["total_ms"] += max(a.elapsed_time(b) - ovh, 1e-4)
             d["flops"] += fl
         return out
 
@@ -132,8 +147,9 @@ class KernelTimer:
         an event pair (an allocator hipMalloc, RCCL's lazy channel set-up in the first eager distributed step: 73 ms once,
         measured) would otherwise be booked on whatever kernel happened to be bracketed."""
         sites = {}
+        ovh = self._overhead_ms()
         for (tag, fl, nb, a, b), det in zip(self.records, self.details):
-            sites.setdefault((tag, det, fl, nb), []).append(a.elapsed_time(b))
+            sites.setdefault((tag, det, fl, nb), []).append(max(a.elapsed_time(b) - ovh, 1e-4))
         out = {}
         for (tag, det, fl, nb), ts in sites.items():
             ts.sort()

@@ -82,9 +82,9 @@ algorithmic ceiling of this layer is 0.75 × (actual / nominal clock) ≈ 0.70 o
 `r02_stage_table_f32.md`, `_bf16.md`, `_infer_b2.md`, `_recAE_f32.md`, `_recAE_192_bf16.md` — per conv STAGE (width, padded
 C_in, padded C_out) → kernel symbol, launches per step, µs per launch, algorithmic TFLOP/s and GB/s (`scripts/stage_table.py`,
 HIP events around every conv / ConvTranspose launch of eager steps; the counter column repeats the per-symbol average of
-`r02_hbm_traffic.json`).  Launches shorter than ≈20 µs read too long in these tables: between the two events of an eagerly
-launched kernel sits the host's enqueue latency (the deep-level kernels measure 14 µs in `r02_kernel_stats_bf16.csv`, ≈20 µs
-here); the rocprofv3 traces are the reference for those.
+`r02_hbm_traffic.json`).  The cost of an event pair itself (median of empty pairs interleaved with the launches, 2–5 µs) is
+subtracted from every bracketed launch; the per-launch figures then agree with the rocprofv3 kernel traces (roofline kernel:
+events vs trace above).
 `r02_kernel_stats_bf16.csv` — `rocprofv3 --kernel-trace --stats` of `python bench.py --dtype bf16 --steps 20 --warmup 5`.
 
 `r02_pmc_lp.txt` — SQ counters of the 16-bit kernels (`scripts/pmc_lp.sh`): the 8→8 128³ forward issues 13 VALU and 5.5
