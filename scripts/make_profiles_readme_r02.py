@@ -102,6 +102,9 @@ k = 5 kernels, `recAE_v2_fixed` 128³ fp32: 22.56 ms (round-1 kernels) → 20.50
 layout) → 16.90 ((w-shift, channel)-tile weight gradient).  16-bit k = 5 forward, `recAE_v2_fixed` 192³ bf16: 29.2 ms (weight
 fragments through a register ring) → 24.0 (groups of 25 K-steps in LDS where a K-step carries ≤ 4 MFMAs; 32→8 at 192³
 5537 → 3136 µs, 64→16 at 96³ 1580 → 793; the ring stays for 8-channel voxels and two out tiles: 8→32 519 vs 1249 µs).
+16-bit train step of `UNet()` 128³ (bf16) through the round: 3.43 ms (first complete path) → 3.36 → 3.17 ((w-shift, channel)
+weight-gradient tiles) → 3.11 (deep-level kernel) → 2.79 (fused decoder up-convolutions through the fp32 fused kernels on
+fp32 copies, `CTUNET_LP_FUSE_UP`).
 
 `r02_diag_grad_UNetDO_seed123{{4,5}}.txt` — `scripts/diag_grad_layers.py`: where this path and ATen-CPU fp32 leave the fp64
 oracle's gradients (single ReLU-mask flips, at different layers), the evidence behind the gradient gates of the tests.
