@@ -368,6 +368,10 @@ def main():
                        "comm_ms_exposed": None if comm_ms_exposed is None else round(comm_ms_exposed, 4),
                        "grad_buckets": (len(gstep.flats) if distributed and mode == "hipgraph" and train else None),
                        "comm_backend": (getattr(gstep.comm, "backend", None) if distributed and mode == "hipgraph" and train else None),
+                       "precision_note": (None if args.dtype == "f32" else
+                                          "16-bit activations / activation gradients, fp32 accumulate, statistics, master weights and "
+                                          "weight gradients; the fused decoder up-convolutions (k = 3 nets) run the fp32 kernels on "
+                                          "fp32 copies of their operands"),
                        "whole_step_tflops_algorithmic": round(flop_vox * value / 1e12, 2),
                        "whole_step_frac_of_mfma_peak": round(flop_vox * value / world / 1e12 /
                                                              (PEAK_16BIT_MFMA_TFLOPS if lowp else PEAK_FP32_MFMA_TFLOPS), 4),
