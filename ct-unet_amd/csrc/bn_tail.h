@@ -16,6 +16,15 @@ namespace {
 __device__ __forceinline__ void st_sc1(float* p, float v) {
     __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// a partial row element: write-through only when this launch finalizes itself (the tail's hand-off needs it); a plain store
+// otherwise, which keeps the line in the XCD's L2 for the finalize launch that follows (an sc1 store drops it)
+__device__ __forceinline__ void st_row(bool write_through, float* p, float v) {
+#ifdef CTU_ROW_SC1                                   /* dev A/B: the round-2 behaviour (always write-through) */
+    write_through = true;
+#endif
+    if (write_through) st_sc1(p, v);
+    else *p = v;
+}
 __device__ __forceinline__ float ld_sc1(const float* p) {
     return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
@@ -102,12 +111,15 @@ __device__ __forceinline__ void bn_fwd_finalize_rows(const ctu_bn_tail& t, const
 __device__ __forceinline__ void bn_bwd_finalize_rows(const ctu_bn_bwd_tail& t, const float* rows, int nrows, int cp) {
     if (t.num_batches_tracked && t.running_mean && threadIdx.x == 0) t.num_batches_tracked[0] += 1;
     tail_reduce_rows(rows, nrows, cp, t.C, [&](int c, double s1, double s2) {
-        if (c >= t.C) { t.coef[c] = 0.f; t.coef[cp + c] = 0.f; t.coef[2 * cp + c] = 0.f; return; }
+        if (c >= t.C) { t.coef[c] = 0.f; t.coef[cp + c] = 0.f; t.coef[2 * cp + c] = 0.f; t.coef[3 * cp + c] = 0.f; t.coef[4 * cp + c] = 0.f; return; }
         t.dbeta[c] = (float)s1;
         t.dgamma[c] = (float)s2;
-        t.coef[c] = t.gamma[c] * t.invstd[c];
-        t.coef[cp + c] = (float)(s1 / t.count);
-        t.coef[2 * cp + c] = (float)(s2 / t.count);
+        const float is_ = t.invstd[c], k0 = t.gamma[c] * is_, k1 = (float)(s1 / t.count), k2 = (float)(s2 / t.count);
+        t.coef[c] = k0;
+        t.coef[cp + c] = k1;
+        t.coef[2 * cp + c] = k2;
+        t.coef[3 * cp + c] = -k0 * k2 * is_;                      // (bn_bwd_finalize_kernel's A, B)
+        t.coef[4 * cp + c] = -k0 * (k1 - k2 * t.mean[c] * is_);
         if (t.running_mean) {
             const double istd = (double)t.invstd[c];
             double var = 1.0 / (istd * istd) - (double)t.eps;

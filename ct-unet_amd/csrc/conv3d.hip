@@ -329,8 +329,8 @@ __global__ __launch_bounds__(256) void conv3d_fwd_kernel(ConvP p) {
                     b += sRed[((w * NT) * 16 + tid) * 2 + 1];
                 }
                 float* row = p.stats + (size_t)blockIdx.x * 2 * p.nout_p;
-                st_sc1(row + co, a);
-                st_sc1(row + p.nout_p + co, b);
+                st_row(p.tail.counter != nullptr, row + co, a);
+                st_row(p.tail.counter != nullptr, row + p.nout_p + co, b);
             }
         }
         if (p.tail.counter) bn_fwd_tail(p.tail, p.stats, gridDim.x, p.nout_p, gridDim.x * gridDim.y);
@@ -368,8 +368,11 @@ __device__ unsigned long long* g_stamp_out = nullptr;
 
 // second launch bound = waves per SIMD the register allocation must allow: 3 resident blocks for the NT = 1 box
 // (45 KB of LDS each), 2 for the pair layout and NT = 2 (LDS- / accumulator-bound)
+#ifndef CTU_FWD_OCC1
+#define CTU_FWD_OCC1 3
+#endif
 template <int NT, bool PAIR>
-__global__ __launch_bounds__(256, (NT == 1 && !PAIR) ? 3 : 2) void conv3d_fwd_k3_persist(ConvP p, int ntiles, int tiles_per_block) {
+__global__ __launch_bounds__(256, (NT == 1 && !PAIR) ? CTU_FWD_OCC1 : 2) void conv3d_fwd_k3_persist(ConvP p, int ntiles, int tiles_per_block) {
     constexpr int MT = 4;
     constexpr int TD = 4, TH = 4, TW = PAIR ? 32 : 16;
     constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2, HV = HD * HH * HW;
@@ -537,11 +540,16 @@ __global__ __launch_bounds__(256, (NT == 1 && !PAIR) ? 3 : 2) void conv3d_fwd_k3
 #endif
 
     while (true) {
+        CTU_SETPRIO(CTU_PRIO_STAGE);           // staging phases outrank the other block's MFMA stream
         __syncthreads();                       // the previous stage's readers are done with sA / sW
         STAMP(tq1);
         {
             auto put = [&](int it, float4 val) {
                 const int i = tid + it * NTHR;
+#ifdef CTU_ABL_NOLDSW                                 // timing-only build: the transform runs, the LDS stores do not
+                asm volatile("" :: "v"(val.x), "v"(val.y), "v"(val.z), "v"(val.w));
+                return;
+#endif
                 if ((it + 1) * NTHR <= AITEMS || i < AITEMS) {
                     if (PAIR) {                       // 40-byte voxel stride: two 8-byte stores
                         sA2[(i >> 1) * VS2 + half * 2] = v2f{val.x, val.y};
@@ -578,10 +586,16 @@ __global__ __launch_bounds__(256, (NT == 1 && !PAIR) ? 3 : 2) void conv3d_fwd_k3
         if (nc == nchunk) { nc = 0; ntile = tile + 1; nbox = box_next(box); }
         const bool has_next = ntile < tile_end;
         if (has_next) {
+#ifndef CTU_ABL_NOLOAD
             load_a(nbox, nc);
+#else       // timing-only build: the staged values stay what the first fetch brought (opaque, so nothing is hoisted)
+#pragma unroll
+            for (int it = 0; it < AITER; ++it) asm volatile("" : "+v"(va[it].x), "+v"(va[it].y), "+v"(va[it].z), "+v"(va[it].w));
+#endif
             if (!hoist_w) load_w(nc);
         }
         STAMP(tq3);
+        CTU_SETPRIO(0);
         // ---- taps on the matrix cores: rows = output channels, columns = voxels (or voxel pairs).
         // Group (kd, kw): the 6 input rows th' = 0..5 feed the 3 kh taps of all 4 M-tiles (row th + kh), so each group
         // needs 6 + 3*NT fragment reads for 12*NT*2 MFMAs; the next group's fragments are read before this group's MFMAs.
@@ -597,10 +611,18 @@ __global__ __launch_bounds__(256, (NT == 1 && !PAIR) ? 3 : 2) void conv3d_fwd_k3
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) bb[kh][nt] = vW[(((kd * 3 + kh) * KWN + kw) * NT + nt) * 64 + bbase];
             };
+#ifdef CTU_ABL_NOMFMA
+            constexpr int NGX = 1;                     // timing-only build: one tap group instead of NG
+#else
+            constexpr int NGX = NG;
+#endif
             load_group(0, ar[0], br[0]);
+#if CTU_PIN_FWD
+            __builtin_amdgcn_sched_barrier(0);         // (the first group's reads stay out of the pinned sequence below)
+#endif
 #pragma unroll
-            for (int gq = 0; gq < NG; ++gq) {
-                if (gq + 1 < NG) load_group(gq + 1, ar[(gq + 1) & 1], br[(gq + 1) & 1]);
+            for (int gq = 0; gq < NGX; ++gq) {
+                if (gq + 1 < NGX) load_group(gq + 1, ar[(gq + 1) & 1], br[(gq + 1) & 1]);
                 v2f (&aa)[6] = ar[gq & 1];
                 v2f (&bb)[3][NT] = br[gq & 1];
 #pragma unroll
@@ -616,9 +638,20 @@ __global__ __launch_bounds__(256, (NT == 1 && !PAIR) ? 3 : 2) void conv3d_fwd_k3
                         for (int mt = 0; mt < MT; ++mt)
                             acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bb[kh][nt].y, aa[mt + kh].y, acc[mt][nt], 0, 0, 0);
                 }
+#if CTU_PIN_FWD
+                // pin the order: the next group's fragment reads go out one per MFMA under THIS group's MFMAs (left to
+                // itself the scheduler sinks every read to just above its first use and drains lgkmcnt(0) there: one
+                // exposed LDS latency per 8 MFMAs, which only a second wave in ITS MFMA phase can cover)
+#pragma unroll
+                for (int q = 0; q < 24 * NT; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (gq + 1 < NGX && q < 6 + 3 * NT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+#endif
             }
         }
         STAMP(tq4);
+        CTU_SETPRIO(CTU_PRIO_STAGE);
         if (c == nchunk - 1) {
             // ---- epilogue of this box: bias, one float4 store per lane and (mt, nt), BN partial sums
             const int n_img = box.n, d0 = box.tz * TD, h0 = box.ty * TH, w0 = box.tx * TW;
@@ -642,7 +675,9 @@ __global__ __launch_bounds__(256, (NT == 1 && !PAIR) ? 3 : 2) void conv3d_fwd_k3
                         float4 o;
                         o.x = acc[mt][nt][0] + bv.x; o.y = acc[mt][nt][1] + bv.y;
                         o.z = acc[mt][nt][2] + bv.z; o.w = acc[mt][nt][3] + bv.w;
+#ifndef CTU_ABL_NOSTORE
                         *reinterpret_cast<float4*>(obase + mt * orow + co) = o;
+#endif
                         s1[nt][0] += o.x; s1[nt][1] += o.y; s1[nt][2] += o.z; s1[nt][3] += o.w;
                         s2[nt][0] += o.x * o.x; s2[nt][1] += o.y * o.y; s2[nt][2] += o.z * o.z; s2[nt][3] += o.w * o.w;
                     }
@@ -694,8 +729,8 @@ __global__ __launch_bounds__(256, (NT == 1 && !PAIR) ? 3 : 2) void conv3d_fwd_k3
                     a2 += sRed[(w * NT * 16 + tid) * 2 + 1];
                 }
                 float* row = p.stats + (size_t)blockIdx.x * 2 * p.nout_p;
-                st_sc1(row + co, a1);
-                st_sc1(row + p.nout_p + co, a2);
+                st_row(p.tail.counter != nullptr, row + co, a1);
+                st_row(p.tail.counter != nullptr, row + p.nout_p + co, a2);
             }
         }
         if (p.tail.counter) bn_fwd_tail(p.tail, p.stats, gridDim.x, p.nout_p, gridDim.x * gridDim.y);
@@ -923,6 +958,9 @@ __global__ __launch_bounds__(256, 1) void conv3d_fwd_k5_persist(ConvP p, int nti
                     for (int nt = 0; nt < NT; ++nt) bb[kh][nt] = vW[wb + ((kh * KWN + kw) * NT + nt) * 64 + bbase];
             };
             load_group(0, ar[0], br[0]);
+#if CTU_PIN_FWD
+            __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
             for (int kw = 0; kw < KWN; ++kw) {
                 if (kw + 1 < KWN) load_group(kw + 1, ar[(kw + 1) & 1], br[(kw + 1) & 1]);
@@ -941,6 +979,14 @@ __global__ __launch_bounds__(256, 1) void conv3d_fwd_k5_persist(ConvP p, int nti
                         for (int mt = 0; mt < MT; ++mt)
                             acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bb[kh][nt].y, aa[mt + kh].y, acc[mt][nt], 0, 0, 0);
                 }
+#if CTU_PIN_FWD
+                // the next group's fragment reads one per MFMA under this group's MFMAs (see conv3d_fwd_k3_persist)
+#pragma unroll
+                for (int q = 0; q < 2 * KS * MT * NT; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (kw + 1 < KWN && q < TH + KS - 1 + KS * NT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+#endif
             }
             if (kd + 1 < KS) {
                 store_w((kd + 1) & 1);         // (its last readers finished before the barrier that ended plane kd - 1)
@@ -1007,8 +1053,8 @@ __global__ __launch_bounds__(256, 1) void conv3d_fwd_k5_persist(ConvP p, int nti
                     a2 += sRed[(w * NT * 16 + tid) * 2 + 1];
                 }
                 float* row = p.stats + (size_t)blockIdx.x * 2 * p.nout_p;
-                st_sc1(row + co, a1);
-                st_sc1(row + p.nout_p + co, a2);
+                st_row(p.tail.counter != nullptr, row + co, a1);
+                st_row(p.tail.counter != nullptr, row + p.nout_p + co, a2);
             }
         }
         if (p.tail.counter) bn_fwd_tail(p.tail, p.stats, gridDim.x, p.nout_p, gridDim.x * gridDim.y);
@@ -1091,6 +1137,15 @@ struct WgP {
     int N, D, H, W;
     int tiles_d, tiles_h, tiles_w, ntiles;
     int n_ci_t, n_co_t;
+    // lazy BatchNorm+ReLU backward (conv3d_wgrad_k3s_kernel<.., LZ = true>): g is the gradient w.r.t. the ACTIVATED output,
+    // lz_y the layer's raw output (same geometry and channel stride as g), lz_scale / lz_shift its BatchNorm vectors,
+    // lz_coef = bn_bwd_finalize's [5][lz_cp] rows (k0, k1, k2, A, B); the raw-output gradient is written to lz_out
+    const float* lz_y;
+    float* lz_out;
+    const float* lz_scale;
+    const float* lz_shift;
+    const float* lz_coef;
+    int lz_cp;
 };
 
 // One block: one (ci-tile of 16, co-tile of 16) pair, KDS kd-planes of taps, a strided set of
@@ -1281,7 +1336,13 @@ inline int wgrad_gx(int ntiles, int pairs_z) {
 // sub-cube of the coarse halo -> dW_eff[parity][tap][ci][co] slabs.
 // UP = 2 (8 padded output channels, gradient stride 8): the tile's 16 columns are (w-parity, c_out) -- the two fine voxels
 // 2x, 2x+1 are 16 contiguous floats -- one (p_d, p_h) parity per block, 2 x 2 x 3 taps (12 MFMAs per K-step instead of 2 x 8).
-template <int SM, int SN, int UP = 0>
+// LZ: lazy BatchNorm+ReLU backward (models.py:27-32's BatchNorm3d + ReLU, backward).  p.g is the gradient w.r.t. the
+// ACTIVATED output; the raw-output gradient  gy = [y sc + sh > 0] k0 g + (A y + B)  (bn_bwd_finalize_kernel's k0, A, B) is
+// formed while the gradient box is written to LDS -- and stored to p.lz_out for the data-gradient kernel that follows --
+// so the separate apply pass over the layer (read g, read y, write g) disappears.  Every staged item stores the value of the
+// address it fetched (volume-face items fetch the box origin and store that voxel's value again; blocks that share a
+// gradient tile store identical values), so the stores need no predicate.  Full boxes and channel tiles only (host check).
+template <int SM, int SN, int UP = 0, bool LZ = false>
 __global__ __launch_bounds__(256, CTU_K3S_OCC) void conv3d_wgrad_k3s_kernel(WgP p, int tiles_per_block) {
     static_assert(!UP || (SM == 1 && SN == 1), "the fused up-convolution uses the full 16 x 16 channel tile");
     // box: 4 x 4 x 16 voxels; 4 x 4 x 8 for the full 16 x 16 channel tile, whose 27 accumulators leave fewer staging registers
@@ -1329,6 +1390,20 @@ __global__ __launch_bounds__(256, CTU_K3S_OCC) void conv3d_wgrad_k3s_kernel(WgP 
     int tile = blockIdx.x * tiles_per_block;
     const int tile_end = min(p.ntiles, tile + tiles_per_block);
     float4 va[AITER], vg[GITER];
+    // LZ: this thread's channel quad of the BatchNorm-backward vectors (a quad beyond the tensor aliases quad 0, whose
+    // address it fetches and stores), and the raw outputs fetched beside the gradient items
+    float4 vy[LZ ? GITER : 1];
+    float4 l_sc = make_float4(0.f, 0.f, 0.f, 0.f), l_sh = l_sc, l_k0 = l_sc, l_A = l_sc, l_B = l_sc;
+    if constexpr (LZ) {
+        const int lzc = (co0 + ((UP && !g_ok) ? 0 : gq * 4)) % p.lz_cp;
+        l_sc = *reinterpret_cast<const float4*>(p.lz_scale + lzc);
+        l_sh = *reinterpret_cast<const float4*>(p.lz_shift + lzc);
+        l_k0 = *reinterpret_cast<const float4*>(p.lz_coef + lzc);
+        l_A = *reinterpret_cast<const float4*>(p.lz_coef + 3 * p.lz_cp + lzc);
+        l_B = *reinterpret_cast<const float4*>(p.lz_coef + 4 * p.lz_cp + lzc);
+    }
+    const long long lz_ydelta = LZ ? reinterpret_cast<const char*>(p.lz_y) - reinterpret_cast<const char*>(p.g) : 0;
+    const long long lz_odelta = LZ ? reinterpret_cast<const char*>(p.lz_out) - reinterpret_cast<const char*>(p.g) : 0;
 
     // staging items: BYTE offsets relative to the box's halo origin (non-negative, so the loads take the
     // scalar-base + 32-bit-offset addressing form and cost no VALU address arithmetic)
@@ -1407,7 +1482,9 @@ __global__ __launch_bounds__(256, CTU_K3S_OCC) void conv3d_wgrad_k3s_kernel(WgP 
     };
     auto fetch_g = [&](int it) {
         const bool ok = !((pf_bface & 16u) && ((gw0 >> it) & 1u)) && (!UP || g_ok);
-        vg[it] = *reinterpret_cast<const float4*>(pf_gbase + (ok ? goff[it] : safe_g));
+        const unsigned off = ok ? goff[it] : safe_g;
+        vg[it] = *reinterpret_cast<const float4*>(pf_gbase + off);
+        if constexpr (LZ) vy[it] = *reinterpret_cast<const float4*>(pf_gbase + lz_ydelta + off);
         gmask |= ok ? (1u << it) : 0u;
     };
     auto load_ragged = [&](Box b) {                // per-item bounds checks (volume not a multiple of the box, channel tails)
@@ -1455,8 +1532,14 @@ __global__ __launch_bounds__(256, CTU_K3S_OCC) void conv3d_wgrad_k3s_kernel(WgP 
     };
     auto put_g = [&](int it, int st) {
         const bool ok = (gmask >> it) & 1u;
+        float4 t = vg[it];
+        if constexpr (LZ) {
+            t = bn_bwd_lazy4(vg[it], vy[it], l_sc, l_sh, l_k0, l_A, l_B);
+            // (pf_gbase still describes the box these registers were fetched from: prep() runs once per loop pass)
+            *reinterpret_cast<float4*>(const_cast<char*>(pf_gbase) + lz_odelta + (ok ? goff[it] : safe_g)) = t;
+        }
         *reinterpret_cast<float4*>(&sG[st * SGF + (tid + it * 256) * 4]) =
-            make_float4(ok ? vg[it].x : 0.f, ok ? vg[it].y : 0.f, ok ? vg[it].z : 0.f, ok ? vg[it].w : 0.f);
+            make_float4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f);
     };
 
     // One box: NKS K-steps of 4 voxels per wave (plane td = wave, row th = ks / KPR, columns (ks % KPR) * 4 + kq).
@@ -1470,7 +1553,7 @@ __global__ __launch_bounds__(256, CTU_K3S_OCC) void conv3d_wgrad_k3s_kernel(WgP 
         constexpr bool FETCH = decltype(fetch_tag)::value;
         constexpr int R = 12, NJ = NKS * NMF;
         constexpr int KW0 = NKS / 2, NIT = AITER + GITER;
-        constexpr int IPF = (NIT + KW0 - 1) / KW0, IPK = (NIT + (NKS - KW0) - 1) / (NKS - KW0);
+        constexpr int IPF = (NIT + KW0 - 1) / KW0;
         lds_f_ptr cA = vA + cur * SAF;
         lds_f_ptr cG = vG + cur * SGF;
         float ar[R], br[2];
@@ -1501,9 +1584,13 @@ __global__ __launch_bounds__(256, CTU_K3S_OCC) void conv3d_wgrad_k3s_kernel(WgP 
                 const int j = ks * NMF + t;
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[j % R], br[ks & 1], acc[t], 0, 0, 0);
                 if (j + R < NJ) ar[j % R] = a_read(j + R);
-                // pin the order: MFMA, then the refill of the slot it consumed
+                // pin the order: MFMA, then the refill of the slot it consumed (and, in the K-steps that also transform and
+                // write staged items, a few of their VALU instructions in the MFMA's shadow instead of one block at the end)
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 if (j + R < NJ) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#if CTU_PIN_VALU
+                if (ks >= KW0) __builtin_amdgcn_sched_group_barrier(0x002, CTU_PIN_VALU, 0);
+#endif
             }
             if (FETCH && ks < KW0) {
 #pragma unroll
@@ -1514,11 +1601,12 @@ __global__ __launch_bounds__(256, CTU_K3S_OCC) void conv3d_wgrad_k3s_kernel(WgP 
                 }
             }
             if (ks >= KW0) {
+                // the NIT staged items spread evenly over the NKS - KW0 K-steps (gradient items, the costlier ones with LZ, first)
+                constexpr int NK2 = NKS - KW0;
 #pragma unroll
-                for (int q = 0; q < IPK; ++q) {
-                    const int it = (ks - KW0) * IPK + q;
-                    if (it < AITER) put_a(it, cur ^ 1);
-                    else if (it < NIT) put_g(it - AITER, cur ^ 1);
+                for (int it = (ks - KW0) * NIT / NK2; it < (ks - KW0 + 1) * NIT / NK2; ++it) {
+                    if (it < GITER) put_g(it, cur ^ 1);
+                    else put_a(it - GITER, cur ^ 1);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -1642,13 +1730,21 @@ static K3sGeom k3s_geom(int N, int D, int H, int W, int cin_p, int cout_p) {
     return g;
 }
 
+// lazy BatchNorm backward inside the k = 3 weight-gradient kernel: full boxes and full channel tiles only
+static bool k3s_lazy_ok(int D, int H, int W, int k, int cin_p, int cout_p) {
+    if (!use_k3s(k, W, cin_p, cout_p)) return false;
+    const int sm = cin_p == 8 ? 2 : 1, sn = cout_p == 8 ? 2 : 1, tw = (sm == 2 && sn == 2) ? 16 : 8;
+    return D % 4 == 0 && H % 4 == 0 && W % tw == 0 && cin_p % (16 / sm) == 0 && cout_p % (16 / sn) == 0;
+}
+
 template <int SM, int SN>
 static int launch_wgrad_k3s(WgP p, float* dw, int Co, int Ci, const int32_t* cinv, hipStream_t st) {
     const K3sGeom g = k3s_geom(p.N, p.D, p.H, p.W, p.cin_p, p.cout_p);
     p.tiles_d = ceil_div(p.D, 4); p.tiles_h = ceil_div(p.H, 4); p.tiles_w = ceil_div(p.W, g.tw);
     p.ntiles = g.ntiles;
     p.n_ci_t = g.n_ci_g;
-    conv3d_wgrad_k3s_kernel<SM, SN><<<dim3(g.gx, g.pairs), 256, 0, st>>>(p, g.tpb);
+    if (p.lz_y) conv3d_wgrad_k3s_kernel<SM, SN, 0, true><<<dim3(g.gx, g.pairs), 256, 0, st>>>(p, g.tpb);
+    else conv3d_wgrad_k3s_kernel<SM, SN><<<dim3(g.gx, g.pairs), 256, 0, st>>>(p, g.tpb);
     CTU_CHECK_LAUNCH("conv3d_wgrad_k3s");
     conv3d_wgrad_k3s_reduce_kernel<SM, SN><<<dim3(ceil_div(g.nmf * 256, 64), g.pairs), 64 * RPARTS, 0, st>>>(
         p.ws, dw, Co, Ci, cinv, p.cin_p, p.n_ci_t, g.gx);
@@ -1862,7 +1958,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_k5s_kernel(WgP p, int til
         constexpr bool FETCH = decltype(fetch_tag)::value;
         constexpr int R = 12, NJ = NKS * NMF;
         constexpr int KW0 = NKS / 2, NIT = AITER + GITER;
-        constexpr int IPF = (NIT + KW0 - 1) / KW0, IPK = (NIT + (NKS - KW0) - 1) / (NKS - KW0);
+        constexpr int IPF = (NIT + KW0 - 1) / KW0;
         lds_f_ptr cA = vA + cur * SAF;
         lds_f_ptr cG = vG + cur * SGF;
         float ar[R], br[2];
@@ -1894,9 +1990,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_k5s_kernel(WgP p, int til
                 const int j = ks * NMF + t;
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[j % R], br[ks & 1], acc[t], 0, 0, 0);
                 if (j + R < NJ) ar[j % R] = a_read(j + R);
-                // pin the order: MFMA, then the refill of the slot it consumed
+                // pin the order: MFMA, then the refill of the slot it consumed (and, in the K-steps that also transform and
+                // write staged items, a few of their VALU instructions in the MFMA's shadow instead of one block at the end)
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 if (j + R < NJ) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#if CTU_PIN_VALU
+                if (ks >= KW0) __builtin_amdgcn_sched_group_barrier(0x002, CTU_PIN_VALU, 0);
+#endif
             }
             if (FETCH && ks < KW0) {
 #pragma unroll
@@ -1907,11 +2007,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_k5s_kernel(WgP p, int til
                 }
             }
             if (ks >= KW0) {
+                // the NIT staged items spread evenly over the NKS - KW0 K-steps (gradient items, the costlier ones with LZ, first)
+                constexpr int NK2 = NKS - KW0;
 #pragma unroll
-                for (int q = 0; q < IPK; ++q) {
-                    const int it = (ks - KW0) * IPK + q;
-                    if (it < AITER) put_a(it, cur ^ 1);
-                    else if (it < NIT) put_g(it - AITER, cur ^ 1);
+                for (int it = (ks - KW0) * NIT / NK2; it < (ks - KW0 + 1) * NIT / NK2; ++it) {
+                    if (it < GITER) put_g(it, cur ^ 1);
+                    else put_a(it - GITER, cur ^ 1);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -2184,7 +2285,7 @@ extern "C" int ctu_conv3d_num_blocks(int N, int D, int H, int W, int k, int nout
         return gx;
     }
     if (use_persist(k, nt, tw)) {
-        persist_grid(ntiles, ceil_div(ceil_div(nout_p, 16), nt), nt == 1 ? 3 : 2, &gx, &tpb);
+        persist_grid(ntiles, ceil_div(ceil_div(nout_p, 16), nt), nt == 1 ? CTU_FWD_OCC1 : 2, &gx, &tpb);
         return gx;
     }
     return ntiles;
@@ -2327,7 +2428,7 @@ extern "C" int ctu_conv3d_fwd(const float* in, int in_cs, int rin_p, const float
         const int ntiles = N * p.tiles_d * p.tiles_h * p.tiles_w;
         const int ny = ceil_div(p.n16, NT);
         int gx, tpb;
-        persist_grid(ntiles, ny, NT == 1 ? 3 : 2, &gx, &tpb);
+        persist_grid(ntiles, ny, NT == 1 ? CTU_FWD_OCC1 : 2, &gx, &tpb);
         if (NT == 1) conv3d_fwd_k3_persist<1, false><<<dim3(gx, ny), 256, 0, st>>>(p, ntiles, tpb);
         else conv3d_fwd_k3_persist<2, false><<<dim3(gx, ny), 256, 0, st>>>(p, ntiles, tpb);
         CTU_CHECK_LAUNCH("conv3d_fwd_k3_persist");
@@ -2392,10 +2493,42 @@ static int launch_wgrad(WgP p, float* dw, int Co, int Ci, const int32_t* cinv, i
     return CTU_OK;
 }
 
+struct LazyBn { const float* y; const float* scale; const float* shift; const float* coef; float* out; int cp; };
+
+static int conv3d_wgrad_impl(const float* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
+                             int in_relu, const float* gout, int g_cs, int cout_p, float* dw, float* dbias, int Co,
+                             int Ci, const int32_t* cinv, float* ws, int N, int D, int H, int W, int k, const LazyBn* lz,
+                             void* stream);
+
 extern "C" int ctu_conv3d_wgrad(const float* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
                                 int in_relu, const float* gout, int g_cs, int cout_p, float* dw, float* dbias, int Co,
                                 int Ci, const int32_t* cinv, float* ws, int N, int D, int H, int W, int k,
                                 void* stream) {
+    return conv3d_wgrad_impl(in, in_cs, cin_p, in_scale, in_shift, in_relu, gout, g_cs, cout_p, dw, dbias, Co, Ci, cinv, ws,
+                             N, D, H, W, k, nullptr, stream);
+}
+
+extern "C" int ctu_conv3d_wgrad_bn_supported(int N, int D, int H, int W, int k, int cin_p, int cout_p) {
+    return (N > 0 && k3s_lazy_ok(D, H, W, k, cin_p, cout_p)) ? 1 : 0;
+}
+
+extern "C" int ctu_conv3d_wgrad_bn(const float* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
+                                   int in_relu, const float* ga, int g_cs, int cout_p, const float* y,
+                                   const float* bn_scale, const float* bn_shift, const float* coef, float* gy_out,
+                                   float* dw, int Co, int Ci, const int32_t* cinv, float* ws, int N, int D, int H, int W,
+                                   int k, void* stream) {
+    CTU_REQUIRE(y && bn_scale && bn_shift && coef && gy_out, "conv3d_wgrad_bn: null pointer");
+    CTU_REQUIRE(k3s_lazy_ok(D, H, W, k, cin_p, cout_p), "conv3d_wgrad_bn: geometry not supported (ask ctu_conv3d_wgrad_bn_supported)");
+    CTU_REQUIRE(((uintptr_t)y & 15) == 0 && ((uintptr_t)gy_out & 15) == 0 && gy_out != ga, "conv3d_wgrad_bn: y / gy_out alignment, gy_out must not alias ga");
+    const LazyBn lz = {y, bn_scale, bn_shift, coef, gy_out, cout_p};
+    return conv3d_wgrad_impl(in, in_cs, cin_p, in_scale, in_shift, in_relu, ga, g_cs, cout_p, dw, nullptr, Co, Ci, cinv, ws,
+                             N, D, H, W, k, &lz, stream);
+}
+
+static int conv3d_wgrad_impl(const float* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
+                             int in_relu, const float* gout, int g_cs, int cout_p, float* dw, float* dbias, int Co,
+                             int Ci, const int32_t* cinv, float* ws, int N, int D, int H, int W, int k, const LazyBn* lz,
+                             void* stream) {
     CTU_REQUIRE(k == 3 || k == 5, "conv3d_wgrad: k=%d unsupported (3 or 5)", k);
     CTU_REQUIRE(in && gout && dw && ws, "conv3d_wgrad: null pointer");
     CTU_REQUIRE(cin_p % 8 == 0 && cout_p % 8 == 0 && cin_p > 0 && cout_p > 0, "conv3d_wgrad: padded channels");
@@ -2407,6 +2540,8 @@ extern "C" int ctu_conv3d_wgrad(const float* in, int in_cs, int cin_p, const flo
     p.in = in; p.in_scale = in_scale; p.in_shift = in_shift; p.g = gout; p.ws = ws;
     p.in_cs = in_cs; p.cin_p = cin_p; p.in_relu = in_relu; p.g_cs = g_cs; p.cout_p = cout_p;
     p.N = N; p.D = D; p.H = H; p.W = W;
+    p.lz_y = nullptr; p.lz_out = nullptr; p.lz_scale = nullptr; p.lz_shift = nullptr; p.lz_coef = nullptr; p.lz_cp = 0;
+    if (lz) { p.lz_y = lz->y; p.lz_out = lz->out; p.lz_scale = lz->scale; p.lz_shift = lz->shift; p.lz_coef = lz->coef; p.lz_cp = lz->cp; }
     int gz, gx, bt;
     wgrad_geom(N, D, H, W, k, cin_p, cout_p, &p.ntiles, &p.n_ci_t, &p.n_co_t, &gz, &gx, &bt);
     if (use_k3s(k, W, cin_p, cout_p)) {
@@ -2445,9 +2580,36 @@ extern "C" size_t ctu_upconv_fused_wgrad_ws_floats(int N, int D, int H, int W, i
     return na > nb ? na : nb;                            // either tiling (the w-parity tile needs nout_p = 8 = g_cs)
 }
 
+static int upconv_fused_wgrad_impl(const float* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
+                                   int in_relu, const float* gout, int g_cs, int nout_p, float* dweff, float* ws,
+                                   int N, int D, int H, int W, const LazyBn* lz, void* stream);
+
 extern "C" int ctu_upconv_fused_wgrad(const float* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
                                       int in_relu, const float* gout, int g_cs, int nout_p, float* dweff, float* ws,
                                       int N, int D, int H, int W, void* stream) {
+    return upconv_fused_wgrad_impl(in, in_cs, cin_p, in_scale, in_shift, in_relu, gout, g_cs, nout_p, dweff, ws, N, D, H, W,
+                                   nullptr, stream);
+}
+
+// full coarse boxes (4 x 4 x 8) and full 16-channel input tiles
+extern "C" int ctu_upconv_fused_wgrad_bn_supported(int N, int D, int H, int W, int cin_p, int nout_p) {
+    return (N > 0 && D % 4 == 0 && H % 4 == 0 && W % 8 == 0 && cin_p % 16 == 0 && nout_p % 8 == 0) ? 1 : 0;
+}
+
+extern "C" int ctu_upconv_fused_wgrad_bn(const float* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
+                                         int in_relu, const float* ga, int g_cs, int nout_p, const float* y,
+                                         const float* bn_scale, const float* bn_shift, const float* coef, float* gy_out,
+                                         float* dweff, float* ws, int N, int D, int H, int W, void* stream) {
+    CTU_REQUIRE(y && bn_scale && bn_shift && coef && gy_out, "upconv_fused_wgrad_bn: null pointer");
+    CTU_REQUIRE(ctu_upconv_fused_wgrad_bn_supported(N, D, H, W, cin_p, nout_p), "upconv_fused_wgrad_bn: geometry not supported");
+    CTU_REQUIRE(((uintptr_t)y & 15) == 0 && ((uintptr_t)gy_out & 15) == 0 && gy_out != ga, "upconv_fused_wgrad_bn: y / gy_out alignment, gy_out must not alias ga");
+    const LazyBn lz = {y, bn_scale, bn_shift, coef, gy_out, nout_p};
+    return upconv_fused_wgrad_impl(in, in_cs, cin_p, in_scale, in_shift, in_relu, ga, g_cs, nout_p, dweff, ws, N, D, H, W, &lz, stream);
+}
+
+static int upconv_fused_wgrad_impl(const float* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
+                                   int in_relu, const float* gout, int g_cs, int nout_p, float* dweff, float* ws,
+                                   int N, int D, int H, int W, const LazyBn* lz, void* stream) {
     CTU_REQUIRE(in && gout && dweff && ws, "upconv_fused_wgrad: null pointer");
     CTU_REQUIRE(cin_p % 8 == 0 && nout_p % 8 == 0 && cin_p > 0 && nout_p > 0 && nout_p <= 64, "upconv_fused_wgrad: padded channels");
     CTU_REQUIRE(in_cs >= cin_p && in_cs % 4 == 0 && g_cs >= nout_p && g_cs % 4 == 0, "upconv_fused_wgrad: bad stride");
@@ -2464,15 +2626,19 @@ extern "C" int ctu_upconv_fused_wgrad(const float* in, int in_cs, int cin_p, con
     p.N = N; p.D = D; p.H = H; p.W = W;
     p.tiles_d = ceil_div(D, 4); p.tiles_h = ceil_div(H, 4); p.tiles_w = ceil_div(W, 8);
     p.ntiles = g.ntiles; p.n_ci_t = g.n_ci_g; p.n_co_t = g.n_co_g;
+    p.lz_y = nullptr; p.lz_out = nullptr; p.lz_scale = nullptr; p.lz_shift = nullptr; p.lz_coef = nullptr; p.lz_cp = 0;
+    if (lz) { p.lz_y = lz->y; p.lz_out = lz->out; p.lz_scale = lz->scale; p.lz_shift = lz->shift; p.lz_coef = lz->coef; p.lz_cp = lz->cp; }
     if (pw) {
         p.cout_p = 16;                                   // all 4 channel quads of the (w-parity, c_out) tile are real
-        conv3d_wgrad_k3s_kernel<1, 1, 2><<<dim3(g.gx, g.pairs), 256, 0, st>>>(p, g.tpb);
+        if (lz) conv3d_wgrad_k3s_kernel<1, 1, 2, true><<<dim3(g.gx, g.pairs), 256, 0, st>>>(p, g.tpb);
+        else conv3d_wgrad_k3s_kernel<1, 1, 2><<<dim3(g.gx, g.pairs), 256, 0, st>>>(p, g.tpb);
         CTU_CHECK_LAUNCH("upconv_fused_wgrad(pw)");
         upconv_wgrad_reduce_pw_kernel<<<dim3(12 * 256 / 64, g.pairs), 64 * RPARTS, 0, st>>>(ws, dweff, cin_p, g.n_ci_g, g.gx);
         CTU_CHECK_LAUNCH("upconv_fused_wgrad_reduce(pw)");
         return CTU_OK;
     }
-    conv3d_wgrad_k3s_kernel<1, 1, 1><<<dim3(g.gx, g.pairs), 256, 0, st>>>(p, g.tpb);
+    if (lz) conv3d_wgrad_k3s_kernel<1, 1, 1, true><<<dim3(g.gx, g.pairs), 256, 0, st>>>(p, g.tpb);
+    else conv3d_wgrad_k3s_kernel<1, 1, 1><<<dim3(g.gx, g.pairs), 256, 0, st>>>(p, g.tpb);
     CTU_CHECK_LAUNCH("upconv_fused_wgrad");
     upconv_wgrad_reduce_kernel<<<dim3(8 * 256 / 64, g.pairs), 64 * RPARTS, 0, st>>>(ws, dweff, cin_p, nout_p, g.n_ci_g, g.n_co_g, g.gx);
     CTU_CHECK_LAUNCH("upconv_fused_wgrad_reduce");

@@ -8,6 +8,7 @@
 //   input gradient .. direct VALU convolution of the 8-channel gradient with the flipped weights, writes NCDHW planes
 //   weight gradient . MFMA with M = (tap, c_in) (27*C_in rows, padded to 32/64), N = c_out, K = voxels
 // All three are persistent over 4x4x32 / 4x4x16 voxel boxes with the box staged in LDS.
+#include <type_traits>
 #include "common.h"
 #include "bn_tail.h"
 
@@ -24,6 +25,14 @@ struct FirstP {
     int g_cs, out_cs, Co, nbias;
     int N, D, H, W;
     int tiles_d, tiles_h, tiles_w, ntiles;
+    // lazy BatchNorm + ReLU backward in first_wgrad_kernel<.., LZ = true> (as conv3d_wgrad_k3s_kernel's, conv3d.hip): g is the
+    // gradient w.r.t. the ACTIVATED output, lz_y the raw output (geometry and stride of g), lz_coef bn_bwd_finalize's
+    // [5][8] rows; the raw-output gradient goes to lz_out (geometry of g) for first_bwd_data_kernel
+    const float* lz_y;
+    float* lz_out;
+    const float* lz_scale;
+    const float* lz_shift;
+    const float* lz_coef;
 };
 
 constexpr int TD = 4, TH = 4;
@@ -136,7 +145,7 @@ __global__ __launch_bounds__(256) void first_fwd_kernel(FirstP p, int tiles_per_
             if (m == 0 && kq < 2) { sRed[wave * 16 + cq + r] = a1; sRed[wave * 16 + 8 + cq + r] = a2; }
         }
         __syncthreads();
-        if (tid < 16) st_sc1(p.stats + (size_t)blockIdx.x * 16 + tid, (sRed[tid] + sRed[16 + tid]) + (sRed[32 + tid] + sRed[48 + tid]));
+        if (tid < 16) st_row(tail.counter != nullptr, p.stats + (size_t)blockIdx.x * 16 + tid, (sRed[tid] + sRed[16 + tid]) + (sRed[32 + tid] + sRed[48 + tid]));
         if (tail.counter) bn_fwd_tail(tail, p.stats, gridDim.x, 8, gridDim.x);
     }
 }
@@ -235,7 +244,7 @@ __global__ __launch_bounds__(256) void first_bwd_data_kernel(FirstP p, int tiles
 }
 
 // ------------------------------------------------------------------ weight gradient: M = (tap, ci), N = co, K = voxels
-template <int CIN, class T>
+template <int CIN, class T, bool LZ = false>
 __global__ __launch_bounds__(256) void first_wgrad_kernel(FirstP p, int tiles_per_block) {
     constexpr int TW = 32, HD = TD + 2, HH = TH + 2, HW = TW + 2, HV = HD * HH * HW, NV = TD * TH * TW;
     constexpr int MTN = (27 * CIN + 15) / 16;                  // M tiles
@@ -264,6 +273,15 @@ __global__ __launch_bounds__(256) void first_wgrad_kernel(FirstP p, int tiles_pe
     const int half = tid & 1;
     float vx[NIT];
     float4 vg[GIT];
+    float4 vy[LZ ? GIT : 1];
+    float4 l_sc = make_float4(0.f, 0.f, 0.f, 0.f), l_sh = l_sc, l_k0 = l_sc, l_A = l_sc, l_B = l_sc;
+    if constexpr (LZ) {
+        l_sc = *reinterpret_cast<const float4*>(p.lz_scale + half * 4);
+        l_sh = *reinterpret_cast<const float4*>(p.lz_shift + half * 4);
+        l_k0 = *reinterpret_cast<const float4*>(p.lz_coef + half * 4);
+        l_A = *reinterpret_cast<const float4*>(p.lz_coef + 24 + half * 4);
+        l_B = *reinterpret_cast<const float4*>(p.lz_coef + 32 + half * 4);
+    }
     auto load = [&](int t) {
         int n, d0, h0, w0;
         box_origin(p, t, TW, n, d0, h0, w0);
@@ -284,8 +302,11 @@ __global__ __launch_bounds__(256) void first_wgrad_kernel(FirstP p, int tiles_pe
             const int tw_ = v % TW, th_ = (v / TW) % TH, td_ = v / (TW * TH);
             const int gd = d0 + td_, gh = h0 + th_, gw = w0 + tw_;
             float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gd < p.D && gh < p.H && gw < p.W)
-                val = ld4<T>(reinterpret_cast<const T*>(p.g) + ((((size_t)n * p.D + gd) * p.H + gh) * p.W + gw) * p.g_cs + half * 4);
+            if (gd < p.D && gh < p.H && gw < p.W) {
+                const size_t idx = ((((size_t)n * p.D + gd) * p.H + gh) * p.W + gw) * p.g_cs + half * 4;
+                val = ld4<T>(reinterpret_cast<const T*>(p.g) + idx);
+                if constexpr (LZ) vy[it] = *reinterpret_cast<const float4*>(p.lz_y + idx);
+            }
             vg[it] = val;
         }
     };
@@ -296,6 +317,21 @@ __global__ __launch_bounds__(256) void first_wgrad_kernel(FirstP p, int tiles_pe
         for (int it = 0; it < NIT; ++it) {
             const int e = tid + it * 256;
             if (e < HV * CIN) sX[e] = vx[it];
+        }
+        if constexpr (LZ) {
+            // the registers hold box `tile`: form its raw-output gradient (out-of-volume items stay 0) and write it out
+            int n, d0, h0, w0;
+            box_origin(p, tile, TW, n, d0, h0, w0);
+#pragma unroll
+            for (int it = 0; it < GIT; ++it) {
+                const int e = tid + it * 256, v = e >> 1;
+                const int tw_ = v % TW, th_ = (v / TW) % TH, td_ = v / (TW * TH);
+                const int gd = d0 + td_, gh = h0 + th_, gw = w0 + tw_;
+                if (gd < p.D && gh < p.H && gw < p.W) {
+                    vg[it] = bn_bwd_lazy4(vg[it], vy[it], l_sc, l_sh, l_k0, l_A, l_B);
+                    *reinterpret_cast<float4*>(p.lz_out + ((((size_t)n * p.D + gd) * p.H + gh) * p.W + gw) * p.g_cs + half * 4) = vg[it];
+                }
+            }
         }
 #pragma unroll
         for (int it = 0; it < GIT; ++it) {
@@ -424,22 +460,31 @@ int first_bwd_data_impl(const T* g, int g_cs, const float* w, int cin, int Co, f
     return CTU_OK;
 }
 
+struct FirstLazy { const float* y; const float* scale; const float* shift; const float* coef; float* out; };
+
 template <class T>
 int first_wgrad_impl(const float* x, int cin, const T* g, int g_cs, float* dw, int Co, float* ws, int N, int D, int H, int W,
-                     void* stream) {
+                     const FirstLazy* lz, void* stream) {
     CTU_REQUIRE(x && g && dw && ws, "conv3d_first_wgrad: null pointer");
     CTU_REQUIRE((cin == 1 || cin == 2) && Co >= 1 && Co <= 8 && g_cs >= 8 && g_cs % 4 == 0 && ((uintptr_t)g & (4 * sizeof(T) - 1)) == 0,
                 "conv3d_first_wgrad: bad argument");
     FirstP p{};
     p.x = x; p.g = g; p.g_cs = g_cs; p.ws = ws; p.Co = Co;
+    if (lz) { p.lz_y = lz->y; p.lz_out = lz->out; p.lz_scale = lz->scale; p.lz_shift = lz->shift; p.lz_coef = lz->coef; }
     int gx, tpb;
     grid_for(fill(p, N, D, H, W, 32), 5, &gx, &tpb);
     hipStream_t st = (hipStream_t)stream;
     if (cin == 1) {
-        first_wgrad_kernel<1, T><<<gx, 256, 0, st>>>(p, tpb);
+        if constexpr (std::is_same<T, float>::value) {
+            if (lz) first_wgrad_kernel<1, T, true><<<gx, 256, 0, st>>>(p, tpb);
+            else first_wgrad_kernel<1, T><<<gx, 256, 0, st>>>(p, tpb);
+        } else first_wgrad_kernel<1, T><<<gx, 256, 0, st>>>(p, tpb);
         first_wgrad_reduce_kernel<1><<<ceil_div(2 * 256, 64), 1024, 0, st>>>(ws, dw, Co, gx);
     } else {
-        first_wgrad_kernel<2, T><<<gx, 256, 0, st>>>(p, tpb);
+        if constexpr (std::is_same<T, float>::value) {
+            if (lz) first_wgrad_kernel<2, T, true><<<gx, 256, 0, st>>>(p, tpb);
+            else first_wgrad_kernel<2, T><<<gx, 256, 0, st>>>(p, tpb);
+        } else first_wgrad_kernel<2, T><<<gx, 256, 0, st>>>(p, tpb);
         first_wgrad_reduce_kernel<2><<<ceil_div(4 * 256, 64), 1024, 0, st>>>(ws, dw, Co, gx);
     }
     CTU_CHECK_LAUNCH("conv3d_first_wgrad");
@@ -475,9 +520,17 @@ extern "C" size_t ctu_conv3d_first_wgrad_ws_floats(int N, int D, int H, int W, i
 
 extern "C" int ctu_conv3d_first_wgrad(const float* x, int cin, const float* g, int g_cs, float* dw, int Co, float* ws, int N,
                                       int D, int H, int W, void* stream) {
-    return first_wgrad_impl<float>(x, cin, g, g_cs, dw, Co, ws, N, D, H, W, stream);
+    return first_wgrad_impl<float>(x, cin, g, g_cs, dw, Co, ws, N, D, H, W, nullptr, stream);
+}
+extern "C" int ctu_conv3d_first_wgrad_bn(const float* x, int cin, const float* ga, int g_cs, const float* y, const float* bn_scale,
+                                         const float* bn_shift, const float* coef, float* gy_out, float* dw, int Co, float* ws,
+                                         int N, int D, int H, int W, void* stream) {
+    CTU_REQUIRE(y && bn_scale && bn_shift && coef && gy_out && gy_out != ga, "conv3d_first_wgrad_bn: null pointer / gy_out aliases ga");
+    CTU_REQUIRE(((uintptr_t)y & 15) == 0 && ((uintptr_t)gy_out & 15) == 0, "conv3d_first_wgrad_bn: 16-byte alignment");
+    const FirstLazy lz = {y, bn_scale, bn_shift, coef, gy_out};
+    return first_wgrad_impl<float>(x, cin, ga, g_cs, dw, Co, ws, N, D, H, W, &lz, stream);
 }
 extern "C" int ctu_lp_conv3d_first_wgrad(int dtype, const float* x, int cin, const void* g, int g_cs, float* dw, int Co, float* ws,
                                          int N, int D, int H, int W, void* stream) {
-    CTU_DISPATCH_LP(dtype, return first_wgrad_impl<T>(x, cin, (const T*)g, g_cs, dw, Co, ws, N, D, H, W, stream));
+    CTU_DISPATCH_LP(dtype, return first_wgrad_impl<T>(x, cin, (const T*)g, g_cs, dw, Co, ws, N, D, H, W, nullptr, stream));
 }

@@ -450,7 +450,7 @@ __global__ __launch_bounds__(256) void lp_conv_fwd_kernel(LpConvP p) {
                 float s = 0.f;
 #pragma unroll
                 for (int wv = 0; wv < 4; ++wv) s += sRed[((wv * NT + nt) * 2 + which) * 16 + c];
-                st_sc1(p.stats + (size_t)blockIdx.x * 2 * p.nout_p + which * p.nout_p + ch, s);
+                st_row(p.tail.counter != nullptr, p.stats + (size_t)blockIdx.x * 2 * p.nout_p + which * p.nout_p + ch, s);
             }
         }
         if (p.tail.counter) bn_fwd_tail(p.tail, p.stats, gridDim.x, p.nout_p, gridDim.x * gridDim.y);
@@ -657,7 +657,7 @@ __global__ __launch_bounds__(256) void lp_conv_fwd_small_kernel(LpConvP p) {
                 float sx = 0.f;
 #pragma unroll
                 for (int wv = 0; wv < 4; ++wv) sx += sRed[((wv * NT + nt) * 2 + which) * 16 + c];
-                st_sc1(p.stats + (size_t)blockIdx.x * 2 * p.nout_p + which * p.nout_p + ch, sx);
+                st_row(p.tail.counter != nullptr, p.stats + (size_t)blockIdx.x * 2 * p.nout_p + which * p.nout_p + ch, sx);
             }
         }
         if (p.tail.counter) bn_fwd_tail(p.tail, p.stats, gridDim.x, p.nout_p, gridDim.x * gridDim.y);
@@ -943,7 +943,7 @@ __global__ __launch_bounds__(256) void lp_conv_fwd_p1_kernel(LpConvP p, int ntil
                 float sx = 0.f;
 #pragma unroll
                 for (int wv = 0; wv < 4; ++wv) sx += sRed[((wv * NT + nt) * 2 + which) * 16 + c];
-                st_sc1(p.stats + (size_t)blockIdx.x * 2 * p.nout_p + which * p.nout_p + ch, sx);
+                st_row(p.tail.counter != nullptr, p.stats + (size_t)blockIdx.x * 2 * p.nout_p + which * p.nout_p + ch, sx);
             }
         }
         if (p.tail.counter) bn_fwd_tail(p.tail, p.stats, gridDim.x, p.nout_p, gridDim.x * gridDim.y);

@@ -175,13 +175,15 @@ __global__ void bn_relu_bwd_reduce_kernel(const T* __restrict__ y, int y_cs, con
             s1 += red[(l * nq + q) * 8 + j];
             s2 += red[(l * nq + q) * 8 + 4 + j];
         }
-        st_sc1(partials + (size_t)blockIdx.x * 2 * cp + c, s1);
-        st_sc1(partials + (size_t)blockIdx.x * 2 * cp + cp + c, s2);
+        st_row(tail.counter != nullptr, partials + (size_t)blockIdx.x * 2 * cp + c, s1);
+        st_row(tail.counter != nullptr, partials + (size_t)blockIdx.x * 2 * cp + cp + c, s2);
     }
     if (tail.counter) bn_bwd_tail(tail, partials, gridDim.x, cp, gridDim.x);
 }
 
-// coef[0..cp) = gamma*invstd ; coef[cp..2cp) = dbeta/n ; coef[2cp..3cp) = dgamma/n
+// coef[0..cp) = k0 = gamma*invstd ; coef[cp..2cp) = k1 = dbeta/n ; coef[2cp..3cp) = k2 = dgamma/n ; and the same backward
+// as one affine map of the raw output (bn_bwd_lazy4, common.h): coef[3cp..4cp) = A = -k0 k2 invstd,
+// coef[4cp..5cp) = B = -k0 (k1 - k2 mean invstd)
 __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nb, int C, int cp, double count,
                                        const float* __restrict__ gamma, const float* __restrict__ invstd,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta,
@@ -192,8 +194,8 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int n
     if (nbt && rmean && c == 0 && threadIdx.x == 0) nbt[0] += 1;                      // the replayed update counts too
     float g_ = 0.f, is_ = 0.f, mu_ = 0.f, rm0 = 0.f, rv0 = 0.f;                      // (prefetched: see bn_finalize_kernel)
     if (threadIdx.x == 0 && c < C) {
-        g_ = gamma[c]; is_ = invstd[c];
-        if (rmean) { mu_ = mean[c]; rm0 = rmean[c]; rv0 = rvar[c]; }
+        g_ = gamma[c]; is_ = invstd[c]; mu_ = mean[c];
+        if (rmean) { rm0 = rmean[c]; rv0 = rvar[c]; }
     }
     double s1 = 0.0, s2 = 0.0;
     if (c < C) {
@@ -208,9 +210,12 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int n
         if (c < C) {
             dbeta[c] = (float)s1;
             dgamma[c] = (float)s2;
-            coef[c] = g_ * is_;
-            coef[cp + c] = (float)(s1 / count);
-            coef[2 * cp + c] = (float)(s2 / count);
+            const float k0 = g_ * is_, k1 = (float)(s1 / count), k2 = (float)(s2 / count);
+            coef[c] = k0;
+            coef[cp + c] = k1;
+            coef[2 * cp + c] = k2;
+            coef[3 * cp + c] = -k0 * k2 * is_;
+            coef[4 * cp + c] = -k0 * (k1 - k2 * mu_ * is_);
             if (rmean) {
                 // the running-stat update torch.utils.checkpoint's recompute repeats in backward (models.py:232-255):
                 // same batch statistics as the forward update; the biased variance is recovered from invstd
@@ -222,7 +227,7 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int n
                 rvar[c] = (1.f - momentum) * rv0 + momentum * unb;
             }
         } else {
-            coef[c] = 0.f; coef[cp + c] = 0.f; coef[2 * cp + c] = 0.f;
+            coef[c] = 0.f; coef[cp + c] = 0.f; coef[2 * cp + c] = 0.f; coef[3 * cp + c] = 0.f; coef[4 * cp + c] = 0.f;
         }
     }
 }
@@ -398,8 +403,8 @@ __global__ void maxpool2_bwd_kernel(const T* __restrict__ in, int in_cs, int cp,
                 s1 += red[(l * nq + q) * 8 + j];
                 s2 += red[(l * nq + q) * 8 + 4 + j];
             }
-            st_sc1(partials + (size_t)blockIdx.x * 2 * cp + c, s1);
-            st_sc1(partials + (size_t)blockIdx.x * 2 * cp + cp + c, s2);
+            st_row(tail.counter != nullptr, partials + (size_t)blockIdx.x * 2 * cp + c, s1);
+            st_row(tail.counter != nullptr, partials + (size_t)blockIdx.x * 2 * cp + cp + c, s2);
         }
         if (tail.counter) bn_bwd_tail(tail, partials, gridDim.x, cp, gridDim.x);
     }
@@ -695,7 +700,7 @@ extern "C" int ctu_bn_bwd_finalize(const float* partials, int nb, int C, int cp,
                                    const float* invstd, float* dgamma, float* dbeta, float* coef, const float* mean,
                                    float* running_mean, float* running_var, float momentum, float eps,
                                    long long* num_batches_tracked, void* stream) {
-    CTU_REQUIRE(partials && gamma && invstd && dgamma && dbeta && coef, "bn_bwd_finalize: null pointer");
+    CTU_REQUIRE(partials && gamma && invstd && dgamma && dbeta && coef && mean, "bn_bwd_finalize: null pointer");
     CTU_REQUIRE((running_mean == nullptr) == (running_var == nullptr) && (!running_mean || mean),
                 "bn_bwd_finalize: the running-stat replay needs mean, running_mean and running_var together");
     bn_bwd_finalize_kernel<<<cp, EW_BLOCK, 0, (hipStream_t)stream>>>(partials, nb, C, cp, count, gamma, invstd, dgamma,

@@ -183,6 +183,7 @@ __global__ __launch_bounds__(256, 2) void upconv_fused_fwd_kernel(UpP p, int nti
     load_w(0);
 
     while (true) {
+        CTU_SETPRIO(CTU_PRIO_STAGE);           // staging phases outrank the other block's MFMA stream (common.h)
         __syncthreads();
         {
             auto put = [&](int it, float4 val) {
@@ -214,6 +215,7 @@ __global__ __launch_bounds__(256, 2) void upconv_fused_fwd_kernel(UpP p, int nti
         }
         // ---- MFMAs: flat sequence of PB * 4 groups (parity pi, dz, dx); a group's 5 input rows feed the 2 dy taps of the
         // 4 M-tiles: 5 + 2*NTP fragment reads for 16*NTP MFMAs, read one group ahead
+        CTU_SETPRIO(0);
         {
             constexpr int NG = PB * 2 * NTW;
             v2f ar[2][5], br[2][2][NTP];
@@ -229,6 +231,9 @@ __global__ __launch_bounds__(256, 2) void upconv_fused_fwd_kernel(UpP p, int nti
                     for (int nt = 0; nt < NTP; ++nt) bb[dy][nt] = vW[((pi * TAPS + (dz * 2 + dy) * NTW + dx) * NTP + nt) * 64];
             };
             load_group(0, ar[0], br[0]);
+            // (the 128-accumulator variants have no registers for a second fragment set: they keep the compiler's order)
+            constexpr bool PIN = CTU_PIN_FWD && PB * NTP <= 4;
+            if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);      // the first group's reads stay out of the pinned sequence
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
                 if (g + 1 < NG) load_group(g + 1, ar[(g + 1) & 1], br[(g + 1) & 1]);
@@ -248,8 +253,18 @@ __global__ __launch_bounds__(256, 2) void upconv_fused_fwd_kernel(UpP p, int nti
                         for (int mt = 0; mt < MT; ++mt)
                             acc[pi][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bb[dy][nt].y, aa[mt + dy].y, acc[pi][mt][nt], 0, 0, 0);
                 }
+                // pin the order: the next group's fragment reads go out one per MFMA under this group's MFMAs (left alone the
+                // scheduler sinks each read to just above its first use and drains lgkmcnt(0) there)
+                if constexpr (PIN) {
+#pragma unroll
+                    for (int q = 0; q < 4 * MT * NTP; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        if (g + 1 < NG && q < 5 + 2 * NTP) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                }
             }
         }
+        CTU_SETPRIO(CTU_PRIO_STAGE);
         if (c == nchunk - 1) {
             // ---- epilogue of this coarse box: scatter its 8 * 256 fine voxels, border-class bias, BN partial sums
             const int d0 = box.tz * TD, h0 = box.ty * TH, w0 = box.tx * TW;
@@ -319,8 +334,8 @@ __global__ __launch_bounds__(256, 2) void upconv_fused_fwd_kernel(UpP p, int nti
                 a1 += sRed[(w * NTP * 16 + ch) * 2 + 0];
                 a2 += sRed[(w * NTP * 16 + ch) * 2 + 1];
             }
-            st_sc1(row + ch, a1);
-            st_sc1(row + p.nout_p + ch, a2);
+            st_row(p.tail.counter != nullptr, row + ch, a1);
+            st_row(p.tail.counter != nullptr, row + p.nout_p + ch, a2);
         }
         if (p.tail.counter) bn_fwd_tail(p.tail, p.stats, gridDim.x * gridDim.y, p.nout_p, gridDim.x * gridDim.y);
     }
@@ -472,6 +487,7 @@ __global__ __launch_bounds__(256, 2) void upconv_fused_bwd_data_kernel(UpDP p, i
     load_w(0);
 
     while (true) {
+        CTU_SETPRIO(CTU_PRIO_STAGE);           // staging phases outrank the other block's MFMA stream (common.h)
         __syncthreads();
         {
             auto put = [&](int it, float4 val) {
@@ -503,6 +519,7 @@ __global__ __launch_bounds__(256, 2) void upconv_fused_bwd_data_kernel(UpDP p, i
             load_a(nbox, nc);
             load_w(nc);
         }
+        CTU_SETPRIO(0);
         {
             v2f ar[2][5], br[2][2][NT];
             auto load_group = [&](int g, v2f (&aa)[5], v2f (&bb)[2][NT]) {
@@ -515,6 +532,9 @@ __global__ __launch_bounds__(256, 2) void upconv_fused_bwd_data_kernel(UpDP p, i
                     for (int nt = 0; nt < NT; ++nt) bb[ey][nt] = vW[(((ez * 2 + ey) * 2 + ex) * NT + nt) * 64];
             };
             load_group(0, ar[0], br[0]);
+#if CTU_PIN_FWD
+            __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 if (g + 1 < 4) load_group(g + 1, ar[(g + 1) & 1], br[(g + 1) & 1]);
@@ -533,8 +553,16 @@ __global__ __launch_bounds__(256, 2) void upconv_fused_bwd_data_kernel(UpDP p, i
                         for (int mt = 0; mt < MT; ++mt)
                             acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bb[ey][nt].y, aa[mt + ey].y, acc[mt][nt], 0, 0, 0);
                 }
+#if CTU_PIN_FWD
+#pragma unroll
+                for (int q = 0; q < 4 * MT * NT; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (g + 1 < 4 && q < 5 + 2 * NT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+#endif
             }
         }
+        CTU_SETPRIO(CTU_PRIO_STAGE);
         if (c == nchunk - 1) {
             const int d0 = box.tz * TD, h0 = box.ty * TH, w0 = box.tx * TW;
             const int gw = w0 + m;

@@ -60,12 +60,15 @@ SIGNATURES = {
     "ctu_conv3d_fwd": (I, [P, I, I, P, P, I, P, P, I, P, I, I, P, I, I, I, I, I, I, P, P]),
     "ctu_conv3d_wgrad_ws_floats": (Z, [I, I, I, I, I, I, I]),
     "ctu_conv3d_wgrad": (I, [P, I, I, P, P, I, P, I, I, P, P, I, I, P, P, I, I, I, I, I, P]),
+    "ctu_conv3d_wgrad_bn_supported": (I, [I, I, I, I, I, I, I]),
+    "ctu_conv3d_wgrad_bn": (I, [P, I, I, P, P, I, P, I, I, P, P, P, P, P, P, I, I, P, P, I, I, I, I, I, P]),
     "ctu_conv3d_first_supported": (I, [I, I, I, I]),
     "ctu_conv3d_first_num_blocks": (I, [I, I, I, I]),
     "ctu_conv3d_first_fwd": (I, [P, I, P, P, I, P, I, I, P, I, I, I, I, P, P]),
     "ctu_conv3d_first_bwd_data": (I, [P, I, P, I, I, P, I, I, I, I, P]),
     "ctu_conv3d_first_wgrad_ws_floats": (Z, [I, I, I, I, I]),
     "ctu_conv3d_first_wgrad": (I, [P, I, P, I, P, I, P, I, I, I, I, P]),
+    "ctu_conv3d_first_wgrad_bn": (I, [P, I, P, I, P, P, P, P, P, P, I, P, I, I, I, I, P]),
     "ctu_bn_finalize": (I, [P, I, I, I, D, P, P, P, P, F, F, I, P, P, P, P, P, P]),
     "ctu_bn_eval_affine": (I, [P, P, P, P, F, I, I, P, P, P]),
     "ctu_bn_bwd_num_blocks": (I, [L]),
@@ -99,6 +102,8 @@ SIGNATURES = {
     "ctu_upconv_fused_fwd": (I, [P, I, I, P, P, I, P, P, P, I, I, P, I, I, I, I, P, P]),
     "ctu_upconv_fused_wgrad_ws_floats": (Z, [I, I, I, I, I, I]),
     "ctu_upconv_fused_wgrad": (I, [P, I, I, P, P, I, P, I, I, P, P, I, I, I, I, P]),
+    "ctu_upconv_fused_wgrad_bn_supported": (I, [I, I, I, I, I, I]),
+    "ctu_upconv_fused_wgrad_bn": (I, [P, I, I, P, P, I, P, I, I, P, P, P, P, P, P, P, I, I, I, I, P]),
     "ctu_upconv_fused_project_ws_floats": (Z, [I, L]),
     "ctu_upconv_fused_project": (I, [P, P, I, I, I, I, I, I, P, P, P, I, I, I, P, P, P, P, P]),
     "ctu_upconv_fused_bwd_packed_floats": (Z, [I, I]),
@@ -151,7 +156,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 5          # CTU_ABI_VERSION of the csrc/ this file mirrors (bumped on any signature change)
+ABI_VERSION = 6          # CTU_ABI_VERSION of the csrc/ this file mirrors (bumped on any signature change)
 
 
 class CtuError(RuntimeError):

@@ -39,6 +39,9 @@ POOL_BN = os.environ.get("CTUNET_POOL_BN", "1") != "0"
 # Conv3d kernels (top level of UNet() 128^3 bf16: 720 -> ~460 us).  CTUNET_LP_FUSE_UP=0: the unfused 16-bit kernels.
 LP_FUSE_UP = os.environ.get("CTUNET_LP_FUSE_UP", "1") != "0"
 BN_MOMENTUM = 0.1
+# BatchNorm + ReLU backward applied by the weight-gradient kernel while it stages the gradient (ops.conv3d_wgrad_bn) instead
+# of a separate in-place pass over the layer (CTUNET_LAZY_BN=0: the separate ctu_bn_relu_bwd_apply pass)
+LAZY_BN = os.environ.get("CTUNET_LAZY_BN", "1") != "0"
 # the launch that writes a BatchNorm's partial rows also finalizes them (its last block: ctu_bn_tail / ctu_bn_bwd_tail)
 # instead of a separate ctu_bn_finalize / ctu_bn_bwd_finalize launch (CTUNET_BN_TAIL=0: the separate launches)
 BN_TAIL = os.environ.get("CTUNET_BN_TAIL", "0") != "0"
@@ -451,18 +454,47 @@ class UNetEngine:
         counter = self._counter(rec.bn, "bwd", device)
         return None if counter is None else (P[rec.bn + ".weight"].detach(), rec.cout, self._replay(P, rec), counter)
 
+    def _gy_like(self, ga: CL) -> CL:
+        """Where a lazy BatchNorm backward writes the raw-output gradient: a buffer of ga's shape (one per ga buffer and
+        backward pass -- the two convs that share a concat-level gradient buffer use disjoint channel halves of it)."""
+        ent = self._gy_bufs.get(id(ga.buf))          # (the entry keeps ga's buffer alive, so its id cannot be recycled)
+        if ent is None:
+            ent = self._gy_bufs[id(ga.buf)] = (ga.buf, torch.empty_like(ga.buf))
+        return CL(ent[1], ga.c0, ga.cp)
+
     def _conv_bn_bwd(self, P, rec: _ConvRec, ga: CL, gin: Optional[CL], grads: Dict[str, torch.Tensor], ws, part,
-                     pre_reduced: Optional[int] = None, finalized=None):
-        """ga: gradient w.r.t. the ACTIVATED output (overwritten with the raw-output gradient).
-        gin: where to write the gradient w.r.t. this conv's activated input (None: not needed)."""
+                     pre_reduced: Optional[int] = None, finalized=None, up_in: Optional[CL] = None):
+        """ga: gradient w.r.t. the ACTIVATED output (overwritten with the raw-output gradient unless the BatchNorm backward
+        is folded into the weight-gradient kernel, ops.conv3d_wgrad_bn: then the raw-output gradient goes to a second buffer).
+        gin: where to write the gradient w.r.t. this conv's activated input (None: not needed).
+        up_in: rec is a fused up-convolution and this is its coarse input -- only the BatchNorm part runs here; returns what
+        the caller hands to ops.upconv_fused_wgrad(lazy=...) (None: ga already holds the raw-output gradient)."""
         k = self.plan.k
-        dg, db = ops.bn_relu_bwd(rec.y, ga, rec.vec, P[rec.bn + ".weight"].detach(), rec.cout, part, self._replay(P, rec),
-                                 pre_reduced, self._counter(rec.bn, "bwd", ga.buf.device), finalized)
-        grads[rec.bn + ".weight"], grads[rec.bn + ".bias"] = dg, db
+        fp32 = self.dtype == torch.float32 and LAZY_BN and ga.cs == rec.y.cs
+        if up_in is not None:
+            lazy = fp32 and ops.upconv_fused_wgrad_bn_supported(up_in.dims, up_in.cp, ga.cp)
+        else:
+            lazy = fp32 and not rec.bias and (rec.first is not None or (
+                rec.x is not None and ops.conv3d_wgrad_bn_supported(ga.dims, k, rec.x.cp, ga.cp)))
+        res = ops.bn_relu_bwd(rec.y, ga, rec.vec, P[rec.bn + ".weight"].detach(), rec.cout, part, self._replay(P, rec),
+                              pre_reduced, self._counter(rec.bn, "bwd", ga.buf.device), finalized, lazy)
+        grads[rec.bn + ".weight"], grads[rec.bn + ".bias"] = res[0], res[1]
+        if up_in is not None:
+            return (rec.y, rec.vec, res[2], self._gy_like(ga)) if lazy else None
         if rec.first is not None:                  # direct C_in <= 2 kernels; gin is a request flag here
-            grads[rec.conv + ".weight"] = ops.conv_first_wgrad(rec.first, ga, rec.cout, ws)
+            if lazy:
+                gy = self._gy_like(ga)
+                grads[rec.conv + ".weight"] = ops.conv_first_wgrad_bn(rec.first, ga, rec.y, rec.vec, res[2], gy, rec.cout, ws)
+                ga = gy
+            else:
+                grads[rec.conv + ".weight"] = ops.conv_first_wgrad(rec.first, ga, rec.cout, ws)
             return ops.conv_first_bwd_data(ga, P[rec.conv + ".weight"].detach(), rec.cin) if gin is not None else None
-        if rec.x is not None:                      # (None: fused up-convolution, its weight gradients come from the caller)
+        if lazy:
+            gy = self._gy_like(ga)
+            grads[rec.conv + ".weight"] = ops.conv3d_wgrad_bn(rec.x, ga, rec.y, rec.vec, res[2], gy, rec.cout, rec.cin, k,
+                                                             rec.imap, ws)
+            ga = gy
+        elif rec.x is not None:                    # (None: fused up-convolution, its weight gradients come from the caller)
             dw, dbias = ops.conv3d_wgrad(rec.x, ga, rec.cout, rec.cin, k, rec.imap, ws, rec.bias)
             grads[rec.conv + ".weight"] = dw
             if rec.bias:
@@ -491,6 +523,7 @@ class UNetEngine:
             ops.scale_tensors([g0, g1], gs)
         grads: Dict[str, torch.Tensor] = {}
         emitted: set = set()
+        self._gy_bufs: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
 
         def emit():
             """Block boundary: the gradients produced since the last one are final -- un-scale them (float16 loss
@@ -588,14 +621,16 @@ class UNetEngine:
                 # ConvTranspose3d -> Conv3d ran fused (the transposed conv's output never existed): BatchNorm backward,
                 # then the gradients of BOTH layers' parameters from the composite-weight gradient of (coarse input, g_u1)
                 # and the data gradient straight back to the coarse grid
-                self._conv_bn_bwd(P, r1, g_u1, None, grads, ws, part)
+                lz = self._conv_bn_bwd(P, r1, g_u1, None, grads, ws, part, up_in=x_in)
                 xq, gq, ginq = x_in, g_u1, gin
                 if g_u1.lp:                           # 16-bit path: fp32 copies around the fp32 fused kernels (see _upconv_bn)
                     xq = r1.x32
                     gq = CL(g_u1.buf.float(), g_u1.c0, g_u1.cp)
                     ginq = CL(torch.empty(gin.dims + (gin.cp,), dtype=torch.float32, device=dev), 0, gin.cp)
                 dwt, dbt, dw3 = ops.upconv_fused_wgrad(xq, gq, ct, blk.cout, P[f"{blk.prefix}.0.bias"],
-                                                       self._up_cache[blk.prefix][4], imap_t)
+                                                       self._up_cache[blk.prefix][4], imap_t, lz)
+                if lz is not None:
+                    gq = lz[3]                        # the raw-output gradient the weight-gradient kernel wrote
                 grads[f"{blk.prefix}.1.weight"] = dw3
                 grads[f"{blk.prefix}.0.weight"], grads[f"{blk.prefix}.0.bias"] = dwt, dbt
                 ops.upconv_fused_bwd_data(gq, self._up_cache[blk.prefix][5], ginq, (ct, blk.cout))
@@ -653,6 +688,7 @@ class UNetEngine:
             ops.scale_tensors([dx], 1.0 / gs)
         if sync is not None:
             grads.update(sync.finish())
+        self._gy_bufs = {}
         return grads, dx
 
 

@@ -386,6 +386,36 @@ def conv3d_wgrad(x: CL, g: CL, co: int, ci: int, k: int, cinv: Optional[torch.Te
     return dw, db
 
 
+def conv3d_wgrad_bn_supported(dims, k: int, cin_p: int, cout_p: int, dtype=torch.float32) -> bool:
+    """Can conv3d_wgrad_bn take this layer (fp32, k = 3, full boxes and channel tiles)?"""
+    n, d, h, w = dims
+    return dtype == torch.float32 and bool(_lib.load().ctu_conv3d_wgrad_bn_supported(n, d, h, w, k, cin_p, cout_p))
+
+
+def conv3d_wgrad_bn(x: CL, ga: CL, y: CL, vec: torch.Tensor, coef: torch.Tensor, gy: CL, co: int, ci: int, k: int,
+                    cinv: Optional[torch.Tensor], ws: torch.Tensor) -> torch.Tensor:
+    """Weight gradient with the layer's BatchNorm + ReLU backward folded in: ga = gradient w.r.t. the ACTIVATED output, y =
+    the raw conv output, vec = its [4, cp] BatchNorm vectors, coef = bn_relu_bwd(lazy=True)'s rows; gy (same buffer shape
+    and channel offset as ga) receives the raw-output gradient for the data-gradient kernel."""
+    n, d, h, w = x.dims
+    lib = _lib.load()
+    assert not x.lp and ga.dims == x.dims and y.dims == x.dims and gy.dims == x.dims
+    assert y.cs == ga.cs == gy.cs and y.cp == ga.cp == gy.cp and gy.buf.data_ptr() != ga.buf.data_ptr()
+    need = lib.ctu_conv3d_wgrad_ws_floats(n, d, h, w, k, x.cp, ga.cp)
+    assert ws.numel() >= need, (ws.numel(), need)
+    dw = torch.empty((co, ci, k, k, k), dtype=torch.float32, device=x.buf.device)
+    t0 = TIMER.begin() if TIMER is not None else None
+    _lib.check(lib.ctu_conv3d_wgrad_bn(x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), ga.ptr, ga.cs, ga.cp,
+                                       y.ptr, vec[0].data_ptr(), vec[1].data_ptr(), coef.data_ptr(), gy.ptr,
+                                       dw.data_ptr(), co, ci, _ptr(cinv), ws.data_ptr(), n, d, h, w, k, _stream()),
+               "conv3d_wgrad_bn")
+    if t0 is not None:
+        vox = n * d * h * w
+        TIMER.end(lib.ctu_conv3d_wgrad_kernel_name(w, k, x.cp, ga.cp).decode() + " (+slab reduce)",
+                  2.0 * ci * co * k ** 3 * vox, 4.0 * vox * (ci + co), t0, (w, x.cp, ga.cp))
+    return dw
+
+
 def conv3d_wgrad_ws(dims, k, cin_p, cout_p, dtype=torch.float32) -> int:
     n, d, h, w = dims
     if lp(dtype):
@@ -456,6 +486,24 @@ def conv_first_wgrad(x: torch.Tensor, g: CL, co: int, ws: torch.Tensor) -> torch
     return dw
 
 
+def conv_first_wgrad_bn(x: torch.Tensor, ga: CL, y: CL, vec: torch.Tensor, coef: torch.Tensor, gy: CL, co: int,
+                        ws: torch.Tensor) -> torch.Tensor:
+    """conv_first_wgrad with the BatchNorm + ReLU backward folded in (see conv3d_wgrad_bn); fp32 only."""
+    n, cin, d, h, w_ = x.shape
+    lib = _lib.load()
+    assert not ga.lp and y.cs == ga.cs == gy.cs and ga.cp == 8 and gy.buf.data_ptr() != ga.buf.data_ptr()
+    assert ws.numel() >= lib.ctu_conv3d_first_wgrad_ws_floats(n, d, h, w_, cin)
+    dw = torch.empty((co, cin, 3, 3, 3), dtype=torch.float32, device=x.device)
+    t0 = TIMER.begin() if TIMER is not None else None
+    _lib.check(lib.ctu_conv3d_first_wgrad_bn(x.data_ptr(), cin, ga.ptr, ga.cs, y.ptr, vec[0].data_ptr(), vec[1].data_ptr(),
+                                             coef.data_ptr(), gy.ptr, dw.data_ptr(), co, ws.data_ptr(), n, d, h, w_, _stream()),
+               "conv3d_first_wgrad_bn")
+    if t0 is not None:
+        vox = n * d * h * w_
+        TIMER.end(f"first_wgrad_kernel<{cin}> (+slab reduce)", 2.0 * cin * co * 27 * vox, 4.0 * vox * (cin + co), t0)
+    return dw
+
+
 def conv_first_wgrad_ws(dims, cin: int) -> int:
     n, d, h, w = dims
     return _lib.load().ctu_conv3d_first_wgrad_ws_floats(n, d, h, w, cin)
@@ -492,12 +540,15 @@ def bn_eval_affine(gamma, beta, rmean, rvar, eps, c, cp):
 
 
 def bn_relu_bwd(y: CL, ga: CL, vec: torch.Tensor, gamma: torch.Tensor, c: int, partials: torch.Tensor,
-                replay=None, pre_reduced: Optional[int] = None, counter: Optional[torch.Tensor] = None, finalized=None):
+                replay=None, pre_reduced: Optional[int] = None, counter: Optional[torch.Tensor] = None, finalized=None,
+                lazy: bool = False):
     """In place: ga <- gradient w.r.t. the raw conv output y.  Returns (dgamma, dbeta).
     replay = (running_mean, running_var, momentum, eps[, num_batches_tracked]): also apply the running-stat update a
     second time (the one torch.utils.checkpoint's recompute performs in backward, models.py:232-255).
     counter: the reduction launch finalizes itself (ctu_bn_bwd_tail) instead of a ctu_bn_bwd_finalize launch.
-    finalized = (dgb, coef): the kernel that produced ga already reduced AND finalized (maxpool_bwd / head_bwd with fin=)."""
+    finalized = (dgb, coef): the kernel that produced ga already reduced AND finalized (maxpool_bwd / head_bwd with fin=).
+    lazy: reduce and finalize only -- ga stays the gradient w.r.t. the ACTIVATED output and the weight-gradient kernel
+    applies the backward while it stages ga (conv3d_wgrad_bn / upconv_fused_wgrad_bn); returns (dgamma, dbeta, coef)."""
     lib = _lib.load()
     nvox = y.nvox
     cp = y.cp
@@ -505,12 +556,14 @@ def bn_relu_bwd(y: CL, ga: CL, vec: torch.Tensor, gamma: torch.Tensor, c: int, p
     st = _stream()
     if finalized is not None:
         dgb, coef = finalized
+        if lazy:
+            return dgb[0], dgb[1], coef
         _dual(y.lp, "bn_relu_bwd_apply", y.ptr, y.cs, ga.ptr, ga.cs, cp, sc, sh, mu, istd, coef.data_ptr(), nvox, st)
         return dgb[0], dgb[1]
     nb = lib.ctu_bn_bwd_num_blocks(nvox) if pre_reduced is None else pre_reduced
     assert partials.numel() >= nb * 2 * cp
     dgb = torch.empty((2, c), dtype=torch.float32, device=y.buf.device)
-    coef = torch.empty((3, cp), dtype=torch.float32, device=y.buf.device)
+    coef = torch.empty((5, cp), dtype=torch.float32, device=y.buf.device)
     tail = make_bn_bwd_tail(c, nvox, gamma, vec, dgb, coef, replay, counter) if (counter is not None and pre_reduced is None) else None
     if pre_reduced is None:       # (else: the kernel that produced ga wrote the nb reduction rows, maxpool_bwd(bn=...))
         assert ga.dtype == y.dtype
@@ -522,6 +575,8 @@ def bn_relu_bwd(y: CL, ga: CL, vec: torch.Tensor, gamma: torch.Tensor, c: int, p
         _lib.check(lib.ctu_bn_bwd_finalize(partials.data_ptr(), nb, c, cp, float(nvox), gamma.data_ptr(), istd,
                                            dgb[0].data_ptr(), dgb[1].data_ptr(), coef.data_ptr(), mu, _ptr(rm), _ptr(rv),
                                            mom, eps, None if nbt is None else nbt.data_ptr(), st), "bn_bwd_finalize")
+    if lazy:
+        return dgb[0], dgb[1], coef
     _dual(y.lp, "bn_relu_bwd_apply", y.ptr, y.cs, ga.ptr, ga.cs, cp, sc, sh, mu, istd, coef.data_ptr(), nvox, st)
     return dgb[0], dgb[1]
 
@@ -560,7 +615,7 @@ def maxpool_bwd(x: CL, gout: CL, gin: CL, accumulate: bool, bn=None, fin=None):
         if fin is not None:
             gamma, c, replay, counter = fin
             dgb = torch.empty((2, c), dtype=torch.float32, device=x.buf.device)
-            coef = torch.empty((3, x.cp), dtype=torch.float32, device=x.buf.device)
+            coef = torch.empty((5, x.cp), dtype=torch.float32, device=x.buf.device)
             tail, done = make_bn_bwd_tail(c, x.nvox, gamma, vec, dgb, coef, replay, counter), (dgb, coef)
         _dual(x.lp, "maxpool2_bwd_bn", x.ptr, x.cs, x.cp, vec[0].data_ptr(), vec[1].data_ptr(), vec[2].data_ptr(),
               vec[3].data_ptr(), gout.ptr, gout.cs, gin.ptr, gin.cs, int(accumulate), n, d, h, w, partials.data_ptr(),
@@ -714,7 +769,7 @@ def head_bwd(x: CL, w: torch.Tensor, b: torch.Tensor, imap, act: int, head_mode:
         if fin is not None:
             gamma, c, replay = fin[:3]
             dgb = torch.empty((2, c), dtype=torch.float32, device=dev)
-            coef = torch.empty((3, bn_cp), dtype=torch.float32, device=dev)
+            coef = torch.empty((5, bn_cp), dtype=torch.float32, device=dev)
             tail, done = make_bn_bwd_tail(c, n * v, gamma, vec, dgb, coef, replay, None), (dgb, coef)
         _dual(x.lp, "head_bwd_bn", x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), w.data_ptr(), b.data_ptr(),
               _ptr(imap), ci, co, act, head_mode, g0.data_ptr(), _ptr(g1), gin.ptr, gin.cs, dw.data_ptr(), db.data_ptr(),
@@ -832,10 +887,18 @@ def upconv_fused_fwd(x: CL, wp: torch.Tensor, beff: torch.Tensor, out: CL, stats
                   t0, (w, x.cp, out.cp))
 
 
-def upconv_fused_wgrad(x: CL, g: CL, c: int, co: int, bt: torch.Tensor, pack_ws: torch.Tensor, imap):
+def upconv_fused_wgrad_bn_supported(dims, cin_p: int, nout_p: int, dtype=torch.float32) -> bool:
+    n, d, h, w = dims
+    return dtype == torch.float32 and bool(_lib.load().ctu_upconv_fused_wgrad_bn_supported(n, d, h, w, cin_p, nout_p))
+
+
+def upconv_fused_wgrad(x: CL, g: CL, c: int, co: int, bt: torch.Tensor, pack_ws: torch.Tensor, imap, lazy=None):
     """(dWT [C,C,2,2,2], dbT [C], dW3 [Co,C,3,3,3]) of the fused ConvTranspose3d -> Conv3d pair: x = COARSE input of the
     transposed conv, g = fine-grid gradient w.r.t. the conv's raw output, pack_ws = scratch of this step's
-    upconv_fused_pack (transposed weights)."""
+    upconv_fused_pack (transposed weights).
+    lazy = (y, vec, coef, gy): g is the gradient w.r.t. the ACTIVATED output; the BatchNorm + ReLU backward is applied while
+    the weight-gradient kernel stages it and the raw-output gradient lands in gy (read by the projections here and by
+    upconv_fused_bwd_data afterwards) -- see conv3d_wgrad_bn."""
     n, d, h, w = x.dims
     assert g.dims == (n, 2 * d, 2 * h, 2 * w)
     lib = _lib.load()
@@ -843,8 +906,18 @@ def upconv_fused_wgrad(x: CL, g: CL, c: int, co: int, bt: torch.Tensor, pack_ws:
     dweff = torch.empty((8, 8, x.cp, g.cp), dtype=torch.float32, device=dev)
     ws = torch.empty(lib.ctu_upconv_fused_wgrad_ws_floats(n, d, h, w, x.cp, g.cp), dtype=torch.float32, device=dev)
     t0 = TIMER.begin() if TIMER is not None else None
-    _lib.check(lib.ctu_upconv_fused_wgrad(x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), g.ptr, g.cs, g.cp,
-                                          dweff.data_ptr(), ws.data_ptr(), n, d, h, w, _stream()), "upconv_fused_wgrad")
+    if lazy is not None:
+        y, vec, coef, gy = lazy
+        assert y.dims == g.dims and gy.dims == g.dims and y.cs == g.cs == gy.cs and y.cp == g.cp == gy.cp
+        assert gy.buf.data_ptr() != g.buf.data_ptr()
+        _lib.check(lib.ctu_upconv_fused_wgrad_bn(x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), g.ptr, g.cs,
+                                                 g.cp, y.ptr, vec[0].data_ptr(), vec[1].data_ptr(), coef.data_ptr(), gy.ptr,
+                                                 dweff.data_ptr(), ws.data_ptr(), n, d, h, w, _stream()),
+                   "upconv_fused_wgrad_bn")
+        g = gy
+    else:
+        _lib.check(lib.ctu_upconv_fused_wgrad(x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), g.ptr, g.cs, g.cp,
+                                              dweff.data_ptr(), ws.data_ptr(), n, d, h, w, _stream()), "upconv_fused_wgrad")
     if t0 is not None:
         vox = n * d * h * w
         TIMER.end(f"upconv_fused_wgrad_kernel<{g.cp}> (+slab reduce)", vox * (16.0 * c * c + 8 * 54.0 * c * co),

@@ -66,7 +66,7 @@ typedef struct ctu_bn_tail {
 } ctu_bn_tail;
 typedef struct ctu_bn_bwd_tail {
     const float* gamma; const float* invstd;
-    float* dgamma; float* dbeta; float* coef;         /* coef [3][cp] as ctu_bn_bwd_finalize */
+    float* dgamma; float* dbeta; float* coef;         /* coef [5][cp] as ctu_bn_bwd_finalize */
     const float* mean; float* running_mean; float* running_var;   /* the replayed update; NULL running_mean: none */
     long long* num_batches_tracked;
     unsigned int* counter;
@@ -158,6 +158,19 @@ int ctu_conv3d_wgrad(const float* in, int in_cs, int cin_p,
                      const float* gout, int g_cs, int cout_p,
                      float* dw, float* dbias, int Co, int Ci, const int32_t* cinv,
                      float* ws, int N, int D, int H, int W, int k, void* stream);
+/* The same with the BatchNorm3d + ReLU backward of the layer (models.py:27-32, torch autograd) folded in: ga is the
+ * gradient w.r.t. the ACTIVATED output, y the layer's raw output (same geometry and channel stride g_cs as ga), bn_scale /
+ * bn_shift its ctu_bn_finalize vectors, coef the [5][cout_p] rows of ctu_bn_bwd_finalize.  The kernel forms the raw-output
+ * gradient gy while staging ga, uses it for dW and writes it to gy_out (geometry of ga, must not alias it) for the
+ * data-gradient call that follows -- the ctu_bn_relu_bwd_apply pass over the layer disappears.  Only for the geometries
+ * ctu_conv3d_wgrad_bn_supported accepts (k = 3, volume a multiple of the 4 x 4 x 8|16 box, full channel tiles). */
+int ctu_conv3d_wgrad_bn_supported(int N, int D, int H, int W, int k, int cin_p, int cout_p);
+int ctu_conv3d_wgrad_bn(const float* in, int in_cs, int cin_p,
+                        const float* in_scale, const float* in_shift, int in_relu,
+                        const float* ga, int g_cs, int cout_p, const float* y,
+                        const float* bn_scale, const float* bn_shift, const float* coef, float* gy_out,
+                        float* dw, int Co, int Ci, const int32_t* cinv,
+                        float* ws, int N, int D, int H, int W, int k, void* stream);
 
 /* First encoder convolution: C_in = 1 or 2, k = 3, at most 8 output channels (nn.Conv3d(input_channels, i_size, 3),
  * models.py:26 with the channel plan of :175,272-296).  K = 27*C_in is too short for the implicit-GEMM tile and the
@@ -178,6 +191,12 @@ int ctu_conv3d_first_bwd_data(const float* g, int g_cs, const float* w, int cin,
 size_t ctu_conv3d_first_wgrad_ws_floats(int N, int D, int H, int W, int cin);
 int ctu_conv3d_first_wgrad(const float* x, int cin, const float* g, int g_cs, float* dw, int Co,
                            float* ws, int N, int D, int H, int W, void* stream);
+/* ctu_conv3d_first_wgrad with the layer's BatchNorm + ReLU backward folded in (see ctu_conv3d_wgrad_bn): ga = gradient
+ * w.r.t. the ACTIVATED output, y = the raw output, coef = ctu_bn_bwd_finalize's [5][8] rows; the raw-output gradient is
+ * written to gy_out (geometry of ga) for ctu_conv3d_first_bwd_data. */
+int ctu_conv3d_first_wgrad_bn(const float* x, int cin, const float* ga, int g_cs, const float* y, const float* bn_scale,
+                              const float* bn_shift, const float* coef, float* gy_out, float* dw, int Co, float* ws,
+                              int N, int D, int H, int W, void* stream);
 
 /* ------------------------------------------------------------ BatchNorm3d ---- */
 /* Train mode: reduce the per-block partials written by ctu_conv3d_fwd into batch
@@ -207,7 +226,11 @@ int ctu_bn_bwd_num_blocks(int64_t nvox);
 int ctu_bn_relu_bwd_reduce(const float* y, int y_cs, const float* ga, int g_cs, int cp,
                            const float* scale, const float* shift, const float* mean,
                            const float* invstd, int64_t nvox, float* partials, const ctu_bn_bwd_tail* tail, void* stream);
-/* running_mean/running_var non-NULL: additionally replay the running-statistics update once, with the batch
+/* coef [5][cp]: rows k0 = gamma*invstd, k1 = dbeta/n, k2 = dgamma/n (what ctu_bn_relu_bwd_apply reads) and the same
+ * backward as one affine map of the raw output, A = -k0*k2*invstd, B = -k0*(k1 - k2*mean*invstd):
+ *     gy = (y*scale + shift > 0 ? k0*ga : 0) + A*y + B
+ * (what the weight-gradient kernels of ctu_conv3d_wgrad_bn / ctu_upconv_fused_wgrad_bn apply while staging ga).
+ * running_mean/running_var non-NULL: additionally replay the running-statistics update once, with the batch
  * statistics saved by ctu_bn_finalize (mean, invstd) -- the second update torch.utils.checkpoint's recompute
  * performs in backward when use_checkpoint=True (models.py:232-255). */
 int ctu_bn_bwd_finalize(const float* partials, int nb, int C, int cp, double count,
@@ -352,6 +375,14 @@ size_t ctu_upconv_fused_wgrad_ws_floats(int N, int D, int H, int W, int cin_p, i
 int ctu_upconv_fused_wgrad(const float* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
                            int in_relu, const float* gout, int g_cs, int nout_p, float* dweff, float* ws,
                            int N, int D, int H, int W, void* stream);
+/* ctu_upconv_fused_wgrad with the BatchNorm + ReLU backward of the fused op's output folded in (as ctu_conv3d_wgrad_bn):
+ * ga = fine-grid gradient w.r.t. the ACTIVATED output, y = the fused op's raw output, gy_out = the raw-output gradient the
+ * ctu_upconv_fused_project and ctu_upconv_fused_bwd_data calls that follow read.  N, D, H, W: COARSE dims. */
+int ctu_upconv_fused_wgrad_bn_supported(int N, int D, int H, int W, int cin_p, int nout_p);
+int ctu_upconv_fused_wgrad_bn(const float* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
+                              int in_relu, const float* ga, int g_cs, int nout_p, const float* y,
+                              const float* bn_scale, const float* bn_shift, const float* coef, float* gy_out,
+                              float* dweff, float* ws, int N, int D, int H, int W, void* stream);
 size_t ctu_upconv_fused_project_ws_floats(int nout_p, int64_t fine_nvox);
 int ctu_upconv_fused_project(const float* dweff, const float* gout, int g_cs, int nout_p, int N, int D, int H, int W,
                              const float* bt, const float* pack_ws, const int32_t* imap, int C, int Co, int cin_p,

@@ -1,5 +1,5 @@
 """Single-layer microbenchmark through the C ABI (dev tool): conv fwd / wgrad / convT at a given shape.
-usage: bench_layer.py <op> <cin> <cout> <size> [k] [iters]   op in {fwd, wgrad, convt, convt_bwd, convt_wgrad}
+usage: bench_layer.py <op> <cin> <cout> <size> [k] [iters]   op in {fwd, wgrad, wgrad_bn, convt, convt_bwd, convt_wgrad}
 CTU_DT=bf16|f16 in the environment: the 16-bit (ctu_lp_*) kernels."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -33,6 +33,14 @@ elif op == "wgrad":
     g = ops.CL(torch.randn(1, s, s, s, cop, device=dev).to(DT), 0, cop)
     ws = torch.empty(ops.conv3d_wgrad_ws((1, s, s, s), k, cip, cop, DT), device=dev)
     fn = lambda: ops.conv3d_wgrad(xx, g, co, ci, k, None, ws, False)
+elif op == "wgrad_bn":      # weight gradient with the BatchNorm + ReLU backward folded in (fp32)
+    g = ops.CL(torch.randn(1, s, s, s, cop, device=dev), 0, cop)
+    y = ops.CL(torch.randn(1, s, s, s, cop, device=dev), 0, cop)
+    gy = ops.CL(torch.empty(1, s, s, s, cop, device=dev), 0, cop)
+    vec = torch.rand(4, cop, device=dev) + 0.5
+    coef = torch.randn(5, cop, device=dev) * 0.1
+    ws = torch.empty(ops.conv3d_wgrad_ws((1, s, s, s), k, cip, cop, DT), device=dev)
+    fn = lambda: ops.conv3d_wgrad_bn(xx, g, y, vec, coef, gy, co, ci, k, None, ws)
 elif op == "convt":
     w = torch.randn(ci, co, 2, 2, 2, device=dev) * 0.1
     wp = ops.pack_convt_w_lp(w, None, cip, cop, 0, DT) if LP else ops.pack_convt_w(w, None, cip, cop, 0)

@@ -1,6 +1,6 @@
 // Diagnostic build (never shipped): where a stage of conv3d_fwd_k3_persist spends its cycles.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DCTU_STAMP -Iinclude -Ict-unet_amd/csrc scripts/diag_stamp.hip \
-//         ct-unet_amd/csrc/elementwise.hip -o gpurun_out/diag_stamp && gpurun_out/diag_stamp <cin_p> <nout_p> <size> <layout>
+//         ct-unet_amd/csrc/elementwise.hip ct-unet_amd/csrc/convt.hip -o scripts/build/diag_stamp && gpurun_out/diag_stamp <cin_p> <nout_p> <size> <layout>
 // Phases (wave 0 of every block, s_memtime cycles): 0 wait at the top barrier, 1 LDS write + barrier,
 // 2 prefetch issue, 3 MFMA loop, 4 epilogue.
 #include "conv3d.hip"
@@ -37,7 +37,7 @@ int main(int argc, char** argv) {
                                  1, S, S, S, 3, nullptr)) { printf("error: %s\n", ctu_last_error()); return 1; }
     } else
     for (int it = 0; it < 5; ++it)
-        if (ctu_conv3d_fwd(in, cin_p, cin_p, nullptr, nullptr, 0, wp, nullptr, 0, out, nout_p, nout_p, stats, 1, S, S, S, 3, layout, nullptr)) {
+        if (ctu_conv3d_fwd(in, cin_p, cin_p, nullptr, nullptr, 0, wp, nullptr, 0, out, nout_p, nout_p, stats, 1, S, S, S, 3, layout, nullptr, nullptr)) {
             printf("error: %s\n", ctu_last_error()); return 1;
         }
     hipDeviceSynchronize();

@@ -698,3 +698,132 @@ def test_upconv_fused_bwd_data(c, co, dims, segs):
     rest = [q for q in range(cp) if q not in pos]
     if rest:
         assert torch.equal(gin.buf.cpu()[..., rest], torch.zeros(n, d, h, w, len(rest)))      # padding positions get zeros
+
+
+def _bn_setup(ops, y, c, cp, seed):
+    """BatchNorm vectors [4, cp] (scale, shift, mean, invstd) of a raw tensor y [N,C,D,H,W] with random gamma / beta."""
+    gamma = torch.rand(c, generator=g(seed)) * 1.5 - 0.25
+    beta = torch.randn(c, generator=g(seed + 1)) * 0.2
+    mean = y.double().mean(dim=(0, 2, 3, 4))
+    var = y.double().var(dim=(0, 2, 3, 4), unbiased=False)
+    invstd = (1.0 / torch.sqrt(var + 1e-5)).float()
+    vec = torch.zeros(4, cp)
+    vec[0, :c] = gamma * invstd
+    vec[1, :c] = beta - mean.float() * gamma * invstd
+    vec[2, :c] = mean.float()
+    vec[3, :c] = invstd
+    return gamma, beta, vec.cuda()
+
+
+@pytest.mark.parametrize("case", [
+    # N, Ci, Co, D, H, W, cs of the gradient / raw-output buffers, channel offset
+    (1, 8, 8, 8, 8, 32, 8, 0),          # 8 -> 8: (shift, channel) tiles on both sides, 4x4x16 boxes
+    (2, 8, 8, 4, 8, 16, 16, 8),         # ... in the second half of a concat-level buffer
+    (1, 16, 8, 8, 4, 16, 8, 0),         # C -> 8
+    (1, 8, 16, 4, 8, 24, 16, 0),        # 8 -> C
+    (1, 16, 16, 8, 8, 16, 32, 16),      # full 16 x 16 tile, slice of a wider buffer
+    (1, 32, 16, 4, 4, 16, 16, 0),       # two input-channel tiles share a gradient tile (identical gy stores)
+])
+def test_conv3d_wgrad_with_lazy_batchnorm_backward(case):
+    """ops.conv3d_wgrad_bn (BatchNorm + ReLU backward folded into the weight-gradient kernel's staging) against the
+    three-pass path it replaces (reduce, finalize, in-place apply, plain weight gradient) and against fp64 autograd of
+    relu(batch_norm(y)) for the raw-output gradient it writes out."""
+    ops = _ops()
+    n, ci, co, d, h, w, cs, c0 = case
+    cip, cop = ops.pad8(ci), ops.pad8(co)
+    assert ops.conv3d_wgrad_bn_supported((n, d, h, w), 3, cip, cop)
+    x = torch.randn(n, ci, d, h, w, generator=g(41))
+    y = torch.randn(n, co, d, h, w, generator=g(42)) * 1.3 + 0.3
+    ga = torch.randn(n, co, d, h, w, generator=g(43))
+    gamma, beta, vec = _bn_setup(ops, y, co, cop, 44)
+    sc, sh = xf_vectors(ci, cip, 46)
+    xc = to_cl(x).with_xf(sc.cuda(), sh.cuda(), True)
+    yc, gac = to_cl(y, cs, c0, cop), to_cl(ga, cs, c0, cop)
+    part = torch.empty(ops.bn_bwd_partials_floats(n * d * h * w, cop), device="cuda")
+    ws = torch.empty(ops.conv3d_wgrad_ws((n, d, h, w), 3, cip, cop), device="cuda")
+    # lazy path
+    dg1, db1, coef = ops.bn_relu_bwd(yc, gac, vec, gamma.cuda(), co, part, lazy=True)
+    gy = ops.CL(torch.full_like(gac.buf, float("nan")), c0, cop)
+    ga_before = gac.buf.clone()
+    dw1 = ops.conv3d_wgrad_bn(xc, gac, yc, vec, coef, gy, co, ci, 3, None, ws)
+    torch.cuda.synchronize()
+    assert torch.equal(gac.buf, ga_before)                      # the activated-output gradient is left alone
+    # three-pass path
+    gac2 = to_cl(ga, cs, c0, cop)
+    dg2, db2 = ops.bn_relu_bwd(yc, gac2, vec, gamma.cuda(), co, part)
+    dw2, _ = ops.conv3d_wgrad(xc, gac2, co, ci, 3, None, ws, False)
+    torch.cuda.synchronize()
+    assert torch.equal(dg1, dg2) and torch.equal(db1, db2)
+    gy_l, gy_3 = from_cl(gy, co), from_cl(gac2, co)
+    assert not torch.isnan(gy_l).any()
+    assert rel_err(gy_l, gy_3) < 2e-6
+    assert rel_err(dw1.cpu(), dw2.cpu()) < 1e-5
+    if cs > cop:                                                # channels outside the slice are never written
+        other = torch.ones(cs, dtype=torch.bool); other[c0:c0 + cop] = False
+        assert torch.isnan(gy.buf[..., other.cuda()]).all()
+    # fp64 autograd of relu(batch_norm(y)) for the raw-output gradient
+    y64 = y.double().requires_grad_(True)
+    a = F.relu(F.batch_norm(y64, None, None, gamma.double(), beta.double(), True, 0.1, 1e-5))
+    a.backward(ga.double())
+    assert rel_err(gy_l.double(), y64.grad) < 2e-4
+
+
+@pytest.mark.parametrize("c,co,dims,cs", [
+    (16, 8, (1, 4, 4, 16), 8),          # 8 padded output channels, gradient stride 8: the (w-parity, c_out) tile
+    (16, 8, (1, 4, 8, 8), 16),          # 8 output channels inside a 16-wide buffer: the plain tile, two quads masked
+    (32, 16, (2, 4, 4, 8), 16),
+    (16, 32, (1, 4, 4, 8), 32),         # two gradient channel tiles
+])
+def test_upconv_fused_wgrad_with_lazy_batchnorm_backward(c, co, dims, cs):
+    """ops.upconv_fused_wgrad(lazy=...) against the same call on the gradient a separate BatchNorm-backward pass produced."""
+    ops = _ops()
+    n, d, h, w = dims
+    cp, cop = ops.pad8(c), ops.pad8(co)
+    assert ops.upconv_fused_wgrad_bn_supported(dims, cp, cop)
+    x = torch.randn(n, c, d, h, w, generator=g(51))
+    wt = torch.randn(c, c, 2, 2, 2, generator=g(52)) * 0.2
+    bt = torch.randn(c, generator=g(53))
+    w3 = torch.randn(co, c, 3, 3, 3, generator=g(54)) * 0.1
+    y = torch.randn(n, co, 2 * d, 2 * h, 2 * w, generator=g(55)) * 1.2 - 0.2
+    ga = torch.randn(n, co, 2 * d, 2 * h, 2 * w, generator=g(56))
+    gamma, beta, vec = _bn_setup(ops, y, co, cop, 57)
+    sc, sh = xf_vectors(c, cp, 59)
+    xc = to_cl(x).with_xf(sc.cuda(), sh.cuda(), True)
+    _, _, pws = ops.upconv_fused_pack(wt.cuda(), bt.cuda(), w3.cuda(), None, cp, cop)
+    yc, gac = to_cl(y, cs, 0, cop), to_cl(ga, cs, 0, cop)
+    part = torch.empty(ops.bn_bwd_partials_floats(yc.nvox, cop), device="cuda")
+    _, _, coef = ops.bn_relu_bwd(yc, gac, vec, gamma.cuda(), co, part, lazy=True)
+    gy = ops.CL(torch.full_like(gac.buf, float("nan")), 0, cop)
+    got = ops.upconv_fused_wgrad(xc, gac, c, co, bt.cuda(), pws, None, (yc, vec, coef, gy))
+    gac2 = to_cl(ga, cs, 0, cop)
+    ops.bn_relu_bwd(yc, gac2, vec, gamma.cuda(), co, part)
+    want = ops.upconv_fused_wgrad(xc, gac2, c, co, bt.cuda(), pws, None)
+    torch.cuda.synchronize()
+    assert rel_err(from_cl(gy, co), from_cl(gac2, co)) < 2e-6
+    for name, a, b in zip(("dWT", "dbT", "dW3"), got, want):
+        assert rel_err(a.cpu(), b.cpu()) < 1e-5, name
+
+
+@pytest.mark.parametrize("case", [(1, 1, 8, 8, 8, 32, 8, 0), (2, 2, 7, 6, 5, 40, 16, 8), (1, 1, 3, 4, 4, 16, 8, 0)])
+def test_first_layer_wgrad_with_lazy_batchnorm_backward(case):
+    """ops.conv_first_wgrad_bn against the three-pass path (reduce, finalize, in-place apply, plain weight gradient);
+    ragged boxes included (the first-layer kernel checks bounds per item)."""
+    ops = _ops()
+    n, ci, co, d, h, w, cs, c0 = case
+    x = torch.randn(n, ci, d, h, w, generator=g(61)).cuda()
+    y = torch.randn(n, co, d, h, w, generator=g(62)) * 0.9 - 0.1
+    ga = torch.randn(n, co, d, h, w, generator=g(63))
+    gamma, beta, vec = _bn_setup(ops, y, co, 8, 64)
+    yc, gac = to_cl(y, cs, c0, 8), to_cl(ga, cs, c0, 8)
+    part = torch.empty(ops.bn_bwd_partials_floats(n * d * h * w, 8), device="cuda")
+    ws = torch.empty(ops.conv_first_wgrad_ws((n, d, h, w), ci), device="cuda")
+    _, _, coef = ops.bn_relu_bwd(yc, gac, vec, gamma.cuda(), co, part, lazy=True)
+    gy = ops.CL(torch.full_like(gac.buf, float("nan")), c0, 8)
+    dw1 = ops.conv_first_wgrad_bn(x, gac, yc, vec, coef, gy, co, ws)
+    gac2 = to_cl(ga, cs, c0, 8)
+    ops.bn_relu_bwd(yc, gac2, vec, gamma.cuda(), co, part)
+    dw2 = ops.conv_first_wgrad(x, gac2, co, ws)
+    torch.cuda.synchronize()
+    assert rel_err(from_cl(gy, co), from_cl(gac2, co)) < 2e-6
+    assert torch.all(from_cl(gy, 8)[:, co:] == 0)
+    assert rel_err(dw1.cpu(), dw2.cpu()) < 1e-5
