@@ -1115,11 +1115,17 @@ __host__ __device__ constexpr int lp_wg_entry_kw(int KS, int SM, int SN, int q, 
 
 // Block (x, y = (ci tile, co tile), z = kd plane for k = 5): accumulates dW[tap][16 ci][16 co] over a contiguous range of
 // boxes (4 x TH x BW voxels, 16 K-steps of 32 voxels, 4 per wave) and writes ONE slab.
-template <class T, int KS, int BW, int SM, int SN>
+// UP = 2: the weight gradient of the FUSED decoder up-convolution with 8 padded output channels (upconv_lp.hip; the 16-bit
+// twin of conv3d_wgrad_k3s_kernel<1, 1, 2>): x = COARSE activations, g = the fine-grid gradient (channel stride 8) read at one
+// (p_d, p_h) output parity per block (blockIdx.y = par4 * n_ci + ci tile); the gradient image's 16 columns are (w-parity,
+// c_out) -- the fine voxels 2w, 2w + 1 are 32 contiguous bytes -- and the 12 taps are (dz, dy, dxx) of the parity's sub-cube of
+// the coarse halo: slabs [12][16 ci][16 = (p_w, co)] in upconv_wgrad_reduce_pw_kernel's layout.
+template <class T, int KS, int BW, int SM, int SN, int UP = 0>
 __global__ __launch_bounds__(256) void lp_conv_wgrad_kernel(LpWgP p, int tiles_per_block) {
     typedef typename Vec<T>::v8 v8;
+    static_assert(!UP || (KS == 3 && SM == 1 && SN == 1), "fused up-convolution: full 16 x 16 tile, k = 3 halo");
     constexpr int PK = (KS - 1) / 2;
-    constexpr int QN = lp_wg_qn(KS, SM, SN), ROWS = (KS == 3) ? 9 : KS;
+    constexpr int QN = UP ? 3 : lp_wg_qn(KS, SM, SN), ROWS = UP ? 4 : ((KS == 3) ? 9 : KS);
     constexpr int NTAP = ROWS * QN;                                 // accumulators per block (k = 5: one kd plane)
     constexpr int RPK = 32 / BW, TD = 4, TH = 4 * RPK;
     constexpr int HD = (KS == 3) ? TD + 2 : TD, HH = TH + 2 * PK, HW = BW + 2 * PK, HV = HD * HH * HW, NV = TD * TH * BW;
@@ -1128,8 +1134,10 @@ __global__ __launch_bounds__(256) void lp_conv_wgrad_kernel(LpWgP p, int tiles_p
     unsigned char* sX = smem + 128;                                 // haloed input image, 16 channels
     unsigned char* sG = sX + (size_t)HV * WG_SX;                    // gradient image, 16 channels
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15, q = i >> 2, pc = i & 3;
-    const int nco = (p.cout_p + 15) >> 4;
-    const int cit = blockIdx.y / nco, cot = blockIdx.y % nco;
+    const int nco = (p.cout_p + 15) >> 4, nci_up = p.cin_p >> 4;
+    const int cit = UP ? blockIdx.y % nci_up : blockIdx.y / nco, cot = UP ? 0 : blockIdx.y % nco;
+    const int upz = UP ? (blockIdx.y / nci_up) >> 1 : 0, upy = UP ? (blockIdx.y / nci_up) & 1 : 0;      // UP: this block's (p_d, p_h)
+    const int gH = UP ? 2 * p.H : p.H, gW = UP ? 2 * p.W : p.W;     // the gradient grid's row strides
     const int kd = (KS == 3) ? 0 : blockIdx.z;                      // k = 5: this block's kd plane (halo rows d0 + td + kd - PK)
     const T* x = reinterpret_cast<const T*>(p.x);
     const T* gr = reinterpret_cast<const T*>(p.g);
@@ -1152,7 +1160,7 @@ __global__ __launch_bounds__(256) void lp_conv_wgrad_kernel(LpWgP p, int tiles_p
 #pragma unroll
     for (int t = 0; t < NTAP; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     // live 8-channel halves of the two images (a shifted half is always live)
-    const int nchx = SM == 2 ? 2 : min(2, (p.cin_p - cit * 16) >> 3), nchg = SN == 2 ? 2 : min(2, (p.cout_p - cot * 16) >> 3);
+    const int nchx = SM == 2 ? 2 : min(2, (p.cin_p - cit * 16) >> 3), nchg = (SN == 2 || UP) ? 2 : min(2, (p.cout_p - cot * 16) >> 3);
     int tile = blockIdx.x * tiles_per_block;
     const int tile_end = min(p.ntiles, tile + tiles_per_block);
     // software pipeline: the NEXT box's global loads are in flight (in registers) while this box's taps run
@@ -1182,7 +1190,8 @@ __global__ __launch_bounds__(256) void lp_conv_wgrad_kernel(LpWgP p, int tiles_p
         const int tw = v % BW, t2 = v / BW, th = t2 % TH, td = t2 / TH;
         // SN = 2: half 1 = channels 0..7 of the voxel one step BACK in w
         const int sw = (SN == 2 && c == 1) ? -1 : 0, cc = (SN == 2 || !live) ? 0 : c;
-        goff[u] = (((td * p.H + th) * p.W + tw + sw) * p.g_cs + cot * 16 + cc * 8) * (int)sizeof(T);
+        if (UP) goff[u] = (((2 * td * gH + 2 * th) * gW + 2 * tw + c) * p.g_cs) * (int)sizeof(T);      // half c = fine voxel 2 tw + c
+        else goff[u] = (((td * p.H + th) * p.W + tw + sw) * p.g_cs + cot * 16 + cc * 8) * (int)sizeof(T);
         glive |= live ? (1u << u) : 0u;
     }
     auto load_box = [&](int tl) {
@@ -1196,7 +1205,8 @@ __global__ __launch_bounds__(256) void lp_conv_wgrad_kernel(LpWgP p, int tiles_p
         // uniform: the whole haloed box (and the gradient box) lies inside the volume
         if (dlo >= 0 && dlo + HD <= p.D && hlo >= 0 && hlo + HH <= p.H && wlo >= 0 && wlo + HW <= p.W) {
             const char* xb = reinterpret_cast<const char*>(x + ((((size_t)n * p.D + dlo) * p.H + hlo) * p.W + wlo) * p.x_cs);
-            const char* gb = reinterpret_cast<const char*>(gr + ((((size_t)n * p.D + d0) * p.H + h0) * p.W + w0) * p.g_cs);
+            const char* gb = UP ? reinterpret_cast<const char*>(gr + ((((size_t)n * 2 * p.D + 2 * d0 + upz) * gH + 2 * h0 + upy) * gW + 2 * w0) * p.g_cs)
+                                : reinterpret_cast<const char*>(gr + ((((size_t)n * p.D + d0) * p.H + h0) * p.W + w0) * p.g_cs);
 #pragma unroll
             for (int u = 0; u < NX; ++u) rx[u] = *reinterpret_cast<const uint4*>(xb + xoff[u]);
 #pragma unroll
@@ -1228,8 +1238,9 @@ __global__ __launch_bounds__(256) void lp_conv_wgrad_kernel(LpWgP p, int tiles_p
             const int gd = d0 + td, gh = h0 + th, gw = w0 + tw - ((SN == 2 && c == 1) ? 1 : 0);
             const bool ok = c < nchg && gd < p.D && gh < p.H && gw >= 0 && gw < p.W;
             const int cd = min(gd, p.D - 1), chh = min(gh, p.H - 1), cw = min(max(gw, 0), p.W - 1);
-            const uint4 r = *reinterpret_cast<const uint4*>(gr + ((((size_t)n * p.D + cd) * p.H + chh) * p.W + cw) * p.g_cs + cot * 16 +
-                                                            ((SN == 1 && c < nchg) ? c : 0) * 8);
+            const uint4 r = UP ? *reinterpret_cast<const uint4*>(gr + ((((size_t)n * 2 * p.D + 2 * cd + upz) * gH + 2 * chh + upy) * gW + 2 * cw + c) * p.g_cs)
+                               : *reinterpret_cast<const uint4*>(gr + ((((size_t)n * p.D + cd) * p.H + chh) * p.W + cw) * p.g_cs + cot * 16 +
+                                                                 ((SN == 1 && c < nchg) ? c : 0) * 8);
             rg[u] = ok ? r : make_uint4(0u, 0u, 0u, 0u);
         }
     };
@@ -1277,14 +1288,15 @@ __global__ __launch_bounds__(256) void lp_conv_wgrad_kernel(LpWgP p, int tiles_p
             }
             // taps in groups (k = 3: the 9 taps of one kd plane, k = 5: the 5 of one kh row): the NEXT group's transposed
             // fragment reads are issued before this group's MFMAs, so a tap no longer pays its own LDS latency
-            constexpr int GT = (KS == 3) ? (QN == 3 ? 9 : 3 * QN) : KS, NGRP = NTAP / GT;
+            constexpr int GT = UP ? 6 : ((KS == 3) ? (QN == 3 ? 9 : 3 * QN) : KS), NGRP = NTAP / GT;
             static_assert(NTAP % GT == 0, "tap groups");
             typedef short s16x8 __attribute__((ext_vector_type(8)));
             auto read_grp = [&](int grp, s16x8 (&fr)[GT]) {
 #pragma unroll
                 for (int j = 0; j < GT; ++j) {
-                    const int t = grp * GT + j, row = t / QN, kw = lp_wg_t0(KS, SM, SN, t % QN);     // (kw = the w offset t0)
-                    const int kdd = (KS == 3) ? row / 3 : 0, kh = (KS == 3) ? row % 3 : row;
+                    const int t = grp * GT + j, row = t / QN, kw = UP ? t % 3 : lp_wg_t0(KS, SM, SN, t % QN);     // (kw = the w offset t0)
+                    // UP: tap (dz, dy, dxx) of the sub-cube that starts at (p_d, p_h, 0): halo rows upz + dz, upy + dy
+                    const int kdd = UP ? upz + (row >> 1) : ((KS == 3) ? row / 3 : 0), kh = UP ? upy + (row & 1) : ((KS == 3) ? row % 3 : row);
                     const int to = ((kdd * HH + kh) * HW + kw) * WG_SX;
                     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sX + xa[0] + xo + to));
                     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sX + xa[1] + xo + to));
@@ -1405,6 +1417,47 @@ int lp_wgrad_launch(LpWgP& p, int gx, int tpb, int pairs, hipStream_t st) {
     lp_conv_wgrad_kernel<T, KS, BW, SM, SN><<<dim3(gx, pairs, KS == 3 ? 1 : KS), 256, lds, st>>>(p, tpb);
     CTU_CHECK_LAUNCH("lp_conv3d_wgrad");
     return CTU_OK;
+}
+
+// fused up-convolution (UP = 2): COARSE boxes 4 x TH x BW, blockIdx.y = (p_d, p_h) parity x input-channel tile
+template <class T, int BW>
+int lp_upwg_launch(LpWgP& p, int gx, int tpb, hipStream_t st) {
+    constexpr int RPK = 32 / BW, TH = 4 * RPK, HV = 6 * (TH + 2) * (BW + 2), NV = 4 * TH * BW;
+    size_t lds = 128 + (size_t)(HV + NV) * WG_SX;
+    if (lds < 128 + (size_t)12 * 1024) lds = 128 + (size_t)12 * 1024;
+    static size_t raised = 64 * 1024;
+    if (lds > raised) {
+        CTU_REQUIRE(hipFuncSetAttribute((const void*)lp_conv_wgrad_kernel<T, 3, BW, 1, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess,
+                    "lp_upconv_fused_wgrad: cannot raise the dynamic LDS limit");
+        raised = lds;
+    }
+    lp_conv_wgrad_kernel<T, 3, BW, 1, 1, 2><<<dim3(gx, 4 * (p.cin_p >> 4)), 256, lds, st>>>(p, tpb);
+    CTU_CHECK_LAUNCH("lp_upconv_fused_wgrad");
+    return CTU_OK;
+}
+
+// dW_eff[(pz,py,px)][(dz,dy,dxx-px)][cin_p][8] from the slabs [12 taps][16 ci][16 = (px, co)] (= conv3d.hip's
+// upconv_wgrad_reduce_pw_kernel for the 16-bit kernel's slabs)
+__global__ __launch_bounds__(1024) void lp_upwg_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dweff, int cin_p, int n_ci_g,
+                                                             int gx) {
+    __shared__ float red[16][64];
+    const int e = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int el = blockIdx.x * 64 + e;                             // element of the [12][16][16] slab
+    const int yb = blockIdx.y;                                      // par4 * n_ci_g + cig
+    float s = 0.f;
+    const float* src = ws + (size_t)yb * gx * (12 * 256) + el;
+    for (int k = part; k < gx; k += 16) s += src[(size_t)k * (12 * 256)];
+    red[part][e] = s;
+    __syncthreads();
+    if (part != 0) return;
+    float tot = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) tot += red[q][e];
+    const int t = el >> 8, i = (el >> 4) & 15, j = el & 15;
+    const int cig = yb % n_ci_g, par4 = yb / n_ci_g;
+    const int px = j >> 3, co = j & 7, jx = t % 3 - px, rp = cig * 16 + i;
+    if ((jx == 0 || jx == 1) && rp < cin_p)
+        dweff[((size_t)((par4 * 2 + px) * 8 + (t / 3) * 2 + jx) * cin_p + rp) * 8 + co] = tot;
 }
 
 // 8-channel sides of volumes at least 16 wide take the (w-shift, channel) tiles
@@ -1542,6 +1595,46 @@ extern "C" int ctu_lp_conv3d_wgrad(int dtype, const void* in, int in_cs, int cin
     }
 #undef CTU_LP_WG_REDUCE
     CTU_CHECK_LAUNCH("lp_conv3d_wgrad reduce");
+    return CTU_OK;
+}
+
+// ---- 16-bit fused decoder up-convolution (upconv_lp.hip): weight gradient w.r.t. the composite weights.  in = COARSE
+// activations (lazy transform), gout = fine-grid gradient of the fused op's raw output (8 padded channels, channel stride 8),
+// dweff fp32 [8][8][cin_p][8] for ctu_lp_upconv_fused_project.  N, D, H, W: COARSE dims; cin_p a multiple of 16.
+static void lp_upwg_geom(int N, int D, int H, int W, int cin_p, int* gx, int* tpb) {
+    LpWgP p;
+    const int ntiles = lp_wg_fill(p, N, D, H, W);
+    lp_wg_grid(ntiles, 4 * (cin_p >> 4), gx, tpb);
+}
+extern "C" size_t ctu_lp_upconv_fused_wgrad_ws_floats(int N, int D, int H, int W, int cin_p) {
+    int gx, tpb;
+    lp_upwg_geom(N, D, H, W, cin_p, &gx, &tpb);
+    return (size_t)gx * 4 * (cin_p >> 4) * 12 * 256;
+}
+extern "C" int ctu_lp_upconv_fused_wgrad(int dtype, const void* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
+                                         int in_relu, const void* gout, int g_cs, float* dweff, float* ws, int N, int D, int H,
+                                         int W, void* stream) {
+    CTU_REQUIRE(in && gout && dweff && ws, "lp_upconv_fused_wgrad: null pointer");
+    CTU_REQUIRE(cin_p >= 16 && cin_p % 16 == 0 && in_cs >= cin_p && in_cs % 8 == 0 && g_cs == 8 && ((uintptr_t)in & 15) == 0 &&
+                ((uintptr_t)gout & 15) == 0, "lp_upconv_fused_wgrad: cin_p=%d in_cs=%d g_cs=%d (gradient stride must be 8)", cin_p, in_cs, g_cs);
+    CTU_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "lp_upconv_fused_wgrad: scale/shift come in pairs");
+    LpWgP p{};
+    p.x = in; p.g = gout; p.scale = in_scale; p.shift = in_shift; p.ws = ws;
+    p.x_cs = in_cs; p.cin_p = cin_p; p.relu = in_relu; p.g_cs = g_cs; p.cout_p = 16;
+    lp_wg_fill(p, N, D, H, W);
+    int gx, tpb;
+    lp_upwg_geom(N, D, H, W, cin_p, &gx, &tpb);
+    hipStream_t st = (hipStream_t)stream;
+    const int bw = lp_wg_box_w(W);
+    int rc = CTU_OK;
+    CTU_DISPATCH_LP(dtype, {
+        if (bw == 32) rc = lp_upwg_launch<T, 32>(p, gx, tpb, st);
+        else if (bw == 16) rc = lp_upwg_launch<T, 16>(p, gx, tpb, st);
+        else rc = lp_upwg_launch<T, 8>(p, gx, tpb, st);
+    });
+    if (rc != CTU_OK) return rc;
+    lp_upwg_reduce_kernel<<<dim3(12 * 256 / 64, 4 * (cin_p >> 4)), 1024, 0, st>>>(ws, dweff, cin_p, cin_p >> 4, gx);
+    CTU_CHECK_LAUNCH("lp_upconv_fused_wgrad reduce");
     return CTU_OK;
 }
 

@@ -744,7 +744,8 @@ __global__ __launch_bounds__(1024) void upconv_beff_kernel(const float* __restri
 // plane, t=2 the last) -- built from 27 box sums T[sel] (each axis: all / first plane / last plane).
 constexpr int FS_SPLIT = 16;      // blocks per face / edge / corner selection (the full-volume sum goes through ctu_channel_sum)
 
-__global__ __launch_bounds__(256) void upconv_face_sums_kernel(const float* __restrict__ dy, int cs, int cp, int N, int Df, int Hf,
+template <class T>
+__global__ __launch_bounds__(256) void upconv_face_sums_kernel(const T* __restrict__ dy, int cs, int cp, int N, int Df, int Hf,
                                                                int Wf, float* __restrict__ tpart) {
     const int sel = blockIdx.x + 1;                               // (sz*3 + sy)*3 + sx, 0 all / 1 first / 2 last; sel 0 is not computed here
     const int sz = sel / 9, sy = (sel / 3) % 3, sx = sel % 3;
@@ -760,7 +761,7 @@ __global__ __launch_bounds__(256) void upconv_face_sums_kernel(const float* __re
         const int y = y0 + (int)(r % ny); r /= ny;
         const int z = z0 + (int)(r % nz);
         const int n = (int)(r / nz);
-        const float4 g = *reinterpret_cast<const float4*>(dy + ((((size_t)n * Df + z) * Hf + y) * Wf + x) * cs + qd * 4);
+        const float4 g = ld4<T>(dy + ((((size_t)n * Df + z) * Hf + y) * Wf + x) * cs + qd * 4);
         acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
     }
     __shared__ float4 red[256];
@@ -1007,9 +1008,12 @@ extern "C" size_t ctu_upconv_fused_project_ws_floats(int nout_p, int64_t fine_nv
 // dweff: [8][8][cin_p][nout_p] from ctu_upconv_fused_wgrad; gout: fine-grid gradient w.r.t. the fused op's RAW output
 // [N,2D,2H,2W,g_cs]; pack_ws: the scratch ctu_upconv_fused_pack filled this step (transposed weights); imap: logical input
 // channel -> padded position (NULL = identity).  Outputs in torch layouts: dwt [C][C][2][2][2], dbt [C], dw3 [Co][C][3][3][3].
-extern "C" int ctu_upconv_fused_project(const float* dweff, const float* gout, int g_cs, int nout_p, int N, int D, int H, int W,
-                                        const float* bt, const float* pack_ws, const int32_t* imap, int C, int Co, int cin_p,
-                                        float* dwt, float* dbt, float* dw3, float* ws, void* stream) {
+extern "C" int ctu_lp_channel_sum(int dtype, const void* x, int cs, int cp, int64_t nvox, float* partials, float* out, int C, void* stream);
+
+// dtype 0: gout is fp32; CTU_BF16 / CTU_F16: a 16-bit gradient tensor (the 16-bit path's ctu_lp_upconv_fused_project)
+static int upconv_project_impl(int dtype, const float* dweff, const void* gout, int g_cs, int nout_p, int N, int D, int H, int W,
+                               const float* bt, const float* pack_ws, const int32_t* imap, int C, int Co, int cin_p,
+                               float* dwt, float* dbt, float* dw3, float* ws, void* stream) {
     CTU_REQUIRE(dweff && gout && bt && pack_ws && dwt && dbt && dw3 && ws, "upconv_fused_project: null pointer");
     CTU_REQUIRE(nout_p == 8 || nout_p == 16 || nout_p == 32 || nout_p == 64, "upconv_fused_project: nout_p=%d", nout_p);
     CTU_REQUIRE(C > 0 && Co > 0 && Co <= nout_p && g_cs >= nout_p && g_cs % 4 == 0, "upconv_fused_project: bad channels");
@@ -1020,9 +1024,16 @@ extern "C" int ctu_upconv_fused_project(const float* dweff, const float* gout, i
     float* tall = V + (size_t)27 * nout_p;
     float* csp = tall + nout_p;
     const int64_t fvox = (int64_t)N * 8 * D * H * W;
-    int rc = ctu_channel_sum(gout, g_cs, nout_p, fvox, csp, tall, nout_p, stream);          // full-volume sum per channel
-    if (rc != CTU_OK) return rc;
-    upconv_face_sums_kernel<<<dim3(26, FS_SPLIT), 256, 0, st>>>(gout, g_cs, nout_p, N, 2 * D, 2 * H, 2 * W, tpart);
+    int rc;
+    if (dtype == 0) {
+        rc = ctu_channel_sum((const float*)gout, g_cs, nout_p, fvox, csp, tall, nout_p, stream);          // full-volume sum per channel
+        if (rc != CTU_OK) return rc;
+        upconv_face_sums_kernel<float><<<dim3(26, FS_SPLIT), 256, 0, st>>>((const float*)gout, g_cs, nout_p, N, 2 * D, 2 * H, 2 * W, tpart);
+    } else {
+        rc = ctu_lp_channel_sum(dtype, gout, g_cs, nout_p, fvox, csp, tall, nout_p, stream);
+        if (rc != CTU_OK) return rc;
+        CTU_DISPATCH_LP(dtype, upconv_face_sums_kernel<T><<<dim3(26, FS_SPLIT), 256, 0, st>>>((const T*)gout, g_cs, nout_p, N, 2 * D, 2 * H, 2 * W, tpart));
+    }
     CTU_CHECK_LAUNCH("upconv_face_sums");
     upconv_v_kernel<<<ceil_div(27 * nout_p, 64), 64, 0, st>>>(tpart, tall, nout_p, V);
     CTU_CHECK_LAUNCH("upconv_v");
@@ -1032,6 +1043,18 @@ extern "C" int ctu_upconv_fused_project(const float* dweff, const float* gout, i
     upconv_project_kernel<<<ceil_div(total, 256), 256, 0, st>>>(dweff, V, wtt, w3t, bt, imap, C, Co, cin_p, nout_p, dwt, dw3, dbt);
     CTU_CHECK_LAUNCH("upconv_project");
     return CTU_OK;
+}
+
+extern "C" int ctu_upconv_fused_project(const float* dweff, const float* gout, int g_cs, int nout_p, int N, int D, int H, int W,
+                                        const float* bt, const float* pack_ws, const int32_t* imap, int C, int Co, int cin_p,
+                                        float* dwt, float* dbt, float* dw3, float* ws, void* stream) {
+    return upconv_project_impl(0, dweff, gout, g_cs, nout_p, N, D, H, W, bt, pack_ws, imap, C, Co, cin_p, dwt, dbt, dw3, ws, stream);
+}
+extern "C" int ctu_lp_upconv_fused_project(int dtype, const float* dweff, const void* gout, int g_cs, int nout_p, int N, int D, int H,
+                                           int W, const float* bt, const float* pack_ws, const int32_t* imap, int C, int Co, int cin_p,
+                                           float* dwt, float* dbt, float* dw3, float* ws, void* stream) {
+    CTU_REQUIRE(dtype == CTU_BF16 || dtype == CTU_F16, "lp_upconv_fused_project: dtype %d", dtype);
+    return upconv_project_impl(dtype, dweff, gout, g_cs, nout_p, N, D, H, W, bt, pack_ws, imap, C, Co, cin_p, dwt, dbt, dw3, ws, stream);
 }
 
 // ---- fused data gradient: gin (coarse) from the fine-grid gradient of the fused op's raw output

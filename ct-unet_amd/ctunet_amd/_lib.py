@@ -117,6 +117,15 @@ SIGNATURES = {
     "ctu_hausdorff": (I, [P, P, I, I, I, I, I, P, P, P]),
     "ctu_extract_patches": (I, [P, P, I, I, I, I, I, I, I, I, P, P]),
     "ctu_stitch_patches": (I, [P, P, I, I, I, I, I, I, I, I, P, P]),
+    "ctu_lp_upconv_fused_supported": (I, [I, I, I, I, I, I]),
+    "ctu_lp_upconv_fused_packed_elems": (Z, [I]),
+    "ctu_lp_upconv_fused_num_blocks": (I, [I, I, I, I]),
+    "ctu_lp_upconv_fused_pack": (I, [I, P, I, P, P]),
+    "ctu_lp_upconv_fused_fwd": (I, [I, P, I, I, P, P, I, P, P, P, I, P, I, I, I, I, P]),
+    "ctu_lp_upconv_fused_wgrad_ws_floats": (Z, [I, I, I, I, I]),
+    "ctu_lp_upconv_fused_wgrad": (I, [I, P, I, I, P, P, I, P, I, P, P, I, I, I, I, P]),
+    "ctu_lp_upconv_fused_project": (I, [I, P, P, I, I, I, I, I, I, P, P, P, I, I, I, P, P, P, P, P]),
+    "ctu_lp_upconv_fused_bwd_data": (I, [I, P, I, P, P, I, I, I, I, I, I, P]),
     "ctu_lp_conv3d_packed_elems": (Z, [I, I, I]),
     "ctu_lp_conv3d_num_blocks": (I, [I, I, I, I, I, I]),
     "ctu_lp_pack_conv3d_weight": (I, [I, P, P, I, I, I, P, I, I, I, P]),

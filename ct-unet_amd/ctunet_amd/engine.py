@@ -34,9 +34,9 @@ FUSE_UP = os.environ.get("CTUNET_FUSE_UP", "1") != "0"
 FUSE_UP_MAX_CO = int(os.environ.get("CTUNET_FUSE_UP_MAXCO", "16"))     # widest (padded) conv output that takes the fused path
 # the max-pool backward also emits the BatchNorm-backward reduction of the layer it pools (CTUNET_POOL_BN=0: separate pass)
 POOL_BN = os.environ.get("CTUNET_POOL_BN", "1") != "0"
-# 16-bit path: the fused decoder up-convolutions (fp32 kernels; there is no 16-bit port of them yet) run on fp32 copies of their
-# operands -- an up-block then costs the fp32 fused kernels + four cast passes instead of the unfused 16-bit ConvTranspose3d and
-# Conv3d kernels (top level of UNet() 128^3 bf16: 720 -> ~460 us).  CTUNET_LP_FUSE_UP=0: the unfused 16-bit kernels.
+# 16-bit path: the decoder's top-level up-convolution (8 padded output channels, input channels a multiple of 32) runs through the
+# 16-bit fused kernels of upconv_lp.hip; every other level takes the unfused 16-bit ConvTranspose3d + Conv3d kernels.
+# CTUNET_LP_FUSE_UP=0: the unfused kernels everywhere.
 LP_FUSE_UP = os.environ.get("CTUNET_LP_FUSE_UP", "1") != "0"
 BN_MOMENTUM = 0.1
 # BatchNorm + ReLU backward applied by the weight-gradient kernel while it stages the gradient (ops.conv3d_wgrad_bn) instead
@@ -75,7 +75,7 @@ class NetPlan:
 
 class _ConvRec:
     """What one conv+BN stage leaves behind for backward."""
-    __slots__ = ("x", "y", "vec", "stats", "nblk", "conv", "bn", "cin", "cout", "imap", "bias", "first", "x32")
+    __slots__ = ("x", "y", "vec", "stats", "nblk", "conv", "bn", "cin", "cout", "imap", "bias", "first")
 
 
 class UNetEngine:
@@ -219,8 +219,11 @@ class UNetEngine:
     def _fuse_up(self, x: CL, nout_p: int) -> bool:
         """Run ConvTranspose3d -> Conv3d of a decoder block as one coarse-grid kernel (ops.upconv_fused_fwd)?
         Levels whose first conv has at most 16 (padded) output channels: they hold the FLOPs and have enough boxes."""
-        return ((self.dtype == torch.float32 or LP_FUSE_UP) and self.plan.k == 3 and not self.plan.conv_bias
-                and nout_p <= FUSE_UP_MAX_CO and FUSE_UP and ops.upconv_fused_supported(x.dims, 3, x.cp, nout_p))
+        if not (self.plan.k == 3 and not self.plan.conv_bias and nout_p <= FUSE_UP_MAX_CO and FUSE_UP):
+            return False
+        if self.dtype == torch.float32:
+            return ops.upconv_fused_supported(x.dims, 3, x.cp, nout_p)
+        return LP_FUSE_UP and ops.lp_upconv_fused_supported(x.dims, 3, x.cp, nout_p)
 
     def _upconv_bn(self, P, x: CL, prefix: str, ct: int, cout: int, cinv, out: CL, vec4: torch.Tensor, training: bool,
                    n_upd: int, save: bool) -> Tuple[CL, Optional[_ConvRec]]:
@@ -228,42 +231,40 @@ class UNetEngine:
         The record's input (the transposed conv's output) is NOT materialised: backward recomputes it (rec.x None)."""
         conv, bn = f"{prefix}.1", f"{prefix}.2"
         wt, bt, w3 = P[f"{prefix}.0.weight"], P[f"{prefix}.0.bias"], P[conv + ".weight"]
-        out16 = None
-        if x.lp:
-            # 16-bit path: the fused kernels are fp32 -- run them on an fp32 copy of the coarse input (the whole, possibly
-            # concatenated, buffer; the lazy BatchNorm vectors are fp32 already) into an fp32 output, which is cast (RNE) into
-            # the 16-bit tensor the rest of the net reads.  The BatchNorm sums are those of the fp32 values.
-            out16 = out
-            x = CL(x.buf.float(), x.c0, x.cp, x.scale, x.shift, x.relu)
-            out = CL(torch.empty(out16.dims + (out16.cp,), dtype=torch.float32, device=x.buf.device), 0, out16.cp)
+        lp = bool(x.lp)                    # 16-bit: the composite is still built in fp32 and rounded once into 16-bit fragments
         ver = tuple((t._version, t.data_ptr()) for t in (wt, bt, w3))
         hit = self._up_cache.get(prefix)
-        if hit is None or hit[0] != ver or hit[3] != (x.cp, out.cp) or torch.cuda.is_current_stream_capturing():
-            same = hit is not None and hit[3] == (x.cp, out.cp)
+        if hit is None or hit[0] != ver or hit[3] != (x.cp, out.cp, self.dtype) or torch.cuda.is_current_stream_capturing():
+            same = hit is not None and hit[3] == (x.cp, out.cp, self.dtype)
             wp, beff, pws = ops.upconv_fused_pack(wt, bt, w3, cinv, x.cp, out.cp, (hit[1], hit[2], hit[4]) if same else None)
-            wpd = ops.upconv_fused_pack_bwd(wp, x.cp, out.cp, hit[5] if same else None)      # same weights, data-gradient order
-            self._up_cache[prefix] = (ver, wp, beff, (x.cp, out.cp), pws, wpd)
+            if lp:
+                wpd = ops.lp_upconv_fused_pack(wp, x.cp, self.dtype, hit[5] if same else None)      # forward + data-gradient fragments
+            else:
+                wpd = ops.upconv_fused_pack_bwd(wp, x.cp, out.cp, hit[5] if same else None)          # same weights, data-gradient order
+            self._up_cache[prefix] = (ver, wp, beff, (x.cp, out.cp, self.dtype), pws, wpd)
         else:
-            wp, beff = hit[1], hit[2]
+            wp, beff, wpd = hit[1], hit[2], hit[5]
         nvox = 8 * x.nvox
         if training:
-            nblk = ops.upconv_fused_num_blocks(x.dims, out.cp)
+            nblk = ops.lp_upconv_fused_num_blocks(x.dims) if lp else ops.upconv_fused_num_blocks(x.dims, out.cp)
             stats = torch.empty((nblk, 2, out.cp), dtype=torch.float32, device=x.buf.device)
-            tail = self._fwd_tail(P, bn, cout, nvox, n_upd, vec4, x.buf.device)
-            ops.upconv_fused_fwd(x, wp, beff, out, stats, (ct, cout), tail)
+            tail = None if lp else self._fwd_tail(P, bn, cout, nvox, n_upd, vec4, x.buf.device)
+            if lp:
+                ops.lp_upconv_fused_fwd(x, wpd, beff, out, stats, (ct, cout))
+            else:
+                ops.upconv_fused_fwd(x, wp, beff, out, stats, (ct, cout), tail)
             if tail is None:
                 ops.bn_finalize_into(stats, nblk, cout, out.cp, nvox, P[bn + ".weight"], P[bn + ".bias"],
                                      P[bn + ".running_mean"], P[bn + ".running_var"], BN_MOMENTUM, BN_EPS, n_upd, vec4,
                                      P.get(bn + ".num_batches_tracked") if n_upd else None)
         else:
             stats, nblk = None, 0
-            ops.upconv_fused_fwd(x, wp, beff, out, None, (ct, cout))
+            if lp:
+                ops.lp_upconv_fused_fwd(x, wpd, beff, out, None, (ct, cout))
+            else:
+                ops.upconv_fused_fwd(x, wp, beff, out, None, (ct, cout))
             ops.bn_eval_affine_into(P[bn + ".weight"], P[bn + ".bias"], P[bn + ".running_mean"],
                                     P[bn + ".running_var"], BN_EPS, cout, out.cp, vec4)
-        x32 = None
-        if out16 is not None:
-            out16.buf[..., out16.c0:out16.c0 + out16.cp].copy_(out.buf)
-            x32, out = x, out16
         y = out.with_xf(vec4[0], vec4[1], True)
         rec = None
         if save:
@@ -271,7 +272,6 @@ class UNetEngine:
             rec.first = None
             rec.x, rec.y, rec.vec, rec.stats, rec.nblk = None, out.raw(), vec4, stats, nblk
             rec.conv, rec.bn, rec.cin, rec.cout, rec.imap, rec.bias = conv, bn, ct, cout, None, False
-            rec.x32 = x32                                # 16-bit path: the fp32 copy of the coarse input, for backward
         return y, rec
 
     def _first_conv_bn(self, P, x: torch.Tensor, conv: str, bn: str, cin: int, cout: int, out: CL, vec4: torch.Tensor,
@@ -622,20 +622,21 @@ class UNetEngine:
                 # then the gradients of BOTH layers' parameters from the composite-weight gradient of (coarse input, g_u1)
                 # and the data gradient straight back to the coarse grid
                 lz = self._conv_bn_bwd(P, r1, g_u1, None, grads, ws, part, up_in=x_in)
-                xq, gq, ginq = x_in, g_u1, gin
-                if g_u1.lp:                           # 16-bit path: fp32 copies around the fp32 fused kernels (see _upconv_bn)
-                    xq = r1.x32
-                    gq = CL(g_u1.buf.float(), g_u1.c0, g_u1.cp)
-                    ginq = CL(torch.empty(gin.dims + (gin.cp,), dtype=torch.float32, device=dev), 0, gin.cp)
-                dwt, dbt, dw3 = ops.upconv_fused_wgrad(xq, gq, ct, blk.cout, P[f"{blk.prefix}.0.bias"],
-                                                       self._up_cache[blk.prefix][4], imap_t, lz)
-                if lz is not None:
-                    gq = lz[3]                        # the raw-output gradient the weight-gradient kernel wrote
+                gq = g_u1
+                if g_u1.lp:                           # 16-bit fused kernels (upconv_lp.hip)
+                    dwt, dbt, dw3 = ops.lp_upconv_fused_wgrad(x_in, gq, ct, blk.cout, P[f"{blk.prefix}.0.bias"],
+                                                              self._up_cache[blk.prefix][4], imap_t)
+                else:
+                    dwt, dbt, dw3 = ops.upconv_fused_wgrad(x_in, gq, ct, blk.cout, P[f"{blk.prefix}.0.bias"],
+                                                           self._up_cache[blk.prefix][4], imap_t, lz)
+                    if lz is not None:
+                        gq = lz[3]                    # the raw-output gradient the weight-gradient kernel wrote
                 grads[f"{blk.prefix}.1.weight"] = dw3
                 grads[f"{blk.prefix}.0.weight"], grads[f"{blk.prefix}.0.bias"] = dwt, dbt
-                ops.upconv_fused_bwd_data(gq, self._up_cache[blk.prefix][5], ginq, (ct, blk.cout))
-                if ginq is not gin:
-                    gin.buf[..., gin.c0:gin.c0 + gin.cp].copy_(ginq.buf)
+                if g_u1.lp:
+                    ops.lp_upconv_fused_bwd_data(gq, self._up_cache[blk.prefix][5], gin, (ct, blk.cout))
+                else:
+                    ops.upconv_fused_bwd_data(gq, self._up_cache[blk.prefix][5], gin, (ct, blk.cout))
             else:
                 g_up = CL(torch.empty_like(up.buf), 0, up.cp)
                 self._conv_bn_bwd(P, r1, g_u1, g_up, grads, ws, part)

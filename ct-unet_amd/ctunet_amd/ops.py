@@ -932,6 +932,84 @@ def upconv_fused_wgrad(x: CL, g: CL, c: int, co: int, bt: torch.Tensor, pack_ws:
     return dwt, dbt, dw3
 
 
+# ---- 16-bit twins (upconv_lp.hip): 8 padded output channels, input channels a multiple of 32
+def lp_upconv_fused_supported(dims, k: int, cin_p: int, nout_p: int) -> bool:
+    n, d, h, w = dims
+    return bool(_lib.load().ctu_lp_upconv_fused_supported(k, d, h, w, cin_p, nout_p))
+
+
+def lp_upconv_fused_pack(wp32: torch.Tensor, cin_p: int, dtype: torch.dtype, into: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """16-bit MFMA fragments (forward, then data gradient) of upconv_fused_pack's fp32 composite weights (nout_p = 8)."""
+    lib = _lib.load()
+    n = lib.ctu_lp_upconv_fused_packed_elems(cin_p)
+    wp16 = into if into is not None else torch.empty(n, dtype=dtype, device=wp32.device)
+    assert wp16.numel() == n and wp16.dtype == dtype
+    _lib.check(lib.ctu_lp_upconv_fused_pack(LP_CODE[dtype], wp32.data_ptr(), cin_p, wp16.data_ptr(), _stream()), "lp_upconv_fused_pack")
+    return wp16
+
+
+def lp_upconv_fused_num_blocks(dims) -> int:
+    n, d, h, w = dims
+    return _lib.load().ctu_lp_upconv_fused_num_blocks(n, d, h, w)
+
+
+def lp_upconv_fused_fwd(x: CL, wp16: torch.Tensor, beff: torch.Tensor, out: CL, stats: Optional[torch.Tensor],
+                        algo_ch: Optional[Tuple[int, int]] = None) -> None:
+    """out (fine grid, 16-bit, raw) = conv3(convT(act(x))) in one kernel; x = the COARSE 16-bit input."""
+    n, d, h, w = x.dims
+    assert out.dims == (n, 2 * d, 2 * h, 2 * w) and x.lp and out.dtype == x.dtype and wp16.dtype == x.dtype and out.cp == 8
+    lib = _lib.load()
+    t0 = TIMER.begin() if TIMER is not None else None
+    _lib.check(lib.ctu_lp_upconv_fused_fwd(x.lp, x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), wp16.data_ptr(),
+                                           beff.data_ptr(), out.ptr, out.cs, _ptr(stats), n, d, h, w, _stream()),
+               "lp_upconv_fused_fwd")
+    if t0 is not None:
+        ci, co = algo_ch if algo_ch is not None else (x.cp, out.cp)
+        vox = n * d * h * w
+        TIMER.end(f"lp_upconv_fwd_kernel<{'bf16' if x.lp == 1 else 'f16'}>", vox * (16.0 * ci * ci + 8 * 54.0 * ci * co),
+                  2.0 * vox * (x.cp + 8 * out.cp), t0, (w, x.cp, out.cp))
+
+
+def lp_upconv_fused_wgrad(x: CL, g: CL, c: int, co: int, bt: torch.Tensor, pack_ws: torch.Tensor, imap):
+    """(dWT, dbT, dW3) as upconv_fused_wgrad, from 16-bit tensors: x = COARSE input, g = fine-grid raw-output gradient."""
+    n, d, h, w = x.dims
+    assert g.dims == (n, 2 * d, 2 * h, 2 * w) and x.lp and g.dtype == x.dtype and g.cp == 8 and g.cs == 8
+    lib = _lib.load()
+    dev = x.buf.device
+    dweff = torch.empty((8, 8, x.cp, 8), dtype=torch.float32, device=dev)
+    ws = torch.empty(lib.ctu_lp_upconv_fused_wgrad_ws_floats(n, d, h, w, x.cp), dtype=torch.float32, device=dev)
+    t0 = TIMER.begin() if TIMER is not None else None
+    _lib.check(lib.ctu_lp_upconv_fused_wgrad(x.lp, x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), g.ptr, g.cs,
+                                             dweff.data_ptr(), ws.data_ptr(), n, d, h, w, _stream()), "lp_upconv_fused_wgrad")
+    if t0 is not None:
+        vox = n * d * h * w
+        TIMER.end(f"lp_upconv_wgrad_kernel<{'bf16' if x.lp == 1 else 'f16'}> (+slab reduce)", vox * (16.0 * c * c + 8 * 54.0 * c * co),
+                  2.0 * vox * (x.cp + 8 * g.cp), t0, (w, x.cp, g.cp))
+    dwt = torch.empty((c, c, 2, 2, 2), dtype=torch.float32, device=dev)
+    dbt = torch.empty(c, dtype=torch.float32, device=dev)
+    dw3 = torch.empty((co, c, 3, 3, 3), dtype=torch.float32, device=dev)
+    ws2 = torch.empty(lib.ctu_upconv_fused_project_ws_floats(g.cp, g.nvox), dtype=torch.float32, device=dev)
+    _lib.check(lib.ctu_lp_upconv_fused_project(x.lp, dweff.data_ptr(), g.ptr, g.cs, g.cp, n, d, h, w, bt.detach().data_ptr(),
+                                               pack_ws.data_ptr(), _ptr(imap), c, co, x.cp, dwt.data_ptr(), dbt.data_ptr(),
+                                               dw3.data_ptr(), ws2.data_ptr(), _stream()), "lp_upconv_fused_project")
+    return dwt, dbt, dw3
+
+
+def lp_upconv_fused_bwd_data(g: CL, wp16: torch.Tensor, gin: CL, algo_ch: Optional[Tuple[int, int]] = None) -> None:
+    """gin (coarse, 16-bit) <- gradient of the fused pair w.r.t. its activated input, from the fine-grid gradient g."""
+    n, d, h, w = gin.dims
+    assert g.dims == (n, 2 * d, 2 * h, 2 * w) and g.lp and gin.dtype == g.dtype and wp16.dtype == g.dtype and g.cp == 8
+    lib = _lib.load()
+    t0 = TIMER.begin() if TIMER is not None else None
+    _lib.check(lib.ctu_lp_upconv_fused_bwd_data(g.lp, g.ptr, g.cs, wp16.data_ptr(), gin.ptr, gin.cs, gin.cp, n, d, h, w, _stream()),
+               "lp_upconv_fused_bwd_data")
+    if t0 is not None:
+        ci, co = algo_ch if algo_ch is not None else (gin.cp, g.cp)
+        vox = n * d * h * w
+        TIMER.end(f"lp_upconv_bwd_data_kernel<{'bf16' if g.lp == 1 else 'f16'}>", vox * (16.0 * ci * ci + 8 * 54.0 * ci * co),
+                  2.0 * vox * (gin.cp + 8 * g.cp), t0, (w, gin.cp, g.cp))
+
+
 def upconv_fused_pack_bwd(wp: torch.Tensor, cin_p: int, nout_p: int, into: Optional[torch.Tensor] = None) -> torch.Tensor:
     lib = _lib.load()
     wpd = into if into is not None else torch.empty(lib.ctu_upconv_fused_bwd_packed_floats(cin_p, nout_p),

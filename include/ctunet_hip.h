@@ -477,6 +477,31 @@ int ctu_lp_convt2_wgrad(int dtype, const void* in, int in_cs, int cin_p, const f
                         int in_relu, const void* gout, int g_cs, int cout_p, float* dw, int Ci, int Co,
                         const int32_t* imap, float* ws, int N, int D, int H, int W, void* stream);
 /* HBM-bound glue: same kernels as the fp32 entry points, instantiated for 16-bit storage */
+/* 16-bit fused decoder up-convolution (upconv_lp.hip; ConvTranspose3d(C,C,2,2) -> Conv3d(C,Co<=8,3,p=1), models.py:37-38) on
+ * v_mfma_f32_16x16x32_{bf16,f16}: the twins of ctu_upconv_fused_fwd / _wgrad / _project / _bwd_data for 16-bit tensors.
+ * Supported: 8 padded output channels, input channels a multiple of 32, coarse width >= 16 (the decoder's top level of the
+ * shipped nets); other geometries take the unfused ctu_lp_convt2_* + ctu_lp_conv3d_* kernels.  N, D, H, W: COARSE dims.
+ *  pack ....... wp32 = ctu_upconv_fused_pack's fp32 packing (cin_p, nout_p = 8) -> wp16 [ctu_lp_upconv_fused_packed_elems]
+ *               (forward fragments, then data-gradient fragments), rounded once from the fp32 composite weights
+ *  fwd ........ out (fine grid, 8 channels, raw) + stats [ctu_lp_upconv_fused_num_blocks][2][8] of the ROUNDED outputs
+ *  wgrad ...... dweff fp32 [8][8][cin_p][8] (gradient channel stride must be 8); then ctu_lp_upconv_fused_project
+ *  bwd_data ... gin (coarse, cin_p channels) from the fine-grid raw-output gradient */
+int ctu_lp_upconv_fused_supported(int k, int D, int H, int W, int cin_p, int nout_p);
+size_t ctu_lp_upconv_fused_packed_elems(int cin_p);
+int ctu_lp_upconv_fused_num_blocks(int N, int D, int H, int W);
+int ctu_lp_upconv_fused_pack(int dtype, const float* wp32, int cin_p, void* wp16, void* stream);
+int ctu_lp_upconv_fused_fwd(int dtype, const void* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
+                            int in_relu, const void* wp16, const float* beff, void* out, int out_cs, float* stats,
+                            int N, int D, int H, int W, void* stream);
+size_t ctu_lp_upconv_fused_wgrad_ws_floats(int N, int D, int H, int W, int cin_p);
+int ctu_lp_upconv_fused_wgrad(int dtype, const void* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
+                              int in_relu, const void* gout, int g_cs, float* dweff, float* ws, int N, int D, int H,
+                              int W, void* stream);
+int ctu_lp_upconv_fused_project(int dtype, const float* dweff, const void* gout, int g_cs, int nout_p, int N, int D, int H,
+                                int W, const float* bt, const float* pack_ws, const int32_t* imap, int C, int Co, int cin_p,
+                                float* dwt, float* dbt, float* dw3, float* ws, void* stream);
+int ctu_lp_upconv_fused_bwd_data(int dtype, const void* gout, int g_cs, const void* wp16, void* gin, int gin_cs, int cin_p,
+                                 int N, int D, int H, int W, void* stream);
 int ctu_lp_ncdhw_to_ndhwc(int dtype, const float* src, void* dst, int N, int C, int D, int H, int W, int cp, int cs,
                           void* stream);
 int ctu_lp_ndhwc_to_ncdhw(int dtype, const void* src, float* dst, int N, int C, int D, int H, int W, int cs,

@@ -336,16 +336,25 @@ def _lowp_vs_oracle(cls, size, name, batch=1):
 
 
 @pytest.mark.parametrize("name", ["bf16", "fp16"])
-@pytest.mark.parametrize("cls", ["UNet", "UNetSP", "UNetSPSmall", "recAE_v2_fixed"])
-def test_lowp_nets_against_the_fp32_oracle(cls, name):
+@pytest.mark.parametrize("cls,fuse", [("UNet", True), ("UNet", False), ("UNetSP", True), ("UNetSP", False), ("UNetSPSmall", True),
+                                      ("recAE_v2_fixed", True)])
+def test_lowp_nets_against_the_fp32_oracle(cls, fuse, name):
     """Small patches, every class family: the 16-bit HIP path deviates from the fp32 oracle no more than the reference's
     own mixed-precision run does (the oracle graph under torch.autocast on the CPU, measured in the same test): output
     error, hard-segmentation Dice vs the CPU reference, loss, and the direction of every parameter gradient.
     Measured at 32^3 (UNet): autocast bf16 out 1.6e-2 / Dice 0.992 / cos 0.86, fp16 2.1e-3 / 0.9991 / 0.977; this path
     bf16 1.4e-2 / 0.994 / 0.89, fp16 1.7e-3 / 0.9991 / 0.985 -- at default initialisation the two output channels of most
     voxels differ by less than ONE layer's 16-bit storage error, so Dice 0.999 is out of reach of any bf16 pipeline here."""
-    r, y = _lowp_vs_oracle(cls, CLASS_INPUT[cls][1], name)
-    print(f"{cls} {name} hip {r}\n{cls} {name} autocast yardstick {y}")
+    # fuse: the decoder's top-level up-convolution through the 16-bit fused kernels (upconv_lp.hip, the default) or through the
+    # unfused 16-bit ConvTranspose3d + Conv3d kernels (CTUNET_LP_FUSE_UP=0) -- both routes stay covered by whole nets
+    from ctunet_amd import engine as E
+    old = E.LP_FUSE_UP
+    E.LP_FUSE_UP = fuse
+    try:
+        r, y = _lowp_vs_oracle(cls, CLASS_INPUT[cls][1], name)
+    finally:
+        E.LP_FUSE_UP = old
+    print(f"{cls} {name} fuse={fuse} hip {r}\n{cls} {name} autocast yardstick {y}")
     assert r["out_err"] <= 1.5 * y["out_err"] and r["loss_err"] <= max(3 * y["loss_err"], 2e-4), (r, y)
     assert r["dice"] >= y["dice"] - 0.004, (r, y)
     assert r["grad_cos_min"] >= y["grad_cos_min"] - 0.05 and r["dx_cos"] >= y["dx_cos"] - 0.05, (r, y)
@@ -378,3 +387,84 @@ def test_lowp_precision_switch_and_loss_scale():
         net.set_precision("int8")
     net.set_precision("fp32")
     assert torch.equal(net(x), y32)
+
+
+UPCONV_LP_CASES = [  # (C, Co, coarse NDHW, concat segments or None)
+    (32, 8, (1, 4, 4, 16), None),                       # one interior-free box: every voxel touches a face
+    (32, 8, (1, 8, 12, 32), None),                      # interior boxes, two boxes along w
+    (32, 7, (2, 6, 5, 20), None),                       # ragged boxes, 7 real output channels, batch 2
+    (64, 8, (1, 4, 8, 16), None),                       # two 32-channel stages
+    (28, 7, (1, 4, 4, 16), ((14, 0), (14, 16))),        # UNetSP widths: concat of two 14-channel halves in a 32-wide buffer
+]
+
+
+@pytest.mark.parametrize("name", ["bf16", "fp16"])
+@pytest.mark.parametrize("c,co,dims,segs", UPCONV_LP_CASES)
+def test_lp_fused_upconv_forward_backward(name, c, co, dims, segs):
+    """The 16-bit fused ConvTranspose3d -> Conv3d kernels (upconv_lp.hip) against fp64 torch autograd of the two unfused ops.
+    Operands are rounded to the 16-bit type first; the fused kernels additionally round the COMPOSITE weights (sums of up to 8
+    products of the two layers' weights over C channels) once, so the forward / data-gradient tolerance is a few 16-bit ulps
+    of the result's scale rather than one; the weight gradients (fp32 accumulation over the voxels) are held to 2e-3 of scale."""
+    ops = _ops()
+    dt = DT[name]
+    g = gen(hash((c, co, dims)) % 1000)
+    n, d, h, w = dims
+    cop = ops.pad8(co)
+    x = rnd(torch.randn(n, c, d, h, w, generator=g), dt)
+    wt = torch.randn(c, c, 2, 2, 2, generator=g) * (1.0 / c) ** 0.5
+    bt = torch.randn(c, generator=g) * 0.1
+    w3 = torch.randn(co, c, 3, 3, 3, generator=g) * (2.0 / (27 * c)) ** 0.5
+    if segs is None:
+        cp = ops.pad8(c)
+        xcl = to_cl(x, cp, dt)
+        cinv = imap = None
+        idx = list(range(c))
+    else:
+        cp = 32
+        buf = torch.zeros(n, d, h, w, cp)
+        cinv_l, idx, lo = [-1] * cp, [], 0
+        for cnt, start in segs:
+            buf[..., start:start + cnt] = x[:, lo:lo + cnt].permute(0, 2, 3, 4, 1)
+            for q in range(cnt):
+                cinv_l[start + q] = lo + q
+                idx.append(start + q)
+            lo += cnt
+        xcl = ops.CL(buf.to(dt).cuda(), 0, cp)
+        cinv = torch.tensor(cinv_l, dtype=torch.int32, device="cuda")
+        imap = torch.tensor(idx, dtype=torch.int32, device="cuda")
+    assert ops.lp_upconv_fused_supported(dims, 3, cp, cop)
+    sc = torch.zeros(cp); sh = torch.zeros(cp)
+    sc[idx] = torch.rand(c, generator=g) + 0.5
+    sh[idx] = torch.randn(c, generator=g) * 0.3
+    a = rnd(F.relu(x * sc[idx].view(1, -1, 1, 1, 1) + sh[idx].view(1, -1, 1, 1, 1)), dt)          # what the kernels stage
+    a64 = a.double().requires_grad_(True)
+    wt64, bt64, w364 = (t.double().requires_grad_(True) for t in (wt, bt, w3))
+    ref = F.conv3d(F.conv_transpose3d(a64, wt64, bt64, stride=2), w364, padding=1)
+    go = rnd(torch.randn(ref.shape, generator=g), dt)
+    ref.backward(go.double())
+    # ---- forward + BatchNorm partial sums
+    wp32, beff, pws = ops.upconv_fused_pack(wt.cuda(), bt.cuda(), w3.cuda(), cinv, cp, cop)
+    wp16 = ops.lp_upconv_fused_pack(wp32, cp, dt)
+    out = ops.CL(torch.full((n, 2 * d, 2 * h, 2 * w, cop), 3.0, dtype=dt).cuda(), 0, cop)
+    nblk = ops.lp_upconv_fused_num_blocks(dims)
+    stats = torch.zeros((nblk, 2, cop), dtype=torch.float32).cuda()
+    ops.lp_upconv_fused_fwd(xcl.with_xf(sc.cuda(), sh.cuda(), True), wp16, beff, out, stats)
+    got = from_cl(out, co)
+    scale = ref.detach().abs().max().item()
+    assert (got.double() - ref.detach()).abs().max().item() <= 6 * ULP[name] * scale
+    full = from_cl(out, cop)
+    assert cop == co or float(full[:, co:].abs().max()) == 0.0                                      # padded channel holds zeros
+    s = stats.sum(0).cpu()
+    assert torch.allclose(s[0, :co], got.sum((0, 2, 3, 4)), rtol=1e-4, atol=1e-2)                   # sums of the ROUNDED outputs
+    assert torch.allclose(s[1, :co], (got * got).sum((0, 2, 3, 4)), rtol=1e-4, atol=1e-2)
+    # ---- data gradient
+    gcl = to_cl(go, cop, dt)
+    gin = ops.CL(torch.full((n, d, h, w, cp), 5.0, dtype=dt).cuda(), 0, cp)
+    ops.lp_upconv_fused_bwd_data(gcl, wp16, gin)
+    dx = from_cl(gin, cp)[:, idx]
+    assert (dx.double() - a64.grad).abs().max().item() <= 6 * ULP[name] * a64.grad.abs().max().item()
+    # ---- parameter gradients
+    dwt, dbt, dw3 = ops.lp_upconv_fused_wgrad(xcl.with_xf(sc.cuda(), sh.cuda(), True), gcl, c, co, bt.cuda(), pws, imap)
+    for nm, gt, want in (("dWT", dwt, wt64.grad), ("dbT", dbt, bt64.grad), ("dW3", dw3, w364.grad)):
+        err = (gt.cpu().double() - want).abs().max().item()
+        assert err <= 2e-3 * want.abs().max().item(), (nm, err, want.abs().max().item())
