@@ -77,6 +77,34 @@ __global__ void lp_pack_conv_w_kernel(const float* __restrict__ w, T* __restrict
     lp_pack_conv_w_elem<T, KS>(blockIdx.x * blockDim.x + threadIdx.x, w, wp, Co, Ci, cinv, rin_p, nout_p, mode);
 }
 
+// "pair" layout (k = 3, 8 padded channels on both sides, volumes at least 32 wide; lp_conv_fwd_pair_kernel): a K-step = the 4 w
+// offsets kw' of one (kd, kh) row x 8 input channels, the 16 rows = (w-shift s, c_out): wp[ks = kd*3+kh][lane][8], element j of
+// lane l = W[co = l&7][ci = j][kd, kh, kw' - s] for s = (l>>3)&1, kw' = l>>4, 0 <= kw' - s <= 2 (else 0).  mode 1: the data
+// gradient's flipped / transposed weights in the same layout.
+constexpr int LP_PAIR_ELEMS = 9 * 512;
+template <class T>
+__device__ __forceinline__ void lp_pack_conv_pair_elem(int idx, const float* __restrict__ w, T* __restrict__ wp, int Co, int Ci,
+                                                       const int32_t* __restrict__ cinv, int mode) {
+    if (idx >= LP_PAIR_ELEMS) return;
+    const int j = idx & 7, lane = (idx >> 3) & 63, row = lane & 15, s = row >> 3, r8 = row & 7, kwp = lane >> 4;
+    const int ks = idx >> 9, kd = ks / 3, kh = ks % 3, kw = kwp - s;
+    float v = 0.f;
+    if (kw >= 0 && kw <= 2) {
+        if (mode == 0) {
+            const int ci = cinv ? cinv[j] : (j < Ci ? j : -1);
+            if (ci >= 0 && r8 < Co) v = w[((size_t)r8 * Ci + ci) * 27 + (kd * 3 + kh) * 3 + kw];
+        } else {
+            const int ci = cinv ? cinv[r8] : (r8 < Ci ? r8 : -1);
+            if (ci >= 0 && j < Co) v = w[((size_t)j * Ci + ci) * 27 + 26 - ((kd * 3 + kh) * 3 + kw)];
+        }
+    }
+    wp[idx] = (T)v;
+}
+template <class T>
+__global__ void lp_pack_conv_pair_kernel(const float* __restrict__ w, T* __restrict__ wp, int Co, int Ci, const int32_t* __restrict__ cinv, int mode) {
+    lp_pack_conv_pair_elem<T>(blockIdx.x * blockDim.x + threadIdx.x, w, wp, Co, Ci, cinv, mode);
+}
+
 // ConvTranspose3d(C, C, 2, 2) packing (layouts: convt_lp.hip): mode 0 wp[tap][ks][n16][lane][8], mode 1 wp[ks][n16][lane][8]
 template <class T>
 __device__ __forceinline__ void lp_pack_convt_w_elem(int idx, const float* __restrict__ w, T* __restrict__ wp, int Ci, int Co,
@@ -119,11 +147,12 @@ __global__ void lp_pack_batch_kernel(LpPackTable tb) {
     T* wp = reinterpret_cast<T*>(jb.wp);
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x;; idx += gridDim.x * blockDim.x) {
         int total;
-        if (jb.kind == 0) total = lp_total_ksteps(jb.k * jb.k * jb.k, jb.rin_p) * ((jb.nout_p + 15) >> 4) * 512;
+        if (jb.kind == 0) total = jb.layout == 1 ? LP_PAIR_ELEMS : lp_total_ksteps(jb.k * jb.k * jb.k, jb.rin_p) * ((jb.nout_p + 15) >> 4) * 512;
         else total = (jb.mode == 0 ? 8 * ((jb.rin_p + 31) >> 5) : 2 * (jb.rin_p >> 3)) * ((jb.nout_p + 15) >> 4) * 512;
         if (idx >= total) break;
         if (jb.kind == 0) {
-            if (jb.k == 3) lp_pack_conv_w_elem<T, 3>(idx, jb.w, wp, jb.Co, jb.Ci, jb.cinv, jb.rin_p, jb.nout_p, jb.mode);
+            if (jb.layout == 1) lp_pack_conv_pair_elem<T>(idx, jb.w, wp, jb.Co, jb.Ci, jb.cinv, jb.mode);
+            else if (jb.k == 3) lp_pack_conv_w_elem<T, 3>(idx, jb.w, wp, jb.Co, jb.Ci, jb.cinv, jb.rin_p, jb.nout_p, jb.mode);
             else lp_pack_conv_w_elem<T, 5>(idx, jb.w, wp, jb.Co, jb.Ci, jb.cinv, jb.rin_p, jb.nout_p, jb.mode);
         } else {
             lp_pack_convt_w_elem<T>(idx, jb.w, wp, jb.Ci, jb.Co, jb.cinv, jb.rin_p, jb.nout_p, jb.mode);
@@ -272,6 +301,11 @@ __global__ __launch_bounds__(256) void lp_conv_fwd_kernel(LpConvP p) {
         }
         if (xf) __syncthreads();                                    // sXf visible
         // ---- stage the haloed box: 16-byte items (halo voxel, chunk), up to UB loads in flight per thread
+        // (every item of a thread is the same chunk -- 256 is a multiple of the chunks per voxel -- so its BatchNorm vectors go
+        //  to registers once per stage instead of 16 LDS reads per item)
+        float xs[8], xh[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { xs[j] = xf ? sXf[(tid & (nchp - 1)) * 8 + j] : 1.f; xh[j] = xf ? sXf[32 + (tid & (nchp - 1)) * 8 + j] : 0.f; }
         const int items = HV << sh;
         for (int i0 = tid; i0 < items; i0 += 256 * UB) {
             uint4 raw[UB];
@@ -299,12 +333,11 @@ __global__ __launch_bounds__(256) void lp_conv_fwd_kernel(LpConvP p) {
                 uint4 r = raw[u];
                 if (dst[u] & 0x40000000) r = make_uint4(0u, 0u, 0u, 0u);
                 else if (xf) {
-                    const int c8 = ((dst[u] >> 26) & 3) * 8;               // first channel of the item within the stage
                     const f32x8 f = __builtin_convertvector(*reinterpret_cast<v8*>(&r), f32x8);
                     f32x8 o;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const float a = fmaf(f[j], sXf[c8 + j], sXf[32 + c8 + j]);
+                        const float a = fmaf(f[j], xs[j], xh[j]);
                         o[j] = p.relu ? fmaxf(a, 0.f) : a;
                     }
                     *reinterpret_cast<v8*>(&r) = __builtin_convertvector(o, v8);
@@ -805,6 +838,15 @@ __global__ __launch_bounds__(256) void lp_conv_fwd_p1_kernel(LpConvP p, int ntil
     unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0, ph_[5] = {0, 0, 0, 0, 0}, nst = 0;
     LPSTAMP(q0);
 #endif
+    // every item of a thread is the same 8-channel chunk (256 is a multiple of the chunks per voxel): its BatchNorm vectors
+    // sit in registers for the whole block instead of 16 LDS reads per item
+    float xs[8], xh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = (tid & (nchp - 1)) * 8 + j;
+        xs[j] = (xf && c < p.rin_p) ? p.scale[c] : 0.f;
+        xh[j] = (xf && c < p.rin_p) ? p.shift[c] : 0.f;
+    }
     for (; tile < tile_end; ++tile) {
         __syncthreads();                                            // tables visible (first pass) / previous box's readers done
         LPSTAMP(q1);
@@ -814,12 +856,11 @@ __global__ __launch_bounds__(256) void lp_conv_fwd_p1_kernel(LpConvP p, int ntil
             uint4 r = raw[u];
             if (!((okb >> u) & 1u)) r = make_uint4(0u, 0u, 0u, 0u);
             else if (xf) {
-                const int c8 = ((dst[u] >> 26) & 3) * 8;
                 const f32x8 f = __builtin_convertvector(*reinterpret_cast<v8*>(&r), f32x8);
                 f32x8 o;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float a = fmaf(f[j], sXf[c8 + j], sXf[32 + c8 + j]);
+                    const float a = fmaf(f[j], xs[j], xh[j]);
                     o[j] = p.relu ? fmaxf(a, 0.f) : a;
                 }
                 *reinterpret_cast<v8*>(&r) = __builtin_convertvector(o, v8);
@@ -948,6 +989,172 @@ __global__ __launch_bounds__(256) void lp_conv_fwd_p1_kernel(LpConvP p, int ntil
         }
         if (p.tail.counter) bn_fwd_tail(p.tail, p.stats, gridDim.x, p.nout_p, gridDim.x * gridDim.y);
     }
+}
+
+// ---- "pair" variant: k = 3 layers with 8 padded channels on BOTH sides at volumes at least 32 wide (every 128^3 conv of the
+// shipped nets but the first; forward and data gradient).  A 16-byte voxel leaves no room for per-voxel work, so:
+//   * rows = (w-shift s, c_out), columns = 16 voxel PAIRS of a 32-voxel row, a K-step = the 4 w offsets of one (kd, kh) row x 8
+//     channels: all 16 MFMA rows and all 64 epilogue lanes carry real outputs (the plain tile pads 8 channels to 16: half the
+//     lanes of its stores idle), 9 K-steps per pair tile instead of 7 per 16 voxels;
+//   * a lane's fragment address = its pair's first voxel + kw' (16 bytes apart: consecutive lanes read overlapping, conflict-
+//     free 16-byte slots) + a compile-time (plane, row) offset -- no offset table, no index arithmetic in the K loop;
+//   * the 10 halo rows of a kd plane are read once and feed the 3 kh taps of the 8 output rows (30 + 9 fragment reads per 72 MFMAs);
+//   * the BatchNorm vectors of the 8 input channels sit in registers; box 4 x 8 x 32, three blocks per CU, persistent.
+constexpr int LPP_TH = 8, LPP_BW = 32, LPP_HH = LPP_TH + 2, LPP_HW = LPP_BW + 2, LPP_HV = 6 * LPP_HH * LPP_HW;
+constexpr int LPP_NI = (LPP_HV + 255) / 256;
+constexpr size_t LPP_LDS = 256 + (size_t)LPP_HV * 16 + 9 * 1024;
+
+template <class T>
+__global__ __launch_bounds__(256, 3) void lp_conv_fwd_pair_kernel(LpConvP p, int ntiles, int tiles_per_block) {
+    typedef typename Vec<T>::v8 v8;
+    constexpr int TH = LPP_TH, BW = LPP_BW, HH = LPP_HH, HW = LPP_HW, HV = LPP_HV, NI = LPP_NI;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* sRed = reinterpret_cast<float*>(smem);                   // [4 waves][2][8]
+    unsigned char* sIn = smem + 256;
+    unsigned char* sW = sIn + (size_t)HV * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 15, kg = lane >> 4;
+    const T* in = reinterpret_cast<const T*>(p.in);
+    T* out = reinterpret_cast<T*>(p.out);
+    const bool xf = p.scale != nullptr;
+    for (int i = tid; i < 9 * 64; i += 256)
+        *reinterpret_cast<uint4*>(sW + (size_t)i * 16) = reinterpret_cast<const uint4*>(p.wp)[i];
+    float sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc[j] = xf ? p.scale[j] : 1.f; sh[j] = xf ? p.shift[j] : 0.f; }
+    unsigned ioff[NI];
+    unsigned live = 0;
+#pragma unroll
+    for (int u = 0; u < NI; ++u) {
+        const int i = tid + u * 256;
+        const bool lv = i < HV;
+        const int v = lv ? i : 0;
+        const int pw = v % HW, t2 = v / HW, ph = t2 % HH, pd = t2 / HH;
+        ioff[u] = (unsigned)((((pd * p.H + ph) * p.W + pw) * p.in_cs) * (int)sizeof(T));
+        live |= lv ? (1u << u) : 0u;
+    }
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 raw[NI];
+    unsigned okb = 0;
+    auto box_of = [&](int t, int& n, int& d0, int& h0, int& w0) {
+        const int tx = t % p.tiles_w; t /= p.tiles_w;
+        const int ty = t % p.tiles_h; t /= p.tiles_h;
+        const int tz = t % p.tiles_d;
+        n = t / p.tiles_d; d0 = tz * 4; h0 = ty * TH; w0 = tx * BW;
+    };
+    auto load_box = [&](int t) {
+        int n, d0, h0, w0;
+        box_of(t, n, d0, h0, w0);
+        if (d0 >= 1 && d0 + 5 <= p.D && h0 >= 1 && h0 + TH + 1 <= p.H && w0 >= 1 && w0 + BW + 1 <= p.W) {       // uniform
+            const char* base = reinterpret_cast<const char*>(in + ((((size_t)n * p.D + d0 - 1) * p.H + h0 - 1) * p.W + w0 - 1) * p.in_cs);
+#pragma unroll
+            for (int u = 0; u < NI; ++u) raw[u] = *reinterpret_cast<const u32x4*>(base + (((live >> u) & 1u) ? ioff[u] : 0u));
+            okb = live;
+            return;
+        }
+        okb = 0;
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {                              // border / ragged box: clamped, branch-free
+            const int v = min(tid + u * 256, HV - 1);
+            const int pw = v % HW, t2 = v / HW, ph = t2 % HH, pd = t2 / HH;
+            const int gd = d0 + pd - 1, gh = h0 + ph - 1, gw = w0 + pw - 1;
+            const bool ok = ((live >> u) & 1u) && (unsigned)gd < (unsigned)p.D && (unsigned)gh < (unsigned)p.H && (unsigned)gw < (unsigned)p.W;
+            const int cd = min(max(gd, 0), p.D - 1), chh = min(max(gh, 0), p.H - 1), cw = min(max(gw, 0), p.W - 1);
+            raw[u] = *reinterpret_cast<const u32x4*>(in + ((((size_t)n * p.D + cd) * p.H + chh) * p.W + cw) * p.in_cs);
+            okb |= ok ? (1u << u) : 0u;
+        }
+    };
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    int tile = blockIdx.x * tiles_per_block;
+    const int tile_end = min(ntiles, tile + tiles_per_block);
+    if (tile < tile_end) load_box(tile);
+    // lane (pair m, K-quarter kg = w offset): halo voxel 2 m + kg of the row
+    const unsigned char* bIn = sIn + (wave * HH * HW + 2 * m + kg) * 16;
+    const unsigned char* bW = sW + lane * 16;
+    const int orow = p.W * p.out_cs;
+    for (; tile < tile_end; ++tile) {
+        __syncthreads();                                            // weights visible (first pass) / previous box's readers done
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+            if (!((live >> u) & 1u)) continue;
+            u32x4 r = raw[u];
+            if (!((okb >> u) & 1u)) r = u32x4{0u, 0u, 0u, 0u};
+            else if (xf) {
+                const f32x8 f = __builtin_convertvector(*reinterpret_cast<v8*>(&r), f32x8);
+                f32x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float a = fmaf(f[j], sc[j], sh[j]);
+                    o[j] = p.relu ? fmaxf(a, 0.f) : a;
+                }
+                *reinterpret_cast<v8*>(&r) = __builtin_convertvector(o, v8);
+            }
+            *reinterpret_cast<u32x4*>(sIn + (size_t)(tid + u * 256) * 16) = r;
+        }
+        __syncthreads();
+        if (tile + 1 < tile_end) load_box(tile + 1);
+        f32x4 acc[TH];
+#pragma unroll
+        for (int ct = 0; ct < TH; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd) {
+            v8 rows[HH];
+#pragma unroll
+            for (int r = 0; r < HH; ++r) rows[r] = *reinterpret_cast<const v8*>(bIn + ((kd * HH + r) * HW) * 16);
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const v8 a = *reinterpret_cast<const v8*>(bW + (kd * 3 + kh) * 1024);
+#pragma unroll
+                for (int ct = 0; ct < TH; ++ct) acc[ct] = Mfma<T>::run(a, rows[ct + kh], acc[ct]);
+            }
+        }
+        // ---- epilogue: lane = (pair m, s = kg >> 1, channel quad kg & 1) of each of the wave's 8 rows
+        int n, d0, h0, w0;
+        box_of(tile, n, d0, h0, w0);
+        const int gd = d0 + wave, gw = w0 + 2 * m + (kg >> 1);
+        const bool full = d0 + 4 <= p.D && h0 + TH <= p.H && w0 + BW <= p.W;          // uniform
+        T* obase = out + ((((size_t)n * p.D + gd) * p.H + h0) * p.W + gw) * p.out_cs + (kg & 1) * 4;
+#pragma unroll
+        for (int ct = 0; ct < TH; ++ct) {
+            if (full || (gd < p.D && h0 + ct < p.H && gw < p.W)) {
+                const float4 o = rnd4<T>(make_float4(acc[ct][0], acc[ct][1], acc[ct][2], acc[ct][3]));
+                st4<T>(obase + (size_t)ct * orow, o);
+                s1[0] += o.x; s1[1] += o.y; s1[2] += o.z; s1[3] += o.w;
+                s2[0] += o.x * o.x; s2[1] += o.y * o.y; s2[2] += o.z * o.z; s2[3] += o.w * o.w;
+            }
+        }
+    }
+    if (p.stats) {                                                  // ONE BatchNorm partial row [2][8] per block
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float a1 = s1[r], a2 = s2[r];
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) { a1 += __shfl_xor(a1, o); a2 += __shfl_xor(a2, o); }
+            a1 += __shfl_xor(a1, 32); a2 += __shfl_xor(a2, 32);    // the two w-shifts hold the same channels
+            if (m == 0 && kg < 2) {
+                sRed[(wave * 2 + 0) * 8 + kg * 4 + r] = a1;
+                sRed[(wave * 2 + 1) * 8 + kg * 4 + r] = a2;
+            }
+        }
+        __syncthreads();
+        if (tid < 16) {
+            const int which = tid >> 3, c = tid & 7;
+            float sx = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < 4; ++wv) sx += sRed[(wv * 2 + which) * 8 + c];
+            st_row(p.tail.counter != nullptr, p.stats + (size_t)blockIdx.x * 16 + which * 8 + c, sx);
+        }
+        if (p.tail.counter) bn_fwd_tail(p.tail, p.stats, gridDim.x, 8, gridDim.x);
+    }
+}
+
+inline bool lp_use_pair(int k, int rin_p, int nout_p, int W) { return k == 3 && rin_p == 8 && nout_p == 8 && W >= 32; }
+inline int lp_pair_ntiles(int N, int D, int H, int W) { return N * ceil_div(D, 4) * ceil_div(H, LPP_TH) * ceil_div(W, LPP_BW); }
+inline void lp_pair_grid(int ntiles, int* gx, int* tpb) {
+    int g = 768;                                                    // 3 blocks per CU
+    if (g > ntiles) g = ntiles;
+    *tpb = ceil_div(ntiles, g);
+    *gx = ceil_div(ntiles, *tpb);
 }
 
 struct LpBox { int th, bw; };
@@ -1245,6 +1452,15 @@ __global__ __launch_bounds__(256) void lp_conv_wgrad_kernel(LpWgP p, int tiles_p
         }
     };
     if (tile < tile_end) load_box(tile);
+    // every X item of a thread is the same 8-channel half (item parity = thread parity; a shifted half holds channels 0..7
+    // again): its BatchNorm vectors go to registers once instead of 16 LDS reads per item
+    float wxs[8], wxh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = cit * 16 + (SM == 2 ? 0 : (tid & 1) * 8) + j;
+        wxs[j] = xf ? (c < p.cin_p ? p.scale[c] : 0.f) : 1.f;
+        wxh[j] = xf ? (c < p.cin_p ? p.shift[c] : 0.f) : 0.f;
+    }
     for (; tile < tile_end; ++tile) {
         __syncthreads();                                            // the previous box's readers are done
         // ---- registers -> LDS images: X with the lazy BatchNorm + ReLU (zero outside the volume), G as it is
@@ -1255,12 +1471,11 @@ __global__ __launch_bounds__(256) void lp_conv_wgrad_kernel(LpWgP p, int tiles_p
             uint4 r = rx[u];
             if (!((okx >> u) & 1u)) r = make_uint4(0u, 0u, 0u, 0u);
             else if (xf) {
-                const int c8 = SM == 2 ? 0 : (it & 1) * 8;         // (a shifted half holds channels 0..7 again)
                 const f32x8 f = __builtin_convertvector(*reinterpret_cast<v8*>(&r), f32x8);
                 f32x8 o;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float a = fmaf(f[j], sXf[c8 + j], sXf[16 + c8 + j]);
+                    const float a = fmaf(f[j], wxs[j], wxh[j]);
                     o[j] = p.relu ? fmaxf(a, 0.f) : a;
                 }
                 *reinterpret_cast<v8*>(&r) = __builtin_convertvector(o, v8);
@@ -1486,12 +1701,24 @@ int lp_wgrad_dispatch(LpWgP& p, int gx, int tpb, int pairs, hipStream_t st) {
 }  // namespace
 
 // =================================================================== C ABI
+// packed-weight layouts of the 16-bit forward / data-gradient kernels: 0 = [K-step][16-wide out tile][lane][8]; 1 ("pair",
+// k = 3 with 8 padded channels on both sides at volumes at least 32 wide) = lp_conv_fwd_pair_kernel's (w-shift, channel) rows.
+// ctu_lp_conv3d_layout: the layout the forward kernel wants for a geometry -- pack, num_blocks and forward must agree on it.
+extern "C" int ctu_lp_conv3d_layout(int k, int rin_p, int nout_p, int W) { return lp_use_pair(k, rin_p, nout_p, W) ? 1 : 0; }
+
 extern "C" size_t ctu_lp_conv3d_packed_elems(int k, int rin_p, int nout_p) {
     if ((k != 3 && k != 5) || rin_p <= 0 || rin_p % 8 || nout_p <= 0 || nout_p % 8) return 0;
-    return (size_t)lp_total_ksteps(k * k * k, rin_p) * ((nout_p + 15) >> 4) * 512;
+    const size_t n = (size_t)lp_total_ksteps(k * k * k, rin_p) * ((nout_p + 15) >> 4) * 512;
+    return (k == 3 && rin_p == 8 && nout_p == 8 && n < (size_t)LP_PAIR_ELEMS) ? (size_t)LP_PAIR_ELEMS : n;      // either layout fits
 }
 
-extern "C" int ctu_lp_conv3d_num_blocks(int N, int D, int H, int W, int k, int rin_p) {
+extern "C" int ctu_lp_conv3d_num_blocks(int N, int D, int H, int W, int k, int rin_p, int nout_p, int layout) {
+    if (layout == 1) {
+        int gx, tpb;
+        lp_pair_grid(lp_pair_ntiles(N, D, H, W), &gx, &tpb);
+        return gx;
+    }
+    (void)nout_p;
     LpConvP p;
     const int ntiles = lp_fill(p, N, D, H, W, rin_p);
     if (lp_use_persist(k, rin_p, ntiles) && lp_box(W, rin_p, (int64_t)N * D * H * W).bw >= 16) {
@@ -1503,8 +1730,15 @@ extern "C" int ctu_lp_conv3d_num_blocks(int N, int D, int H, int W, int k, int r
 }
 
 extern "C" int ctu_lp_pack_conv3d_weight(int dtype, const float* w, void* wp, int Co, int Ci, int k, const int32_t* cinv,
-                                         int rin_p, int nout_p, int mode, void* stream) {
+                                         int rin_p, int nout_p, int mode, int layout, void* stream) {
     CTU_REQUIRE(w && wp, "lp_pack_conv3d_weight: null pointer");
+    CTU_REQUIRE(layout == 0 || (layout == 1 && k == 3 && rin_p == 8 && nout_p == 8), "lp_pack_conv3d_weight: layout %d needs k = 3 and 8 padded channels on both sides", layout);
+    if (layout == 1) {
+        CTU_REQUIRE(mode == 0 || mode == 1, "lp_pack_conv3d_weight: mode=%d", mode);
+        CTU_DISPATCH_LP(dtype, lp_pack_conv_pair_kernel<T><<<ceil_div(LP_PAIR_ELEMS, 256), 256, 0, (hipStream_t)stream>>>(w, (T*)wp, Co, Ci, cinv, mode));
+        CTU_CHECK_LAUNCH("lp_pack_conv3d_weight(pair)");
+        return CTU_OK;
+    }
     CTU_REQUIRE((k == 3 || k == 5) && rin_p > 0 && rin_p % 8 == 0 && nout_p > 0 && nout_p % 8 == 0 && (mode == 0 || mode == 1),
                 "lp_pack_conv3d_weight: k=%d rin_p=%d nout_p=%d mode=%d", k, rin_p, nout_p, mode);
     const size_t total = ctu_lp_conv3d_packed_elems(k, rin_p, nout_p);
@@ -1520,8 +1754,9 @@ extern "C" int ctu_lp_pack_conv3d_weight(int dtype, const float* w, void* wp, in
 
 extern "C" int ctu_lp_conv3d_fwd(int dtype, const void* in, int in_cs, int rin_p, const float* in_scale, const float* in_shift,
                                  int in_relu, const void* wp, const float* bias, int nbias, void* out, int out_cs, int nout_p,
-                                 float* stats, int N, int D, int H, int W, int k, const ctu_bn_tail* tail, void* stream) {
+                                 float* stats, int N, int D, int H, int W, int k, int layout, const ctu_bn_tail* tail, void* stream) {
     CTU_REQUIRE(in && wp && out, "lp_conv3d_fwd: null pointer");
+    CTU_REQUIRE(layout == 0 || (layout == 1 && lp_use_pair(k, rin_p, nout_p, W) && !bias), "lp_conv3d_fwd: layout %d not valid for this geometry", layout);
     CTU_REQUIRE((k == 3 || k == 5) && rin_p > 0 && rin_p % 8 == 0 && nout_p > 0 && nout_p % 8 == 0,
                 "lp_conv3d_fwd: k=%d rin_p=%d nout_p=%d", k, rin_p, nout_p);
     CTU_REQUIRE(in_cs >= rin_p && in_cs % 8 == 0 && out_cs >= nout_p && out_cs % 4 == 0 && ((uintptr_t)in & 15) == 0 &&
@@ -1536,8 +1771,19 @@ extern "C" int ctu_lp_conv3d_fwd(int dtype, const void* in, int in_cs, int rin_p
     p.tail = tail_or_off(tail);
     p.in_cs = in_cs; p.rin_p = rin_p; p.relu = in_relu; p.out_cs = out_cs; p.nout_p = nout_p; p.nbias = bias ? nbias : 0;
     p.S = lp_voxel_stride(rin_p);
-    const int ntiles = lp_fill(p, N, D, H, W, rin_p);
     hipStream_t st = (hipStream_t)stream;
+    if (layout == 1) {
+        p.N = N; p.D = D; p.H = H; p.W = W;
+        p.tiles_d = ceil_div(D, 4); p.tiles_h = ceil_div(H, LPP_TH); p.tiles_w = ceil_div(W, LPP_BW);
+        const int nt_ = lp_pair_ntiles(N, D, H, W);
+        int gx, tpb;
+        lp_pair_grid(nt_, &gx, &tpb);
+        CTU_REQUIRE((int64_t)(6 * H + 6) * W * in_cs * 2 < (int64_t)1 << 31, "lp_conv3d_fwd: volume too large for 32-bit offsets");
+        CTU_DISPATCH_LP(dtype, lp_conv_fwd_pair_kernel<T><<<gx, 256, LPP_LDS, st>>>(p, nt_, tpb));
+        CTU_CHECK_LAUNCH("lp_conv3d_fwd (pair)");
+        return CTU_OK;
+    }
+    const int ntiles = lp_fill(p, N, D, H, W, rin_p);
     // two out tiles per block share one staged box -- unless that leaves CUs idle (small volumes: one tile per block)
     const bool two = nout_p > 16 && (int64_t)ntiles * ceil_div((nout_p + 15) >> 4, 2) >= 256;
     int rc = CTU_OK;
@@ -1653,6 +1899,7 @@ extern "C" int ctu_lp_pack_batch(int dtype, const ctu_pack_job* jobs, int n, voi
                         jb.rin_p % 8 == 0 && jb.nout_p > 0 && jb.nout_p % 8 == 0 && (jb.kind == 1 || jb.k == 3 || jb.k == 5),
                         "lp_pack_batch: bad job %d", j0 + j);
             tb.j[j] = jb;
+            CTU_REQUIRE(jb.kind == 1 || jb.layout == 0 || (jb.layout == 1 && jb.k == 3 && jb.rin_p == 8 && jb.nout_p == 8), "lp_pack_batch: bad layout in job %d", j0 + j);
             const size_t tot = jb.kind == 0 ? ctu_lp_conv3d_packed_elems(jb.k, jb.rin_p, jb.nout_p)
                                             : (size_t)(jb.mode == 0 ? 8 * ((jb.rin_p + 31) >> 5) : 2 * (jb.rin_p >> 3)) * ((jb.nout_p + 15) >> 4) * 512;
             if (tot > mx) mx = tot;

@@ -126,11 +126,12 @@ SIGNATURES = {
     "ctu_lp_upconv_fused_wgrad": (I, [I, P, I, I, P, P, I, P, I, P, P, I, I, I, I, P]),
     "ctu_lp_upconv_fused_project": (I, [I, P, P, I, I, I, I, I, I, P, P, P, I, I, I, P, P, P, P, P]),
     "ctu_lp_upconv_fused_bwd_data": (I, [I, P, I, P, P, I, I, I, I, I, I, P]),
+    "ctu_lp_conv3d_layout": (I, [I, I, I, I]),
     "ctu_lp_conv3d_packed_elems": (Z, [I, I, I]),
-    "ctu_lp_conv3d_num_blocks": (I, [I, I, I, I, I, I]),
-    "ctu_lp_pack_conv3d_weight": (I, [I, P, P, I, I, I, P, I, I, I, P]),
+    "ctu_lp_conv3d_num_blocks": (I, [I, I, I, I, I, I, I, I]),
+    "ctu_lp_pack_conv3d_weight": (I, [I, P, P, I, I, I, P, I, I, I, I, P]),
     "ctu_lp_pack_batch": (I, [I, P, I, P]),
-    "ctu_lp_conv3d_fwd": (I, [I, P, I, I, P, P, I, P, P, I, P, I, I, P, I, I, I, I, I, P, P]),
+    "ctu_lp_conv3d_fwd": (I, [I, P, I, I, P, P, I, P, P, I, P, I, I, P, I, I, I, I, I, I, P, P]),
     "ctu_lp_conv3d_wgrad_ws_floats": (Z, [I, I, I, I, I, I, I]),
     "ctu_lp_conv3d_wgrad": (I, [I, P, I, I, P, P, I, P, I, I, P, I, I, P, P, I, I, I, I, I, P]),
     "ctu_lp_conv3d_first_fwd": (I, [I, P, I, P, P, I, P, I, I, P, I, I, I, I, P, P]),

@@ -142,7 +142,7 @@ class UNetEngine:
             return hit[1]
         wd = w.detach()
         if self.dtype != torch.float32:                # 16-bit fragment-ordered copies of the fp32 masters
-            wp = self._pack_lp(kind, wd, imap, rin_p, nout_p, mode, hit[1] if hit is not None else None)
+            wp = self._pack_lp(kind, wd, imap, rin_p, nout_p, mode, hit[1] if hit is not None else None, layout)
         else:
             wp = hit[1] if hit is not None else torch.empty(ops.packed_floats(kind, w.shape[2], rin_p, nout_p, layout),
                                                             dtype=torch.float32, device=w.device)
@@ -150,9 +150,9 @@ class UNetEngine:
         self._pack_cache[key] = (ver, wp, imap)
         return wp
 
-    def _pack_lp(self, kind, wd, imap, rin_p, nout_p, mode, into):
+    def _pack_lp(self, kind, wd, imap, rin_p, nout_p, mode, into, layout=0):
         if kind == "conv":
-            return ops.pack_conv_w_lp(wd, imap, rin_p, nout_p, mode, self.dtype, into)
+            return ops.pack_conv_w_lp(wd, imap, rin_p, nout_p, mode, self.dtype, into, layout)
         return ops.pack_convt_w_lp(wd, imap, rin_p, nout_p, mode, self.dtype, into)
 
     def refresh_packs(self, P: Dict[str, torch.Tensor]) -> None:
@@ -187,9 +187,11 @@ class UNetEngine:
                  training: bool, n_upd: int, save: bool) -> Tuple[CL, Optional[_ConvRec]]:
         k = self.plan.k
         w = P[conv + ".weight"]
-        lay = ops.conv_layout(k, out.cp, x.dims[3]) if self.dtype == torch.float32 else 0
-        wp = self._packed(conv, w, "conv", imap, x.cp, out.cp, 0, lay)
         bias = P.get(conv + ".bias")
+        lay = ops.conv_layout(k, out.cp, x.dims[3], self.dtype, x.cp)
+        if bias is not None and self.dtype != torch.float32:
+            lay = 0                                  # (the 16-bit pair-layout kernel carries no bias)
+        wp = self._packed(conv, w, "conv", imap, x.cp, out.cp, 0, lay)
         bias_p = None if bias is None else bias.detach()
         dims = x.dims
         c = cout
@@ -500,7 +502,7 @@ class UNetEngine:
             if rec.bias:
                 grads[rec.conv + ".bias"] = dbias
         if gin is not None:
-            lay = ops.conv_layout(k, gin.cp, ga.dims[3]) if self.dtype == torch.float32 else 0
+            lay = ops.conv_layout(k, gin.cp, ga.dims[3], self.dtype, ga.cp)
             wpd = self._packed(rec.conv, P[rec.conv + ".weight"], "conv", rec.imap, ga.cp, gin.cp, 1, lay)
             ops.conv3d_fwd(ga, wpd, None, gin, k, None, (rec.cout, rec.cin), lay)
 

@@ -255,8 +255,11 @@ def cl_to_ncdhw(a: CL, c: int) -> torch.Tensor:
 
 
 # ---------------------------------------------------------------------------- conv3d
-def conv_layout(k: int, nout_p: int, w: int) -> int:
-    """Packed-weight layout the forward kernel wants for this output width / volume width."""
+def conv_layout(k: int, nout_p: int, w: int, dtype=torch.float32, rin_p: int = 0) -> int:
+    """Packed-weight layout the forward kernel wants for this output width / volume width (16-bit path: depends on the
+    padded input channel count too)."""
+    if lp(dtype):
+        return _lib.load().ctu_lp_conv3d_layout(k, rin_p, nout_p, w)
     return _lib.load().ctu_conv3d_layout(k, nout_p, w)
 
 
@@ -297,7 +300,7 @@ def pack_batch(jobs) -> None:
 
 
 def pack_batch_lp(jobs, dtype: torch.dtype) -> None:
-    """jobs as in pack_batch (layout ignored): every 16-bit weight copy in ONE launch."""
+    """jobs as in pack_batch: every 16-bit weight copy in ONE launch."""
     if not jobs:
         return
     arr = (_lib.PackJob * len(jobs))()
@@ -309,7 +312,7 @@ def pack_batch_lp(jobs, dtype: torch.dtype) -> None:
             a.kind, a.Co, a.Ci, a.k = 0, w.shape[0], w.shape[1], w.shape[2]
         else:
             a.kind, a.Ci, a.Co, a.k = 1, w.shape[0], w.shape[1], 2
-        a.rin_p, a.nout_p, a.mode, a.layout = rin_p, nout_p, mode, 0
+        a.rin_p, a.nout_p, a.mode, a.layout = rin_p, nout_p, mode, (layout if kind == "conv" else 0)
     _lib.check(_lib.load().ctu_lp_pack_batch(LP_CODE[dtype], arr, len(jobs), _stream()), "lp_pack_batch")
 
 
@@ -318,7 +321,7 @@ def conv_num_blocks(dims, nout_p: int, layout: int = 0, k: int = 3, dtype=torch.
     input channel count too, pass rin_p)."""
     n, d, h, w = dims
     if lp(dtype):
-        return _lib.load().ctu_lp_conv3d_num_blocks(n, d, h, w, k, rin_p)
+        return _lib.load().ctu_lp_conv3d_num_blocks(n, d, h, w, k, rin_p, nout_p, layout)
     return _lib.load().ctu_conv3d_num_blocks(n, d, h, w, k, nout_p, layout)
 
 
@@ -335,7 +338,7 @@ def conv3d_fwd(x: CL, wp: torch.Tensor, bias: Optional[torch.Tensor], out: CL, k
         t0 = TIMER.begin() if TIMER is not None else None
         _lib.check(lib.ctu_lp_conv3d_fwd(x.lp, x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), wp.data_ptr(),
                                          _ptr(bias), 0 if bias is None else bias.numel(), out.ptr, out.cs, out.cp,
-                                         _ptr(stats), n, d, h, w, k, _tail_arg(tail), _stream()), "lp_conv3d_fwd")
+                                         _ptr(stats), n, d, h, w, k, layout, _tail_arg(tail), _stream()), "lp_conv3d_fwd")
         if t0 is not None:
             ci, co = algo_ch if algo_ch is not None else (x.cp, out.cp)
             vox = n * d * h * w
@@ -424,8 +427,9 @@ def conv3d_wgrad_ws(dims, k, cin_p, cout_p, dtype=torch.float32) -> int:
 
 
 def pack_conv_w_lp(w: torch.Tensor, cinv: Optional[torch.Tensor], rin_p: int, nout_p: int, mode: int, dtype: torch.dtype,
-                   into: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """16-bit MFMA-fragment-ordered copy of an fp32 master Conv3d weight (mode 0 forward, 1 data gradient)."""
+                   into: Optional[torch.Tensor] = None, layout: int = 0) -> torch.Tensor:
+    """16-bit MFMA-fragment-ordered copy of an fp32 master Conv3d weight (mode 0 forward, 1 data gradient; layout as
+    conv_layout(..., dtype, rin_p) says for the launch that will read it)."""
     _need_cuda(w, "conv weight")
     co, ci, k = w.shape[0], w.shape[1], w.shape[2]
     lib = _lib.load()
@@ -433,7 +437,7 @@ def pack_conv_w_lp(w: torch.Tensor, cinv: Optional[torch.Tensor], rin_p: int, no
     wp = into if into is not None else torch.empty(n, dtype=dtype, device=w.device)
     assert wp.numel() == n and wp.dtype == dtype
     _lib.check(lib.ctu_lp_pack_conv3d_weight(LP_CODE[dtype], w.contiguous().data_ptr(), wp.data_ptr(), co, ci, k, _ptr(cinv),
-                                             rin_p, nout_p, mode, _stream()), "lp_pack_conv3d_weight")
+                                             rin_p, nout_p, mode, layout, _stream()), "lp_pack_conv3d_weight")
     return wp
 
 

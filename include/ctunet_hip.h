@@ -438,17 +438,21 @@ int ctu_stitch_patches(const float* patches, const int32_t* coords, int P, int C
  *                      (taken from the ROUNDED outputs), weight / bias / BatchNorm gradients, master weights
  *   packed weights ... 16-bit copies in MFMA fragment order, re-packed from the fp32 masters (ctu_lp_pack_*)
  * fp16 gradients need the caller's loss scaling (the per-voxel loss gradient of a 256^3 patch is 6e-8); bf16 does not. */
+/* packed-weight layouts: 0 = [K-step][16-wide out tile][lane][8]; 1 ("pair": k = 3, 8 padded channels on both sides, W >= 32) =
+ * (w-shift, channel) rows, a K-step = the 4 w offsets of one (kd, kh) row.  ctu_lp_conv3d_layout returns the layout the forward /
+ * data-gradient kernel wants; pack, num_blocks and forward must be given the same one. */
+int ctu_lp_conv3d_layout(int k, int rin_p, int nout_p, int W);
 size_t ctu_lp_conv3d_packed_elems(int k, int rin_p, int nout_p);
-int ctu_lp_conv3d_num_blocks(int N, int D, int H, int W, int k, int rin_p);
+int ctu_lp_conv3d_num_blocks(int N, int D, int H, int W, int k, int rin_p, int nout_p, int layout);
 int ctu_lp_pack_conv3d_weight(int dtype, const float* w, void* wp, int Co, int Ci, int k, const int32_t* cinv,
-                              int rin_p, int nout_p, int mode, void* stream);
+                              int rin_p, int nout_p, int mode, int layout, void* stream);
 /* every 16-bit weight copy of a network in ONE launch (ctu_pack_job as above; `layout` unused, kind 1 = ConvTranspose3d) */
 int ctu_lp_pack_batch(int dtype, const ctu_pack_job* jobs, int n, void* stream);
 /* nn.Conv3d forward (mode-0 packing) / data gradient (mode-1 packing); stats: [ctu_lp_conv3d_num_blocks()][2][nout_p]
  * (the voxel box of a launch grows when rin_p is small, so the row count depends on it) */
 int ctu_lp_conv3d_fwd(int dtype, const void* in, int in_cs, int rin_p, const float* in_scale, const float* in_shift,
                       int in_relu, const void* wp, const float* bias, int nbias, void* out, int out_cs, int nout_p,
-                      float* stats, int N, int D, int H, int W, int k, const ctu_bn_tail* tail, void* stream);
+                      float* stats, int N, int D, int H, int W, int k, int layout, const ctu_bn_tail* tail, void* stream);
 /* weight gradient -> dw fp32 [Co,Ci,k,k,k] (torch layout); ws: ctu_lp_conv3d_wgrad_ws_floats() floats */
 size_t ctu_lp_conv3d_wgrad_ws_floats(int N, int D, int H, int W, int k, int cin_p, int cout_p);
 int ctu_lp_conv3d_wgrad(int dtype, const void* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,

@@ -23,8 +23,10 @@ xx = x.with_xf(sc, sh, True)
 flops = 2.0 * ci * co * k ** 3 * s ** 3
 if op == "fwd":
     w = torch.randn(co, ci, k, k, k, device=dev) * 0.1
-    lay = 0 if LP else ops.conv_layout(k, cop, s)
-    wp = ops.pack_conv_w_lp(w, None, cip, cop, 0, DT) if LP else ops.pack_conv_w(w, None, cip, cop, 0, lay)
+    lay = ops.conv_layout(k, cop, s, DT, cip)
+    if os.environ.get("CTU_LAY") is not None:
+        lay = int(os.environ["CTU_LAY"])
+    wp = ops.pack_conv_w_lp(w, None, cip, cop, 0, DT, None, lay) if LP else ops.pack_conv_w(w, None, cip, cop, 0, lay)
     out = ops.CL(torch.empty(1, s, s, s, cop, device=dev, dtype=DT), 0, cop)
     nb = ops.conv_num_blocks((1, s, s, s), cop, lay, k, DT, cip)
     stats = torch.empty(nb, 2, cop, device=dev)

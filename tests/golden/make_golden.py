@@ -12,7 +12,8 @@ files.  Nothing from the reference's source text is stored.
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
 
 torch 2.10.0+rocm7.0 CPU, 8 threads.  Fixtures: tiny_unet.npz, tiny_unet_add.npz,
-tiny_unet_noskip.npz, tiny_unet_sp.npz, tiny_legacy.npz, losses.npz, class_checksums.json, ini_params.json.
+tiny_unet_noskip.npz, tiny_unet_sp.npz, tiny_legacy.npz, tiny_{unet,unet_sp,legacy}_stable.npz, losses.npz,
+class_checksums.json, ini_params.json.
 """
 import glob
 import importlib.util
@@ -206,6 +207,64 @@ def tiny_legacy(ref, U, PH):
     print("tiny_legacy", rec["eval_out0"].mean(), rec["train_loss"])
 
 
+def stabilize_bn(net, seed):
+    """BatchNorm parameters that pin every ReLU mask: |beta| = 6 |gamma|, so a channel's pre-activations gamma*yhat + beta stay
+    6 sigma away from zero -- two channels of three always on (beta > 0), one always off (beta < 0), at least one on per layer.
+    A whole-net gradient comparison then has no mask flips to hide behind: forward and backward are smooth in the weights."""
+    g = gen(seed)
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm3d):
+            with torch.no_grad():
+                c = m.weight.numel()
+                gam = (torch.rand(c, generator=g) + 0.5) * (torch.randint(0, 2, (c,), generator=g).float() * 2 - 1)
+                on = torch.tensor([1.0 if (i % 3 != 2 or c == 1) else -1.0 for i in range(c)])
+                m.weight.copy_(gam)
+                m.bias.copy_(6.0 * gam.abs() * on)
+                m.running_mean.copy_(torch.randn(c, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(c, generator=g) + 0.5)
+
+
+def mask_stable(ref, U, PH):
+    """tiny_*_stable.npz: the tiny generic / shape-prior / legacy nets with stabilize_bn's parameters -- weights, input, train
+    outputs, loss and ALL gradients from the reference (the tight whole-net gradient gate of tests/test_models_gpu.py)."""
+    class TinySP(ref.UNetSP):
+        def __init__(self):
+            ref.UNet.__init__(self, input_channels=2, out_channels=3, n_blocks=2, i_size=3, use_checkpoint=False)
+
+    def single(out, tgt):
+        h = Holder(1.0, 1.0)
+        PH.ProblemHandler.comp_losses_metrics(h, out, tgt, 0, 1)
+        return h.pt_loss
+
+    def double(out, tgts):
+        h = Holder(1.0, 1.0)
+        PH.FlapRecWithShapePriorDoubleOut.comp_losses_metrics(h, out, tgts, 0, 1)
+        return h.pt_loss
+    cases = [("tiny_unet_stable", lambda: ref.UNet(input_channels=1, out_channels=2, n_blocks=2, i_size=3, use_checkpoint=False), 1, 16, 2, 51),
+             ("tiny_unet_sp_stable", TinySP, 2, 16, 1, 52),
+             ("tiny_legacy_stable", lambda: ref.recAE_v2_fixed(input_channels=1, i_size=1, use_checkpoint=False), 1, 32, 1, 53)]
+    for tag, make, in_ch, size, batch, seed in cases:
+        torch.manual_seed(seed)
+        net = make()
+        stabilize_bn(net, seed + 100)
+        x = torch.randn(batch, in_ch, size, size, size, generator=gen(seed + 200))
+        shape = (batch, 2, size, size, size)
+        rec = {"x": x.numpy()}
+        if "sp" in tag:
+            t_sk, t_fl = onehot_target(shape, seed + 300), onehot_target(shape, seed + 301, 0.1)
+            rec["target_sk"], rec["target_fl"] = t_sk.numpy(), t_fl.numpy()
+            loss_fn = lambda out: double(out, (t_sk, t_fl))
+        else:
+            tgt = onehot_target(shape, seed + 300)
+            rec["target"] = tgt.numpy()
+            loss_fn = lambda out: single(out, tgt)
+        rec.update({"sd." + k: v for k, v in to_np(net.state_dict()).items()})
+        rec.update(step_record(net, x, loss_fn))
+        # how far the fixture's masks are from flipping: smallest |pre-activation| / its channel's std, over all BatchNorms
+        np.savez_compressed(f"{HERE}/{tag}.npz", **rec)
+        print(tag, rec["train_loss"], max(np.abs(v).max() for k, v in rec.items() if k.startswith("grad.") and v.size))
+
+
 def losses(ref, U, PH):
     g = gen(41)
     rec = {}
@@ -308,13 +367,17 @@ def ini_params(ref, U, PH):
 
 if __name__ == "__main__":
     ref, U, PH = load_ref()
-    if len(sys.argv) > 1 and sys.argv[1] == "skip_modes":      # only the fixtures added last
+    if len(sys.argv) > 1 and sys.argv[1] == "skip_modes":      # only the fixtures added in round 2
         tiny_skip_modes(ref, U, PH)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "stable":          # only the fixtures added in round 3
+        mask_stable(ref, U, PH)
         sys.exit(0)
     tiny_generic(ref, U, PH)
     tiny_skip_modes(ref, U, PH)
     tiny_sp(ref, U, PH)
     tiny_legacy(ref, U, PH)
+    mask_stable(ref, U, PH)
     losses(ref, U, PH)
     class_checksums(ref, U, PH)
     ini_params(ref, U, PH)

@@ -53,6 +53,8 @@ CONV_CASES = [  # (k, ci, co, shape NDHW, transform)
     # side; 16- and 32-wide boxes; volumes that are not multiples of the box), the k = 5 forward's weight groups in LDS
     (5, 8, 8, (1, 8, 8, 32), True), (5, 32, 8, (1, 4, 9, 20), True), (3, 8, 16, (2, 5, 9, 40), True),
     (3, 8, 8, (1, 4, 8, 40), False), (5, 8, 8, (1, 5, 6, 18), False), (3, 16, 8, (1, 8, 8, 16), True),
+    # 8 -> 8 at >= 32-wide volumes: the pair-layout kernel (lp_conv_fwd_pair_kernel), interior + border + ragged boxes
+    (3, 8, 8, (2, 5, 9, 70), True), (3, 8, 8, (1, 12, 24, 96), True), (3, 7, 8, (1, 4, 8, 32), True),
 ]
 
 
@@ -78,11 +80,12 @@ def test_lp_conv_forward_stats_dgrad_wgrad(name, k, ci, co, shape, xf):
     else:
         a = x
     # ---- forward + BatchNorm partial sums
-    wp = ops.pack_conv_w_lp(wt.cuda(), None, cip, cop, 0, dt)
+    lay = 0 if bias is not None else ops.conv_layout(k, cop, w, dt, cip)       # (the pair layout carries no bias)
+    wp = ops.pack_conv_w_lp(wt.cuda(), None, cip, cop, 0, dt, None, lay)
     out = ops.CL(torch.full((n, d, h, w, cop + 8), 3.0, dtype=dt).cuda(), 8, cop)
-    nblk = ops.conv_num_blocks(shape, cop, 0, k, dt, cip)
+    nblk = ops.conv_num_blocks(shape, cop, lay, k, dt, cip)
     stats = torch.zeros((nblk, 2, cop), dtype=torch.float32).cuda()
-    ops.conv3d_fwd(xcl, wp, None if bias is None else bias.cuda(), out, k, stats)
+    ops.conv3d_fwd(xcl, wp, None if bias is None else bias.cuda(), out, k, stats, None, lay)
     ref = F.conv3d(a.double(), wt.double(), None if bias is None else bias.double(), 1, (k - 1) // 2).float()
     got = from_cl(out, co)
     tol = ULP[name] * ref.abs().max().item()
@@ -97,9 +100,10 @@ def test_lp_conv_forward_stats_dgrad_wgrad(name, k, ci, co, shape, xf):
     # ---- data gradient (mode-1 packing, no transform on the gradient)
     go = rnd(torch.randn(n, co, d, h, w, generator=g), dt)
     gcl = to_cl(go, cop, dt)
-    wpd = ops.pack_conv_w_lp(wt.cuda(), None, cop, cip, 1, dt)
+    layd = ops.conv_layout(k, cip, w, dt, cop)
+    wpd = ops.pack_conv_w_lp(wt.cuda(), None, cop, cip, 1, dt, None, layd)
     gin = ops.CL(torch.zeros((n, d, h, w, cip), dtype=dt).cuda(), 0, cip)
-    ops.conv3d_fwd(gcl, wpd, None, gin, k)
+    ops.conv3d_fwd(gcl, wpd, None, gin, k, None, None, layd)
     ref_dx = torch.nn.grad.conv3d_input(a.shape, wt.double(), go.double(), 1, (k - 1) // 2).float()
     assert (from_cl(gin, ci) - ref_dx).abs().max().item() <= ULP[name] * ref_dx.abs().max().item()
     # ---- weight gradient (fp32 output; K = voxels)
