@@ -73,18 +73,28 @@ def host_cores():
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the newest committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
     (profiles/rNN_hbm_traffic.json, produced by scripts/collect_traffic.py with the guide's gfx950 corrections);
-    None when no PMC run covers this kernel."""
+    None when no PMC run covers this kernel.  16-bit tags are looked up in the section of their own pass ("kernels_bf16")
+    by kernel base name (rocprofv3 leaves symbols with __bf16 / _Float16 template arguments mangled or half-demangled:
+    `...lp_conv_fwd_pair_kernelIDF16bEE...`), launch-weighted over the template instances that match."""
     import glob
     try:
         files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_hbm_traffic.json")))
         with open(files[-1]) as f:
-            k = json.load(f)["kernels"].get(kernel.split(" (")[0])
-        return None if k is None else round(k["hbm_bytes_per_launch"])
+            doc = json.load(f)
+        tag = kernel.split(" (")[0]
+        dt = "bf16" if "<bf16" in tag else "f16" if "<f16" in tag else None
+        ks = doc.get("kernels" if dt is None else "kernels_" + dt, {})
+        if tag in ks:
+            return round(ks[tag]["hbm_bytes_per_launch"])
+        base = tag.split("<")[0]
+        hit = [v for k, v in ks.items() if base + "<" in k or base + "I" in k] if dt else []
+        n = sum(v["launches"] for v in hit)
+        return round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in hit) / n) if n else None
     except Exception:
         return None
 
 
-def cpu_baseline(size, model="UNet", precision="fp32", mode="train", batch=1, steps=3):
+def cpu_baseline(size, model="UNet", precision="fp32", mode="train", batch=1, steps=3, check_only=False):
     """The oracle (same ATen-CPU graph as the reference) timed on the host cores, bounded: 1 warm-up + best of `steps`
     steps of the same workload.  Train mode reports three points: all granted cores without checkpoint
     recompute (`value`, the algorithmic 3x-forward work), the same with the recompute pass the reference's default
@@ -119,13 +129,15 @@ def cpu_baseline(size, model="UNet", precision="fp32", mode="train", batch=1, st
             if i > 0:
                 best = min(best, dt)
         return best
-    best = timed(cores, False, steps)
+    best = timed(cores, False, 1 if check_only else steps)
     vox = batch * size ** 3
     out = {"value": vox / best, "unit": "voxels/s", "cores": cores, "kind": "port",
            "sample": f"{steps} {'fwd+bwd' if mode == 'train' else 'eval-forward'} steps (best, after 1 warm-up) of the same "
                      f"{size}^3 batch-{batch} {model}() {'train step' if mode == 'train' else 'forward'}, oracle = "
                      f"torch.nn.functional graph on ATen-CPU fp32, no checkpoint recompute, {best:.2f} s/step"}
-    if mode == "train":
+    if check_only:
+        out["sample"] = out["sample"].replace(f"{steps} ", "1 ", 1)
+    if mode == "train" and not check_only:
         bc = timed(cores, True, 2)
         out["checkpoint_default"] = {"value": vox / bc, "s_per_step": round(bc, 2),
                                      "note": "reference default use_checkpoint=True: + one recompute forward per step (emulated)"}
@@ -173,6 +185,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-check-only", action="store_true",
+                    help="cpu_baseline leg: ONE oracle step (its time is reported as the bounded sample) plus the Dice / "
+                         "output-error check against the CPU reference -- for the large cfg 4 / 5 legs")
+    ap.add_argument("--allow-torch-comm", action="store_true",
+                    help="N > 1: accept torch.distributed's RCCL group if the C ABI's communicator (ctu_comm_*) cannot be "
+                         "brought up on every rank (default: exit non-zero -- the measured path is the C-ABI one)")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--eager", action="store_true", help="do not replay the step from a HIP graph (default: graph)")
     # secondary legs (the defaults above ARE the headline: UNet(), 128^3, fp32, batch 1, train step)
@@ -212,7 +230,7 @@ def main():
         else:
             parallel.distribute(net)                        # eager: bucketed all-reduce overlapped with backward
     from ctunet_amd import optim as ctu_optim
-    opt = ctu_optim.Adam(net.parameters(), lr=1e-4, weight_decay=0, amsgrad=True)         # Model.py:514-520, fused kernel
+    opt = ctu_optim.Adam(net.parameters(), lr=1e-4, weight_decay=0, amsgrad=True).guard(net)     # Model.py:514-520, fused kernel
     x, targets = synth_batch(args.size, rank, dev, args.batch, in_ch, 2 if two else 1)
     holder = Holder()
     handler = ProblemHandler.FlapRecWithShapePriorDoubleOut if two else ProblemHandler.ProblemHandler
@@ -236,6 +254,10 @@ def main():
         # eager is the explicit --eager flag, decided identically on every rank before any step runs
         from ctunet_amd.graph import GraphedTrainStep
         gstep = GraphedTrainStep(net, opt, x, targets, 1.0, 1.0, input_requires_grad=True, distributed=distributed)
+        if distributed and world > 1 and isinstance(gstep.comm, parallel.TorchCommunicator) and not args.allow_torch_comm:
+            # the same decision on every rank (get_communicator agreed on it): the C-ABI communicator is the measured path
+            raise SystemExit("bench.py: the ctu_comm_* RCCL communicator could not be brought up on every rank and the gradient "
+                             "exchange fell back to torch.distributed's process group; pass --allow-torch-comm to measure that")
 
         def step():
             vals = gstep(x, targets)                    # same batch each step (synthetic), copied in like a loader would
@@ -332,7 +354,7 @@ def main():
                                 "achieved_gbs": round(d["bytes"] / (d["total_ms"] * 1e-3) / 1e9, 1)}
             # dominant kernel for the roofline leg: largest share of the step among the kernels whose algorithmic FLOPs are
             # the FLOPs they execute (the fused up-convolution symbols are credited with the two layers they replace)
-            plain = {k: v for k, v in summ.items() if not k.startswith("upconv_fused")}
+            plain = {k: v for k, v in summ.items() if not k.startswith(("upconv_fused", "lp_upconv"))}
             dom = max((plain or summ).items(), key=lambda kv: kv[1]["total_ms"])
             meas = ("HIP events around each launch, " +
                     ("inside the timed region" if mode == "eager" else
@@ -358,8 +380,10 @@ def main():
         desc = {"UNet": "UNet() default (1 in, 2 out, i_size 8, 4 blocks)"}.get(args.model, args.model + "()")
         headline = train and args.model == "UNet" and args.dtype == "f32" and args.batch == 1
         line = {
+            # (a secondary leg always names its model, mode and batch: it can never read as the headline line)
             "metric": "voxels/sec fwd+bwd, 128^3 fp32 patch" if headline else
-                      f"voxels/sec {'fwd+bwd' if train else 'fwd'}, {args.size}^3 {precision} patch",
+                      f"voxels/sec {'fwd+bwd' if train else 'fwd'}, {args.size}^3 {precision} patch, {args.model}() batch {args.batch}"
+                      f"{'' if train else ' eval'} (secondary leg)",
             "value": value, "unit": "voxels/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
@@ -367,11 +391,12 @@ def main():
                        "patch": args.size, "per_gpu_batch": args.batch, "parallelism": f"dp{world}", "launch": mode,
                        "comm_ms_exposed": None if comm_ms_exposed is None else round(comm_ms_exposed, 4),
                        "grad_buckets": (len(gstep.flats) if distributed and mode == "hipgraph" and train else None),
+                       "grad_bucket_bytes": ([int(f.numel()) * 4 for f in gstep.flats] if distributed and mode == "hipgraph" and train else None),
                        "comm_backend": (getattr(gstep.comm, "backend", None) if distributed and mode == "hipgraph" and train else None),
                        "precision_note": (None if args.dtype == "f32" else
-                                          "16-bit activations / activation gradients, fp32 accumulate, statistics, master weights and "
-                                          "weight gradients; the fused decoder up-convolutions (k = 3 nets) run the fp32 kernels on "
-                                          "fp32 copies of their operands"),
+                                          "16-bit activations / activation gradients in HBM and LDS, v_mfma_f32_16x16x32 with fp32 accumulation; "
+                                          "fp32 BatchNorm statistics, master weights, weight gradients and optimizer state; every kernel of "
+                                          "the step reads and writes the 16-bit tensors directly (no fp32 copies)"),
                        "whole_step_tflops_algorithmic": round(flop_vox * value / 1e12, 2),
                        "whole_step_frac_of_mfma_peak": round(flop_vox * value / world / 1e12 /
                                                              (PEAK_16BIT_MFMA_TFLOPS if lowp else PEAK_FP32_MFMA_TFLOPS), 4),
@@ -383,7 +408,7 @@ def main():
             "roofline": roofline, "kernels": kernels,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.size, args.model, precision, args.mode, args.batch)
+            line["cpu_baseline"] = cpu_baseline(args.size, args.model, precision, args.mode, args.batch, check_only=args.cpu_check_only)
         real_stdout.write(json.dumps(line) + "\n")
         real_stdout.flush()
     if distributed:

@@ -1287,6 +1287,15 @@ struct LpWgP {
     float* ws;
     int x_cs, cin_p, relu, g_cs, cout_p;
     int N, D, H, W, tiles_d, tiles_h, tiles_w, ntiles;
+    // lazy BatchNorm + ReLU backward (lp_conv_wgrad_kernel<.., LZ = true>; conv3d.hip's conv3d_wgrad_k3s_kernel<.., LZ> for 16-bit
+    // tensors): g is the gradient w.r.t. the ACTIVATED output, lz_y the raw output (geometry and stride of g), lz_coef
+    // bn_bwd_finalize's [5][lz_cp] rows; the raw-output gradient is rounded to the storage type and written to lz_out
+    const void* lz_y;
+    void* lz_out;
+    const float* lz_scale;
+    const float* lz_shift;
+    const float* lz_coef;
+    int lz_cp;
 };
 
 constexpr int WG_SX = 32;      // LDS bytes per voxel of the 16-channel images
@@ -1327,10 +1336,15 @@ __host__ __device__ constexpr int lp_wg_entry_kw(int KS, int SM, int SN, int q, 
 // (p_d, p_h) output parity per block (blockIdx.y = par4 * n_ci + ci tile); the gradient image's 16 columns are (w-parity,
 // c_out) -- the fine voxels 2w, 2w + 1 are 32 contiguous bytes -- and the 12 taps are (dz, dy, dxx) of the parity's sub-cube of
 // the coarse halo: slabs [12][16 ci][16 = (p_w, co)] in upconv_wgrad_reduce_pw_kernel's layout.
-template <class T, int KS, int BW, int SM, int SN, int UP = 0>
+// LZ: lazy BatchNorm + ReLU backward -- g is the gradient w.r.t. the ACTIVATED output; the raw-output gradient
+//   gy = [y sc + sh > 0] k0 g + (A y + B)   (fp32 arithmetic, rounded once to the storage type)
+// is formed when the gradient box is written to LDS, used for dW, and stored to p.lz_out for the data-gradient kernel, so the
+// separate in-place pass over the layer disappears.  Volumes that are multiples of the box only (host check).
+template <class T, int KS, int BW, int SM, int SN, int UP = 0, bool LZ = false>
 __global__ __launch_bounds__(256) void lp_conv_wgrad_kernel(LpWgP p, int tiles_per_block) {
     typedef typename Vec<T>::v8 v8;
     static_assert(!UP || (KS == 3 && SM == 1 && SN == 1), "fused up-convolution: full 16 x 16 tile, k = 3 halo");
+    static_assert(!LZ || KS == 3, "lazy BatchNorm backward: k = 3 layers");
     constexpr int PK = (KS - 1) / 2;
     constexpr int QN = UP ? 3 : lp_wg_qn(KS, SM, SN), ROWS = UP ? 4 : ((KS == 3) ? 9 : KS);
     constexpr int NTAP = ROWS * QN;                                 // accumulators per block (k = 5: one kd plane)
@@ -1373,7 +1387,8 @@ __global__ __launch_bounds__(256) void lp_conv_wgrad_kernel(LpWgP p, int tiles_p
     // software pipeline: the NEXT box's global loads are in flight (in registers) while this box's taps run
     constexpr int NX = (HV * 2 + 255) / 256, NG = NV * 2 / 256;
     uint4 rx[NX], rg[NG];
-    unsigned okx = 0;                                               // bit it: X item it lies inside the volume
+    uint4 ry[LZ ? NG : 1];                                          // LZ: the raw outputs beside the gradient items
+    unsigned okx = 0, okg = 0;                                      // bit it: X / G item it lies inside the volume
     // per-thread item offsets (bytes, relative to the box's halo origin / first voxel), computed ONCE per block: an interior
     // box then costs one 32-bit add per load instead of ~50 VALU instructions of index arithmetic (the 8-channel layers
     // are VALU-bound otherwise: 16 bytes per voxel leave no room for per-voxel address math)
@@ -1401,6 +1416,20 @@ __global__ __launch_bounds__(256) void lp_conv_wgrad_kernel(LpWgP p, int tiles_p
         else goff[u] = (((td * p.H + th) * p.W + tw + sw) * p.g_cs + cot * 16 + cc * 8) * (int)sizeof(T);
         glive |= live ? (1u << u) : 0u;
     }
+    const ptrdiff_t lz_ydelta = LZ ? reinterpret_cast<const char*>(p.lz_y) - reinterpret_cast<const char*>(p.g) : 0;
+    // LZ: every gradient item of a thread carries the same 8 channels (item parity = thread parity; both halves of a shifted /
+    // w-parity image hold channels 0..7): its BatchNorm-backward vectors sit in registers
+    float lsc[LZ ? 8 : 1], lsh[LZ ? 8 : 1], lk0[LZ ? 8 : 1], lA[LZ ? 8 : 1], lB[LZ ? 8 : 1];
+    if constexpr (LZ) {
+        const int cb = (SN == 2 || UP) ? 0 : cot * 16 + (tid & 1) * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = cb + j;
+            const bool in = c < p.lz_cp;
+            lsc[j] = in ? p.lz_scale[c] : 0.f; lsh[j] = in ? p.lz_shift[c] : 0.f;
+            lk0[j] = in ? p.lz_coef[c] : 0.f; lA[j] = in ? p.lz_coef[3 * p.lz_cp + c] : 0.f; lB[j] = in ? p.lz_coef[4 * p.lz_cp + c] : 0.f;
+        }
+    }
     auto load_box = [&](int tl) {
         int t = tl;
         const int tx = t % p.tiles_w; t /= p.tiles_w;
@@ -1420,11 +1449,12 @@ __global__ __launch_bounds__(256) void lp_conv_wgrad_kernel(LpWgP p, int tiles_p
             for (int u = 0; u < NG; ++u) {
                 const uint4 r = *reinterpret_cast<const uint4*>(gb + (ptrdiff_t)goff[u]);
                 rg[u] = ((glive >> u) & 1u) ? r : make_uint4(0u, 0u, 0u, 0u);
+                if constexpr (LZ) ry[u] = *reinterpret_cast<const uint4*>(gb + lz_ydelta + (ptrdiff_t)goff[u]);
             }
-            okx = xlive;
+            okx = xlive; okg = glive;
             return;
         }
-        okx = 0;
+        okx = 0; okg = 0;
 #pragma unroll
         for (int u = 0; u < NX; ++u) {
             const int it = tid + u * 256, v = it >> 1, c = it & 1;
@@ -1445,10 +1475,12 @@ __global__ __launch_bounds__(256) void lp_conv_wgrad_kernel(LpWgP p, int tiles_p
             const int gd = d0 + td, gh = h0 + th, gw = w0 + tw - ((SN == 2 && c == 1) ? 1 : 0);
             const bool ok = c < nchg && gd < p.D && gh < p.H && gw >= 0 && gw < p.W;
             const int cd = min(gd, p.D - 1), chh = min(gh, p.H - 1), cw = min(max(gw, 0), p.W - 1);
-            const uint4 r = UP ? *reinterpret_cast<const uint4*>(gr + ((((size_t)n * 2 * p.D + 2 * cd + upz) * gH + 2 * chh + upy) * gW + 2 * cw + c) * p.g_cs)
-                               : *reinterpret_cast<const uint4*>(gr + ((((size_t)n * p.D + cd) * p.H + chh) * p.W + cw) * p.g_cs + cot * 16 +
-                                                                 ((SN == 1 && c < nchg) ? c : 0) * 8);
+            const size_t ge = UP ? ((((size_t)n * 2 * p.D + 2 * cd + upz) * gH + 2 * chh + upy) * gW + 2 * cw + c) * p.g_cs
+                                 : ((((size_t)n * p.D + cd) * p.H + chh) * p.W + cw) * p.g_cs + cot * 16 + ((SN == 1 && c < nchg) ? c : 0) * 8;
+            const uint4 r = *reinterpret_cast<const uint4*>(gr + ge);
             rg[u] = ok ? r : make_uint4(0u, 0u, 0u, 0u);
+            if constexpr (LZ) ry[u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.lz_y) + ge);
+            okg |= ok ? (1u << u) : 0u;
         }
     };
     if (tile < tile_end) load_box(tile);
@@ -1481,6 +1513,32 @@ __global__ __launch_bounds__(256) void lp_conv_wgrad_kernel(LpWgP p, int tiles_p
                 *reinterpret_cast<v8*>(&r) = __builtin_convertvector(o, v8);
             }
             *reinterpret_cast<uint4*>(sX + (it >> 1) * WG_SX + (it & 1) * 16) = r;
+        }
+        if constexpr (LZ) {
+            // the registers hold box `tile`: its raw-output gradient (inside the volume; zeros stay zeros), also written out --
+            // an in-volume item's address is the plain box formula (the clamped loads only differ outside the volume)
+            int t = tile;
+            const int tx = t % p.tiles_w; t /= p.tiles_w;
+            const int ty = t % p.tiles_h; t /= p.tiles_h;
+            const int tz = t % p.tiles_d;
+            const int n = t / p.tiles_d;
+            const int d0 = tz * TD, h0 = ty * TH, w0 = tx * BW;
+            T* lzo = reinterpret_cast<T*>(p.lz_out);
+            char* ob = UP ? reinterpret_cast<char*>(lzo + ((((size_t)n * 2 * p.D + 2 * d0 + upz) * gH + 2 * h0 + upy) * gW + 2 * w0) * p.g_cs)
+                          : reinterpret_cast<char*>(lzo + ((((size_t)n * p.D + d0) * p.H + h0) * p.W + w0) * p.g_cs);
+            const bool st_own = SN == 2 ? (tid & 1) == 0 : true;   // a shifted half is the neighbour voxel's value: its own box stores it
+#pragma unroll
+            for (int u = 0; u < NG; ++u) {
+                if (!((okg >> u) & 1u)) continue;
+                const f32x8 gq = __builtin_convertvector(*reinterpret_cast<v8*>(&rg[u]), f32x8);
+                const f32x8 yq = __builtin_convertvector(*reinterpret_cast<v8*>(&ry[u]), f32x8);
+                f32x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    o[j] = fmaf(lk0[j], (fmaf(yq[j], lsc[j], lsh[j]) > 0.f) ? gq[j] : 0.f, fmaf(lA[j], yq[j], lB[j]));
+                *reinterpret_cast<v8*>(&rg[u]) = __builtin_convertvector(o, v8);
+                if (st_own) *reinterpret_cast<uint4*>(ob + (ptrdiff_t)goff[u]) = rg[u];
+            }
         }
 #pragma unroll
         for (int u = 0; u < NG; ++u) {
@@ -1552,6 +1610,228 @@ __global__ __launch_bounds__(256) void lp_conv_wgrad_kernel(LpWgP p, int tiles_p
     for (int e = tid; e < NTAP * 256; e += 256) dst[e] = sS[e];
 }
 
+// ---- 8 -> 8 padded channels, k = 3, volumes that are multiples of the 4 x 8 x 32 box: the "pair" weight gradient (the twin of
+// lp_conv_fwd_pair_kernel).  Same (w-shift, channel) tile as lp_conv_wgrad_kernel<T, 3, 32, 2, 2> -- rows (s, ci), columns
+// (s', co), accumulator (kd, kh) entry = dW[kw = s + s'] -- and the same slabs ([9][16][16] per block, lp_wgrad_reduce_kernel
+// <3, 2, 2>), but
+//   * the LDS images hold each voxel ONCE (16 bytes): the transposing fragment read takes one address per lane, so the lanes of
+//     a shifted half simply read the neighbour voxel (X: v + e_w, G: u - e_w; the gradient rows carry the column left of the
+//     box).  Half the global-load and LDS-write instructions of the 32-byte-per-voxel images;
+//   * the box is 4 x 8 x 32 (halo 2.0x instead of 2.4x), one d plane per wave: the 8 gradient fragments of the plane stay in
+//     registers and every input halo row is read once and used by the 3 kh taps that meet it: 76 fragment reads per 72 MFMAs
+//     instead of 160;
+//   * 512 persistent blocks (2 per CU, 50 KB of LDS each), the next box's loads in flight while this one's taps run.
+// LZ as in lp_conv_wgrad_kernel: the raw-output gradient is formed at the LDS write and stored to p.lz_out.
+constexpr int W8_HH = 10, W8_HW = 34, W8_HV = 6 * W8_HH * W8_HW, W8_GW = 33, W8_GV = 32 * W8_GW;
+constexpr int W8_LDS = 128 + (W8_HV + W8_GV) * 16;
+
+template <class T, bool LZ>
+__global__ __launch_bounds__(256, 2) void lp_wgrad8_kernel(LpWgP p, int tiles_per_block) {
+    typedef typename Vec<T>::v8 v8;
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));     // (u32x4 arrays end up as stack objects)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sX = smem + 128;                                 // [6][10][34] voxels x 16 B
+    unsigned char* sG = sX + (size_t)W8_HV * 16;                    // [32 rows][33] voxels x 16 B (column 0 = w0 - 1)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15, q = i >> 2, pc = i & 3;
+    const T* x = reinterpret_cast<const T*>(p.x);
+    const T* gr = reinterpret_cast<const T*>(p.g);
+    const bool xf = p.scale != nullptr;
+    // transposed-read addresses: K-step voxel kk = 8 g + 4 r + q, lane slot pc = (shift, channel quad)
+    int xa[2], ga[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int kk = 8 * g + 4 * r + q;
+        xa[r] = (kk + (pc >> 1)) * 16 + 8 * (pc & 1);
+        ga[r] = (kk + 1 - (pc >> 1)) * 16 + 8 * (pc & 1);
+    }
+    f32x4 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // staging items: 8 input items (halo voxel it = tid + 256 u), 4 gradient items (box voxel (d = u, h = tid >> 5, w = tid & 31))
+    // and, for the first 32 threads, the gradient row's left neighbour.  Offsets relative to the halo origin / box origin, and
+    // which faces of the halo an item sits on (bits d-, d+, h-, h+, w-, w+): a box that touches the volume's border zeroes
+    // exactly the items on those faces
+    int xoff[8];
+    unsigned xface[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int it = tid + u * 256, v = it < W8_HV ? it : 0;
+        const int pw = v % W8_HW, t2 = v / W8_HW, ph = t2 % W8_HH, pd = t2 / W8_HH;
+        xoff[u] = ((pd * p.H + ph) * p.W + pw) * p.x_cs;
+        xface[u] = (pd == 0 ? 1u : 0u) | (pd == 5 ? 2u : 0u) | (ph == 0 ? 4u : 0u) | (ph == W8_HH - 1 ? 8u : 0u) |
+                   (pw == 0 ? 16u : 0u) | (pw == W8_HW - 1 ? 32u : 0u) | (it < W8_HV ? 0u : 64u);
+    }
+    const int gh = tid >> 5, gw = tid & 31;
+    const int goff0 = (gh * p.W + gw) * p.g_cs, gstep = p.H * p.W * p.g_cs;                 // item u: goff0 + u gstep
+    const int gloff = (((tid >> 3) * p.H + (tid & 7)) * p.W - 1) * p.g_cs;                  // tid < 32: row (d = tid >> 3, h = tid & 7)
+    const long long xlim = ((long long)p.N * p.D * p.H * p.W - 1) * p.x_cs;
+    const ptrdiff_t lz_ydelta = LZ ? reinterpret_cast<const char*>(p.lz_y) - reinterpret_cast<const char*>(p.g) : 0;
+    float lsc[LZ ? 8 : 1], lsh[LZ ? 8 : 1], lk0[LZ ? 8 : 1], lA[LZ ? 8 : 1], lB[LZ ? 8 : 1];
+    if constexpr (LZ) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bool in = j < p.lz_cp;
+            lsc[j] = in ? p.lz_scale[j] : 0.f; lsh[j] = in ? p.lz_shift[j] : 0.f;
+            lk0[j] = in ? p.lz_coef[j] : 0.f; lA[j] = in ? p.lz_coef[3 * p.lz_cp + j] : 0.f; lB[j] = in ? p.lz_coef[4 * p.lz_cp + j] : 0.f;
+        }
+    }
+    float wxs[8], wxh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        wxs[j] = xf ? p.scale[j] : 1.f;
+        wxh[j] = xf ? p.shift[j] : 0.f;
+    }
+    u32x4 rx[8], rg[4], rgl, ry[LZ ? 4 : 1], ryl;
+    unsigned okx = 0;                                               // bit u: input item u lies inside the volume
+    bool okl = false;                                               // the left neighbour column lies inside the volume
+    rgl = u32x4{0u, 0u, 0u, 0u}; ryl = rgl;
+    int tile = blockIdx.x * tiles_per_block;
+    const int tile_end = min(p.ntiles, tile + tiles_per_block);
+    auto box_origin = [&](int tl, int& n, int& d0, int& h0, int& w0) {
+        int t = tl;
+        const int tx = t % p.tiles_w; t /= p.tiles_w;
+        const int ty = t % p.tiles_h; t /= p.tiles_h;
+        const int tz = t % p.tiles_d;
+        n = t / p.tiles_d;
+        d0 = tz * 4; h0 = ty * 8; w0 = tx * 32;
+    };
+    auto load_box = [&](int tl) {
+        int n, d0, h0, w0;
+        box_origin(tl, n, d0, h0, w0);
+        const unsigned bm = (d0 == 0 ? 1u : 0u) | (d0 + 4 == p.D ? 2u : 0u) | (h0 == 0 ? 4u : 0u) | (h0 + 8 == p.H ? 8u : 0u) |
+                            (w0 == 0 ? 16u : 0u) | (w0 + 32 == p.W ? 32u : 0u) | 64u;
+        const long long xb = ((((long long)n * p.D + d0 - 1) * p.H + h0 - 1) * p.W + w0 - 1) * p.x_cs;
+        okx = 0;
+        if (bm == 64u) {                                            // (uniform) interior box
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (u == 7 && tid + 7 * 256 >= W8_HV) continue;
+                rx[u] = *reinterpret_cast<const u32x4*>(x + xb + xoff[u]);
+                okx |= 1u << u;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                long long e = xb + xoff[u];
+                e = e < 0 ? 0 : (e > xlim ? xlim : e);              // any readable address: the item is zeroed at the LDS write
+                rx[u] = *reinterpret_cast<const u32x4*>(x + e);
+                okx |= (xface[u] & bm) ? 0u : (1u << u);
+            }
+        }
+        const long long gb = ((((long long)n * p.D + d0) * p.H + h0) * p.W + w0) * p.g_cs;
+        const char* gp = reinterpret_cast<const char*>(gr + gb);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            rg[u] = *reinterpret_cast<const u32x4*>(gp + (ptrdiff_t)(goff0 + u * gstep) * (int)sizeof(T));
+            if constexpr (LZ) ry[u] = *reinterpret_cast<const u32x4*>(gp + lz_ydelta + (ptrdiff_t)(goff0 + u * gstep) * (int)sizeof(T));
+        }
+        okl = w0 > 0;
+        if (tid < 32 && okl) {
+            rgl = *reinterpret_cast<const u32x4*>(gp + (ptrdiff_t)gloff * (int)sizeof(T));
+            if constexpr (LZ) ryl = *reinterpret_cast<const u32x4*>(gp + lz_ydelta + (ptrdiff_t)gloff * (int)sizeof(T));
+        }
+    };
+    auto lazy_bn = [&](u32x4& gq_, const u32x4& yq_) {
+        const f32x8 gq = __builtin_convertvector(*reinterpret_cast<v8*>(&gq_), f32x8);
+        const f32x8 yq = __builtin_convertvector(*reinterpret_cast<const v8*>(&yq_), f32x8);
+        f32x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            o[j] = fmaf(lk0[j], (fmaf(yq[j], lsc[j], lsh[j]) > 0.f) ? gq[j] : 0.f, fmaf(lA[j], yq[j], lB[j]));
+        *reinterpret_cast<v8*>(&gq_) = __builtin_convertvector(o, v8);
+    };
+    auto rd_tr = [&](const unsigned char* base, const int (&a)[2]) -> v8 {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + a[0]));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + a[1]));
+        const s16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return *reinterpret_cast<const v8*>(&f);
+    };
+    if (tile < tile_end) load_box(tile);
+    for (; tile < tile_end; ++tile) {
+        __syncthreads();                                            // the previous box's readers are done
+        // ---- registers -> LDS: X with the lazy BatchNorm + ReLU of its producer (zero outside the volume), G as it is
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int it = tid + u * 256;
+            if (u == 7 && it >= W8_HV) continue;
+            u32x4 r = rx[u];
+            if (!((okx >> u) & 1u)) r = u32x4{0u, 0u, 0u, 0u};
+            else if (xf) {
+                const f32x8 f = __builtin_convertvector(*reinterpret_cast<v8*>(&r), f32x8);
+                f32x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float a = fmaf(f[j], wxs[j], wxh[j]);
+                    o[j] = p.relu ? fmaxf(a, 0.f) : a;
+                }
+                *reinterpret_cast<v8*>(&r) = __builtin_convertvector(o, v8);
+            }
+            *reinterpret_cast<u32x4*>(sX + it * 16) = r;
+        }
+        if constexpr (LZ) {
+            int n, d0, h0, w0;
+            box_origin(tile, n, d0, h0, w0);
+            char* ob = reinterpret_cast<char*>(reinterpret_cast<T*>(p.lz_out) + ((((long long)n * p.D + d0) * p.H + h0) * p.W + w0) * p.g_cs);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                lazy_bn(rg[u], ry[u]);
+                *reinterpret_cast<u32x4*>(ob + (ptrdiff_t)(goff0 + u * gstep) * (int)sizeof(T)) = rg[u];
+            }
+            if (tid < 32 && okl) lazy_bn(rgl, ryl);                 // (the neighbour box stores its own column)
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) *reinterpret_cast<u32x4*>(sG + ((u * 8 + gh) * W8_GW + gw + 1) * 16) = rg[u];
+        if (tid < 32) *reinterpret_cast<u32x4*>(sG + tid * W8_GW * 16) = okl ? rgl : u32x4{0u, 0u, 0u, 0u};
+        __syncthreads();
+        if (tile + 1 < tile_end) load_box(tile + 1);
+        // ---- this wave's d plane: 8 gradient fragments in registers, 30 input halo rows x the kh taps that meet them
+        v8 gf[8];
+#pragma unroll
+        for (int h = 0; h < 8; ++h) gf[h] = rd_tr(sG + (wave * 8 + h) * (W8_GW * 16), ga);
+#pragma unroll
+        for (int hp = 0; hp < W8_HH; ++hp) {
+            v8 xr[3];
+#pragma unroll
+            for (int kd = 0; kd < 3; ++kd) xr[kd] = rd_tr(sX + ((wave + kd) * W8_HH + hp) * (W8_HW * 16), xa);
+#pragma unroll
+            for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    const int h = hp - kh;
+                    if (h >= 0 && h < 8) acc[kd * 3 + kh] = Mfma<T>::run(xr[kd], gf[h], acc[kd * 3 + kh]);
+                }
+        }
+    }
+    // ---- cross-wave sum in LDS, one slab per block (layout of lp_conv_wgrad_kernel<T, 3, 32, 2, 2>)
+    float* sS = reinterpret_cast<float*>(smem + 128);
+    for (int wv = 0; wv < 4; ++wv) {
+        __syncthreads();
+        if (wave == wv) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float* e = &sS[t * 256 + (4 * g + r) * 16 + i];        // row = (s, ci) 4 g + r, col = (s', co) i
+                    *e = (wv == 0) ? acc[t][r] : (*e + acc[t][r]);
+                }
+        }
+    }
+    __syncthreads();
+    float* dst = p.ws + (size_t)blockIdx.x * (9 * 256);
+    for (int e = tid; e < 9 * 256; e += 256) dst[e] = sS[e];
+}
+
+// the geometries lp_wgrad8_kernel takes
+inline bool lp_wg8_ok(int D, int H, int W, int k, int cin_p, int cout_p) {
+    return k == 3 && cin_p == 8 && cout_p == 8 && D % 4 == 0 && H % 8 == 0 && W % 32 == 0;
+}
+inline void lp_wg8_grid(int ntiles, int* gx, int* tpb) {
+    int g = ntiles < 512 ? ntiles : 512;
+    *tpb = ceil_div(ntiles, g);
+    *gx = ceil_div(ntiles, *tpb);
+}
+
 // dw[co][ci][tap] (torch layout) = sum over the gx slabs of (pair, plane); 16 slab groups x 64 elements per block
 template <int KS, int SM, int SN>
 __global__ __launch_bounds__(1024) void lp_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Co, int Ci,
@@ -1606,16 +1886,25 @@ int lp_wg_fill(LpWgP& p, int N, int D, int H, int W) {
     return p.ntiles;
 }
 
-// persistent blocks per (pair, plane): about 768 blocks in all (3 per CU), at least 1 box each
+// persistent blocks per (pair, plane): about 768 blocks in all (3 per CU), at least 1 box each -- and at least LP_WG_MINBOX
+// boxes each while that still leaves one block per CU: a block's fixed costs (the first box's exposed loads, the cross-wave
+// reduction and its slab, which the reduce kernel reads back) are those of several boxes' MFMAs
+#ifndef LP_WG_MINBOX
+#define LP_WG_MINBOX 2
+#endif
+#ifndef LP_WG8
+#define LP_WG8 1               // 8 -> 8 padded channels, k = 3, box-multiple volumes: lp_wgrad8_kernel (0: the generic kernel)
+#endif
 void lp_wg_grid(int ntiles, int groups, int* gx, int* tpb) {
     int g = 768 / groups;
     if (g < 16) g = 16;
+    if (g * LP_WG_MINBOX > ntiles && ntiles / LP_WG_MINBOX * groups >= 256) g = ntiles / LP_WG_MINBOX;
     if (g > ntiles) g = ntiles;
     *tpb = ceil_div(ntiles, g);
     *gx = ceil_div(ntiles, *tpb);
 }
 
-template <class T, int KS, int BW, int SM, int SN>
+template <class T, int KS, int BW, int SM, int SN, bool LZ = false>
 int lp_wgrad_launch(LpWgP& p, int gx, int tpb, int pairs, hipStream_t st) {
     constexpr int PK = (KS - 1) / 2, RPK = 32 / BW, TH = 4 * RPK;
     constexpr int HD = (KS == 3) ? 6 : 4, HV = HD * (TH + 2 * PK) * (BW + 2 * PK), NV = 4 * TH * BW;
@@ -1625,28 +1914,28 @@ int lp_wgrad_launch(LpWgP& p, int gx, int tpb, int pairs, hipStream_t st) {
     // the dynamic-LDS limit is raised only for launches that need more than the default 64 KB, and only to what they need
     static size_t raised = 64 * 1024;
     if (lds > raised) {
-        CTU_REQUIRE(hipFuncSetAttribute((const void*)lp_conv_wgrad_kernel<T, KS, BW, SM, SN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess,
+        CTU_REQUIRE(hipFuncSetAttribute((const void*)lp_conv_wgrad_kernel<T, KS, BW, SM, SN, 0, LZ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess,
                     "lp_conv3d_wgrad: cannot raise the dynamic LDS limit");
         raised = lds;
     }
-    lp_conv_wgrad_kernel<T, KS, BW, SM, SN><<<dim3(gx, pairs, KS == 3 ? 1 : KS), 256, lds, st>>>(p, tpb);
+    lp_conv_wgrad_kernel<T, KS, BW, SM, SN, 0, LZ><<<dim3(gx, pairs, KS == 3 ? 1 : KS), 256, lds, st>>>(p, tpb);
     CTU_CHECK_LAUNCH("lp_conv3d_wgrad");
     return CTU_OK;
 }
 
 // fused up-convolution (UP = 2): COARSE boxes 4 x TH x BW, blockIdx.y = (p_d, p_h) parity x input-channel tile
-template <class T, int BW>
+template <class T, int BW, bool LZ = false>
 int lp_upwg_launch(LpWgP& p, int gx, int tpb, hipStream_t st) {
     constexpr int RPK = 32 / BW, TH = 4 * RPK, HV = 6 * (TH + 2) * (BW + 2), NV = 4 * TH * BW;
     size_t lds = 128 + (size_t)(HV + NV) * WG_SX;
     if (lds < 128 + (size_t)12 * 1024) lds = 128 + (size_t)12 * 1024;
     static size_t raised = 64 * 1024;
     if (lds > raised) {
-        CTU_REQUIRE(hipFuncSetAttribute((const void*)lp_conv_wgrad_kernel<T, 3, BW, 1, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess,
+        CTU_REQUIRE(hipFuncSetAttribute((const void*)lp_conv_wgrad_kernel<T, 3, BW, 1, 1, 2, LZ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess,
                     "lp_upconv_fused_wgrad: cannot raise the dynamic LDS limit");
         raised = lds;
     }
-    lp_conv_wgrad_kernel<T, 3, BW, 1, 1, 2><<<dim3(gx, 4 * (p.cin_p >> 4)), 256, lds, st>>>(p, tpb);
+    lp_conv_wgrad_kernel<T, 3, BW, 1, 1, 2, LZ><<<dim3(gx, 4 * (p.cin_p >> 4)), 256, lds, st>>>(p, tpb);
     CTU_CHECK_LAUNCH("lp_upconv_fused_wgrad");
     return CTU_OK;
 }
@@ -1679,23 +1968,36 @@ __global__ __launch_bounds__(1024) void lp_upwg_reduce_kernel(const float* __res
 inline int lp_wg_sm(int W, int cin_p) { return (W >= 16 && cin_p == 8) ? 2 : 1; }
 inline int lp_wg_sn(int W, int cout_p) { return (W >= 16 && cout_p == 8) ? 2 : 1; }
 
-template <class T, int KS, int BW>
+template <class T, int KS, int BW, bool LZ = false>
 int lp_wgrad_launch_s(LpWgP& p, int gx, int tpb, int pairs, hipStream_t st) {
     if constexpr (BW >= 16) {
         const int sm = lp_wg_sm(p.W, p.cin_p), sn = lp_wg_sn(p.W, p.cout_p);
-        if (sm == 2 && sn == 2) return lp_wgrad_launch<T, KS, BW, 2, 2>(p, gx, tpb, pairs, st);
-        if (sm == 2) return lp_wgrad_launch<T, KS, BW, 2, 1>(p, gx, tpb, pairs, st);
-        if (sn == 2) return lp_wgrad_launch<T, KS, BW, 1, 2>(p, gx, tpb, pairs, st);
+        if (sm == 2 && sn == 2) return lp_wgrad_launch<T, KS, BW, 2, 2, LZ>(p, gx, tpb, pairs, st);
+        if (sm == 2) return lp_wgrad_launch<T, KS, BW, 2, 1, LZ>(p, gx, tpb, pairs, st);
+        if (sn == 2) return lp_wgrad_launch<T, KS, BW, 1, 2, LZ>(p, gx, tpb, pairs, st);
     }
-    return lp_wgrad_launch<T, KS, BW, 1, 1>(p, gx, tpb, pairs, st);
+    return lp_wgrad_launch<T, KS, BW, 1, 1, LZ>(p, gx, tpb, pairs, st);
 }
 
 template <class T, int KS>
 int lp_wgrad_dispatch(LpWgP& p, int gx, int tpb, int pairs, hipStream_t st) {
     const int bw = lp_wg_box_w(p.W);
+    if constexpr (KS == 3) {
+        if (p.lz_y) {                                               // lazy BatchNorm backward (16-wide boxes and wider)
+            if (bw == 32) return lp_wgrad_launch_s<T, 3, 32, true>(p, gx, tpb, pairs, st);
+            return lp_wgrad_launch_s<T, 3, 16, true>(p, gx, tpb, pairs, st);
+        }
+    }
     if (bw == 32) return lp_wgrad_launch_s<T, KS, 32>(p, gx, tpb, pairs, st);
     if (bw == 16) return lp_wgrad_launch_s<T, KS, 16>(p, gx, tpb, pairs, st);
     return lp_wgrad_launch_s<T, KS, 8>(p, gx, tpb, pairs, st);
+}
+
+// lazy BatchNorm backward inside the 16-bit weight-gradient kernel: k = 3, volumes at least 16 wide that are multiples of the box
+inline bool lp_wg_lazy_ok(int D, int H, int W, int k) {
+    if (k != 3 || W < 16) return false;
+    const int bw = lp_wg_box_w(W), th = 4 * (32 / bw);
+    return D % 4 == 0 && H % th == 0 && W % bw == 0;
 }
 
 }  // namespace
@@ -1802,12 +2104,45 @@ extern "C" size_t ctu_lp_conv3d_wgrad_ws_floats(int N, int D, int H, int W, int 
     int gx, tpb;
     lp_wg_grid(ntiles, pairs * planes, &gx, &tpb);
     const int ntap = (k == 3 ? 9 : k) * lp_wg_qn(k, lp_wg_sm(W, cin_p), lp_wg_sn(W, cout_p));
-    return (size_t)gx * pairs * planes * ntap * 256;
+    size_t n = (size_t)gx * pairs * planes * ntap * 256;
+    if (lp_wg8_ok(D, H, W, k, cin_p, cout_p) && n < (size_t)512 * 9 * 256) n = (size_t)512 * 9 * 256;     // lp_wgrad8_kernel's slabs
+    return n;
 }
+
+struct LpLazy { const void* y; const float* scale; const float* shift; const float* coef; void* out; int cp; };
+
+static int lp_conv3d_wgrad_impl(int dtype, const void* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
+                                int in_relu, const void* gout, int g_cs, int cout_p, float* dw, int Co, int Ci,
+                                const int32_t* cinv, float* ws, int N, int D, int H, int W, int k, const LpLazy* lz, void* stream);
 
 extern "C" int ctu_lp_conv3d_wgrad(int dtype, const void* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
                                    int in_relu, const void* gout, int g_cs, int cout_p, float* dw, int Co, int Ci,
                                    const int32_t* cinv, float* ws, int N, int D, int H, int W, int k, void* stream) {
+    return lp_conv3d_wgrad_impl(dtype, in, in_cs, cin_p, in_scale, in_shift, in_relu, gout, g_cs, cout_p, dw, Co, Ci, cinv, ws, N, D, H, W,
+                                k, nullptr, stream);
+}
+
+extern "C" int ctu_lp_conv3d_wgrad_bn_supported(int N, int D, int H, int W, int k, int cin_p, int cout_p) {
+    return (N > 0 && cin_p > 0 && cout_p > 0 && lp_wg_lazy_ok(D, H, W, k)) ? 1 : 0;
+}
+
+// ctu_conv3d_wgrad_bn for 16-bit tensors: ga = gradient w.r.t. the ACTIVATED output, y = the raw output (geometry of ga), coef =
+// ctu_bn_bwd_finalize's [5][cout_p] rows; gy_out (geometry of ga, must not alias it) receives the raw-output gradient.
+extern "C" int ctu_lp_conv3d_wgrad_bn(int dtype, const void* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
+                                      int in_relu, const void* ga, int g_cs, int cout_p, const void* y, const float* bn_scale,
+                                      const float* bn_shift, const float* coef, void* gy_out, float* dw, int Co, int Ci,
+                                      const int32_t* cinv, float* ws, int N, int D, int H, int W, int k, void* stream) {
+    CTU_REQUIRE(y && bn_scale && bn_shift && coef && gy_out && gy_out != ga, "lp_conv3d_wgrad_bn: null pointer / gy_out aliases ga");
+    CTU_REQUIRE(lp_wg_lazy_ok(D, H, W, k), "lp_conv3d_wgrad_bn: geometry not supported (ask ctu_lp_conv3d_wgrad_bn_supported)");
+    CTU_REQUIRE(((uintptr_t)y & 15) == 0 && ((uintptr_t)gy_out & 15) == 0, "lp_conv3d_wgrad_bn: 16-byte alignment");
+    const LpLazy lz = {y, bn_scale, bn_shift, coef, gy_out, cout_p};
+    return lp_conv3d_wgrad_impl(dtype, in, in_cs, cin_p, in_scale, in_shift, in_relu, ga, g_cs, cout_p, dw, Co, Ci, cinv, ws, N, D, H, W,
+                                k, &lz, stream);
+}
+
+static int lp_conv3d_wgrad_impl(int dtype, const void* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
+                                int in_relu, const void* gout, int g_cs, int cout_p, float* dw, int Co, int Ci,
+                                const int32_t* cinv, float* ws, int N, int D, int H, int W, int k, const LpLazy* lz, void* stream) {
     CTU_REQUIRE(in && gout && dw && ws, "lp_conv3d_wgrad: null pointer");
     CTU_REQUIRE((k == 3 || k == 5) && cin_p > 0 && cin_p % 8 == 0 && cout_p > 0 && cout_p % 8 == 0,
                 "lp_conv3d_wgrad: k=%d cin_p=%d cout_p=%d", k, cin_p, cout_p);
@@ -1817,11 +2152,27 @@ extern "C" int ctu_lp_conv3d_wgrad(int dtype, const void* in, int in_cs, int cin
     LpWgP p{};
     p.x = in; p.g = gout; p.scale = in_scale; p.shift = in_shift; p.ws = ws;
     p.x_cs = in_cs; p.cin_p = cin_p; p.relu = in_relu; p.g_cs = g_cs; p.cout_p = cout_p;
+    if (lz) { p.lz_y = lz->y; p.lz_out = lz->out; p.lz_scale = lz->scale; p.lz_shift = lz->shift; p.lz_coef = lz->coef; p.lz_cp = lz->cp; }
+    hipStream_t st = (hipStream_t)stream;
+    if (LP_WG8 && lp_wg8_ok(D, H, W, k, cin_p, cout_p)) {
+        p.N = N; p.D = D; p.H = H; p.W = W;
+        p.tiles_d = D / 4; p.tiles_h = H / 8; p.tiles_w = W / 32;
+        p.ntiles = N * p.tiles_d * p.tiles_h * p.tiles_w;
+        int gx8, tpb8;
+        lp_wg8_grid(p.ntiles, &gx8, &tpb8);
+        CTU_DISPATCH_LP(dtype, {
+            if (lz) lp_wgrad8_kernel<T, true><<<gx8, 256, W8_LDS, st>>>(p, tpb8);
+            else lp_wgrad8_kernel<T, false><<<gx8, 256, W8_LDS, st>>>(p, tpb8);
+        });
+        CTU_CHECK_LAUNCH("lp_conv3d_wgrad (8 -> 8)");
+        lp_wgrad_reduce_kernel<3, 2, 2><<<dim3(ceil_div(9 * 256, 64)), 1024, 0, st>>>(ws, dw, Co, Ci, cinv, cin_p, cout_p, gx8);
+        CTU_CHECK_LAUNCH("lp_conv3d_wgrad reduce");
+        return CTU_OK;
+    }
     const int ntiles = lp_wg_fill(p, N, D, H, W);
     const int nci = (cin_p + 15) >> 4, nco = (cout_p + 15) >> 4, pairs = nci * nco, planes = k == 3 ? 1 : k;
     int gx, tpb;
     lp_wg_grid(ntiles, pairs * planes, &gx, &tpb);
-    hipStream_t st = (hipStream_t)stream;
     int rc = CTU_OK;
     CTU_DISPATCH_LP(dtype, {
         if (k == 3) rc = lp_wgrad_dispatch<T, 3>(p, gx, tpb, pairs, st);
@@ -1857,9 +2208,30 @@ extern "C" size_t ctu_lp_upconv_fused_wgrad_ws_floats(int N, int D, int H, int W
     lp_upwg_geom(N, D, H, W, cin_p, &gx, &tpb);
     return (size_t)gx * 4 * (cin_p >> 4) * 12 * 256;
 }
+static int lp_upconv_fused_wgrad_impl(int dtype, const void* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
+                                      int in_relu, const void* gout, int g_cs, float* dweff, float* ws, int N, int D, int H,
+                                      int W, const LpLazy* lz, void* stream);
 extern "C" int ctu_lp_upconv_fused_wgrad(int dtype, const void* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
                                          int in_relu, const void* gout, int g_cs, float* dweff, float* ws, int N, int D, int H,
                                          int W, void* stream) {
+    return lp_upconv_fused_wgrad_impl(dtype, in, in_cs, cin_p, in_scale, in_shift, in_relu, gout, g_cs, dweff, ws, N, D, H, W, nullptr, stream);
+}
+extern "C" int ctu_lp_upconv_fused_wgrad_bn_supported(int N, int D, int H, int W, int cin_p) {
+    return (N > 0 && cin_p % 16 == 0 && lp_wg_lazy_ok(D, H, W, 3)) ? 1 : 0;
+}
+// ... with the BatchNorm + ReLU backward of the fused op's output folded in (ctu_upconv_fused_wgrad_bn for 16-bit tensors)
+extern "C" int ctu_lp_upconv_fused_wgrad_bn(int dtype, const void* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
+                                            int in_relu, const void* ga, int g_cs, const void* y, const float* bn_scale,
+                                            const float* bn_shift, const float* coef, void* gy_out, float* dweff, float* ws,
+                                            int N, int D, int H, int W, void* stream) {
+    CTU_REQUIRE(y && bn_scale && bn_shift && coef && gy_out && gy_out != ga, "lp_upconv_fused_wgrad_bn: null pointer / gy_out aliases ga");
+    CTU_REQUIRE(ctu_lp_upconv_fused_wgrad_bn_supported(N, D, H, W, cin_p), "lp_upconv_fused_wgrad_bn: geometry not supported");
+    const LpLazy lz = {y, bn_scale, bn_shift, coef, gy_out, 8};
+    return lp_upconv_fused_wgrad_impl(dtype, in, in_cs, cin_p, in_scale, in_shift, in_relu, ga, g_cs, dweff, ws, N, D, H, W, &lz, stream);
+}
+static int lp_upconv_fused_wgrad_impl(int dtype, const void* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
+                                      int in_relu, const void* gout, int g_cs, float* dweff, float* ws, int N, int D, int H,
+                                      int W, const LpLazy* lz, void* stream) {
     CTU_REQUIRE(in && gout && dweff && ws, "lp_upconv_fused_wgrad: null pointer");
     CTU_REQUIRE(cin_p >= 16 && cin_p % 16 == 0 && in_cs >= cin_p && in_cs % 8 == 0 && g_cs == 8 && ((uintptr_t)in & 15) == 0 &&
                 ((uintptr_t)gout & 15) == 0, "lp_upconv_fused_wgrad: cin_p=%d in_cs=%d g_cs=%d (gradient stride must be 8)", cin_p, in_cs, g_cs);
@@ -1867,6 +2239,7 @@ extern "C" int ctu_lp_upconv_fused_wgrad(int dtype, const void* in, int in_cs, i
     LpWgP p{};
     p.x = in; p.g = gout; p.scale = in_scale; p.shift = in_shift; p.ws = ws;
     p.x_cs = in_cs; p.cin_p = cin_p; p.relu = in_relu; p.g_cs = g_cs; p.cout_p = 16;
+    if (lz) { p.lz_y = lz->y; p.lz_out = lz->out; p.lz_scale = lz->scale; p.lz_shift = lz->shift; p.lz_coef = lz->coef; p.lz_cp = lz->cp; }
     lp_wg_fill(p, N, D, H, W);
     int gx, tpb;
     lp_upwg_geom(N, D, H, W, cin_p, &gx, &tpb);
@@ -1874,7 +2247,8 @@ extern "C" int ctu_lp_upconv_fused_wgrad(int dtype, const void* in, int in_cs, i
     const int bw = lp_wg_box_w(W);
     int rc = CTU_OK;
     CTU_DISPATCH_LP(dtype, {
-        if (bw == 32) rc = lp_upwg_launch<T, 32>(p, gx, tpb, st);
+        if (lz) rc = bw == 32 ? lp_upwg_launch<T, 32, true>(p, gx, tpb, st) : lp_upwg_launch<T, 16, true>(p, gx, tpb, st);
+        else if (bw == 32) rc = lp_upwg_launch<T, 32>(p, gx, tpb, st);
         else if (bw == 16) rc = lp_upwg_launch<T, 16>(p, gx, tpb, st);
         else rc = lp_upwg_launch<T, 8>(p, gx, tpb, st);
     });

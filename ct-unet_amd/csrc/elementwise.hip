@@ -465,10 +465,17 @@ struct AdamTable {
     int64_t n[ADAM_MAXT];
 };
 
-__global__ void adam_step_inc_kernel(float* step) { step[0] += 1.f; }
+// skip: optional device flag (float[1]); non-zero = this step's gradients overflowed (ctu_scale_tensors found a non-finite
+// value while un-scaling fp16 gradients): the whole update is skipped -- parameters, moments AND the step counter stay
+// as they are, what torch.amp.GradScaler.step does.  Works inside a replayed graph (the flag is read on the device).
+__global__ void adam_step_inc_kernel(float* step, const float* __restrict__ skip) {
+    if (skip && skip[0] != 0.f) return;
+    step[0] += 1.f;
+}
 
 __global__ void adam_amsgrad_kernel(AdamTable tb, const float* __restrict__ step, float lr, float beta1, float beta2,
-                                    float omb1, float omb2, float eps, float wd, int decoupled) {
+                                    float omb1, float omb2, float eps, float wd, int decoupled, const float* __restrict__ skip) {
+    if (skip && skip[0] != 0.f) return;
     const int t = blockIdx.y;
     const int64_t n = tb.n[t];
     float* __restrict__ p = tb.p[t];
@@ -503,11 +510,18 @@ struct ScaleTable {
     int64_t n[ADAM_MAXT];
 };
 
-__global__ void scale_tensors_kernel(ScaleTable tb, float s) {
+// nonfinite: optional device flag (float[1]) set to 1 when any scaled value is inf / NaN (the fp16 backward overflowed)
+__global__ void scale_tensors_kernel(ScaleTable tb, float s, float* __restrict__ nonfinite) {
     const int t = blockIdx.y;
     float* __restrict__ p = tb.p[t];
     const int64_t n = tb.n[t];
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] *= s;
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = p[i] * s;
+        p[i] = v;
+        bad |= !(fabsf(v) <= 3.4028234e38f);            // inf or NaN
+    }
+    if (nonfinite && bad) nonfinite[0] = 1.f;          // (every writer stores the same value)
 }
 
 }  // namespace
@@ -793,10 +807,10 @@ extern "C" int ctu_lp_channel_sum(int dtype, const void* x, int cs, int cp, int6
 }
 
 extern "C" int ctu_adam_amsgrad(void* const* ptrs, const int64_t* sizes, int n, float* step, double lr, double beta1,
-                                double beta2, double eps, double weight_decay, int decoupled, void* stream) {
+                                double beta2, double eps, double weight_decay, int decoupled, const float* skip_flag, void* stream) {
     CTU_REQUIRE(ptrs && sizes && n > 0 && step, "adam_amsgrad: bad argument");
     hipStream_t st = (hipStream_t)stream;
-    adam_step_inc_kernel<<<1, 1, 0, st>>>(step);
+    adam_step_inc_kernel<<<1, 1, 0, st>>>(step, skip_flag);
     CTU_CHECK_LAUNCH("adam_step_inc");
     for (int t0 = 0; t0 < n; t0 += ADAM_MAXT) {
         const int nt = (n - t0) < ADAM_MAXT ? (n - t0) : ADAM_MAXT;
@@ -814,13 +828,13 @@ extern "C" int ctu_adam_amsgrad(void* const* ptrs, const int64_t* sizes, int n, 
         if (gx < 1) gx = 1;
         adam_amsgrad_kernel<<<dim3(gx, nt), EW_BLOCK, 0, st>>>(tb, step, (float)lr, (float)beta1, (float)beta2,
                                                               (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps,
-                                                              (float)weight_decay, decoupled);
+                                                              (float)weight_decay, decoupled, skip_flag);
         CTU_CHECK_LAUNCH("adam_amsgrad");
     }
     return CTU_OK;
 }
 
-extern "C" int ctu_scale_tensors(void* const* ptrs, const int64_t* sizes, int n, float sc, void* stream) {
+extern "C" int ctu_scale_tensors(void* const* ptrs, const int64_t* sizes, int n, float sc, float* nonfinite_flag, void* stream) {
     CTU_REQUIRE(ptrs && sizes && n > 0, "scale_tensors: bad argument");
     for (int t0 = 0; t0 < n; t0 += ADAM_MAXT) {
         const int nt = (n - t0) < ADAM_MAXT ? (n - t0) : ADAM_MAXT;
@@ -835,7 +849,7 @@ extern "C" int ctu_scale_tensors(void* const* ptrs, const int64_t* sizes, int n,
         int gx = (int)ceil_div64(mx, EW_BLOCK * 4);
         if (gx > 128) gx = 128;
         if (gx < 1) gx = 1;
-        scale_tensors_kernel<<<dim3(gx, nt), EW_BLOCK, 0, (hipStream_t)stream>>>(tb, sc);
+        scale_tensors_kernel<<<dim3(gx, nt), EW_BLOCK, 0, (hipStream_t)stream>>>(tb, sc, nonfinite_flag);
         CTU_CHECK_LAUNCH("scale_tensors");
     }
     return CTU_OK;

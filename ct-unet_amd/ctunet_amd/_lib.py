@@ -124,6 +124,10 @@ SIGNATURES = {
     "ctu_lp_upconv_fused_fwd": (I, [I, P, I, I, P, P, I, P, P, P, I, P, I, I, I, I, P]),
     "ctu_lp_upconv_fused_wgrad_ws_floats": (Z, [I, I, I, I, I]),
     "ctu_lp_upconv_fused_wgrad": (I, [I, P, I, I, P, P, I, P, I, P, P, I, I, I, I, P]),
+    "ctu_lp_upconv_fused_wgrad_bn_supported": (I, [I, I, I, I, I]),
+    "ctu_lp_upconv_fused_wgrad_bn": (I, [I, P, I, I, P, P, I, P, I, P, P, P, P, P, P, P, I, I, I, I, P]),
+    "ctu_lp_conv3d_wgrad_bn_supported": (I, [I, I, I, I, I, I, I]),
+    "ctu_lp_conv3d_wgrad_bn": (I, [I, P, I, I, P, P, I, P, I, I, P, P, P, P, P, P, I, I, P, P, I, I, I, I, I, P]),
     "ctu_lp_upconv_fused_project": (I, [I, P, P, I, I, I, I, I, I, P, P, P, I, I, I, P, P, P, P, P]),
     "ctu_lp_upconv_fused_bwd_data": (I, [I, P, I, P, P, I, I, I, I, I, I, P]),
     "ctu_lp_conv3d_layout": (I, [I, I, I, I]),
@@ -154,7 +158,7 @@ SIGNATURES = {
     "ctu_lp_channel_sum": (I, [I, P, I, I, L, P, P, I, P]),
     "ctu_lp_head_fwd": (I, [I, P, I, I, P, P, I, P, P, P, I, I, I, I, P, P, I, L, P]),
     "ctu_lp_head_bwd_bn": (I, [I, P, I, I, P, P, I, P, P, P, I, I, I, I, P, P, P, I, P, P, P, I, L, P, P, I, P, P, P]),
-    "ctu_scale_tensors": (I, [P, P, I, F, P]),
+    "ctu_scale_tensors": (I, [P, P, I, F, P, P]),
     "ctu_comm_available": (I, []),
     "ctu_comm_unique_id": (I, [P]),
     "ctu_comm_init": (I, [C.POINTER(C.c_void_p), I, I, P]),
@@ -162,7 +166,7 @@ SIGNATURES = {
     "ctu_comm_destroy": (I, [P]),
     "ctu_channel_sum_num_blocks": (I, [L]),
     "ctu_channel_sum": (I, [P, I, I, L, P, P, I, P]),
-    "ctu_adam_amsgrad": (I, [P, P, I, P, D, D, D, D, D, I, P]),
+    "ctu_adam_amsgrad": (I, [P, P, I, P, D, D, D, D, D, I, P, P]),
 }
 
 _lib = None

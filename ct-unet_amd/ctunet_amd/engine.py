@@ -42,6 +42,10 @@ BN_MOMENTUM = 0.1
 # BatchNorm + ReLU backward applied by the weight-gradient kernel while it stages the gradient (ops.conv3d_wgrad_bn) instead
 # of a separate in-place pass over the layer (CTUNET_LAZY_BN=0: the separate ctu_bn_relu_bwd_apply pass)
 LAZY_BN = os.environ.get("CTUNET_LAZY_BN", "1") != "0"
+# ... on the 16-bit path too (ops.conv3d_wgrad_bn with 16-bit tensors).  Off by default: the 16-bit weight-gradient kernels are
+# bound by their staging instructions, and the folded transform costs them what the separate pass cost (UNet() 128^3 bf16:
+# 2.564 ms with it, 2.560 without)
+LAZY_BN_LP = os.environ.get("CTUNET_LAZY_BN_LP", "0") != "0"
 # the launch that writes a BatchNorm's partial rows also finalizes them (its last block: ctu_bn_tail / ctu_bn_bwd_tail)
 # instead of a separate ctu_bn_finalize / ctu_bn_bwd_finalize launch (CTUNET_BN_TAIL=0: the separate launches)
 BN_TAIL = os.environ.get("CTUNET_BN_TAIL", "0") != "0"
@@ -99,6 +103,15 @@ class UNetEngine:
         self._tail_slots: Dict[Tuple[str, str], int] = {}
 
     # ------------------------------------------------------------------ small helpers
+    def overflow_flag(self, device) -> torch.Tensor:
+        """float32[1] on the device: 1 after a float16 backward whose (un-scaled) gradients contained inf / NaN, else 0.  One
+        tensor per engine and device for its whole life (stable pointer: captured graphs and the optimizer keep it)."""
+        flags = self.__dict__.setdefault("_overflow", {})
+        f = flags.get(str(device))
+        if f is None:
+            f = flags[str(device)] = torch.zeros(1, dtype=torch.float32, device=device)
+        return f
+
     def _counter(self, layer: str, direction: str, device) -> Optional[torch.Tensor]:
         """The zero-initialised ticket word of a BatchNorm layer's in-launch finalize (None: BN_TAIL off).  The tail puts
         it back to zero itself, so the words are allocated once and live as long as the engine (graph replays included)."""
@@ -472,12 +485,14 @@ class UNetEngine:
         up_in: rec is a fused up-convolution and this is its coarse input -- only the BatchNorm part runs here; returns what
         the caller hands to ops.upconv_fused_wgrad(lazy=...) (None: ga already holds the raw-output gradient)."""
         k = self.plan.k
-        fp32 = self.dtype == torch.float32 and LAZY_BN and ga.cs == rec.y.cs
+        can = LAZY_BN and ga.cs == rec.y.cs and (not ga.lp or LAZY_BN_LP)
         if up_in is not None:
-            lazy = fp32 and ops.upconv_fused_wgrad_bn_supported(up_in.dims, up_in.cp, ga.cp)
+            lazy = can and (ops.lp_upconv_fused_wgrad_bn_supported(up_in.dims, up_in.cp) if ga.lp else
+                            ops.upconv_fused_wgrad_bn_supported(up_in.dims, up_in.cp, ga.cp))
+        elif rec.first is not None:
+            lazy = can and not rec.bias and not ga.lp
         else:
-            lazy = fp32 and not rec.bias and (rec.first is not None or (
-                rec.x is not None and ops.conv3d_wgrad_bn_supported(ga.dims, k, rec.x.cp, ga.cp)))
+            lazy = can and not rec.bias and rec.x is not None and ops.conv3d_wgrad_bn_supported(ga.dims, k, rec.x.cp, ga.cp, self.dtype)
         res = ops.bn_relu_bwd(rec.y, ga, rec.vec, P[rec.bn + ".weight"].detach(), rec.cout, part, self._replay(P, rec),
                               pre_reduced, self._counter(rec.bn, "bwd", ga.buf.device), finalized, lazy)
         grads[rec.bn + ".weight"], grads[rec.bn + ".bias"] = res[0], res[1]
@@ -518,11 +533,16 @@ class UNetEngine:
         # float16 gradients: scale what comes in (the per-voxel gradient of a mean-reduced loss underflows fp16), un-scale
         # every parameter gradient and dx on the way out; bf16 / fp32 need none
         gs = 1.0
+        flag = None
         if self.dtype == torch.float16:
             gs = self.loss_scale if self.loss_scale else float(2 ** max(0, (n * d * h * w).bit_length() - 5))
             g0 = g0.contiguous().clone()
             g1 = None if g1 is None else g1.contiguous().clone()
             ops.scale_tensors([g0, g1], gs)
+            # overflow guard: the un-scaling launches below set this flag when a gradient came out inf / NaN (a static loss
+            # scale can overflow the 16-bit activation gradients); the fused optimizer skips the step when it is set
+            flag = self.overflow_flag(dev)
+            flag.zero_()
         grads: Dict[str, torch.Tensor] = {}
         emitted: set = set()
         self._gy_bufs: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
@@ -533,7 +553,7 @@ class UNetEngine:
             new = [(nm, g) for nm, g in grads.items() if nm not in emitted and g is not None]
             emitted.update(nm for nm, _ in new)
             if gs != 1.0 and new:
-                ops.scale_tensors([g for _, g in new], 1.0 / gs)
+                ops.scale_tensors([g for _, g in new], 1.0 / gs, flag)
             if sync is not None:
                 sync.push(new)
         k = plan.k
@@ -625,14 +645,10 @@ class UNetEngine:
                 # and the data gradient straight back to the coarse grid
                 lz = self._conv_bn_bwd(P, r1, g_u1, None, grads, ws, part, up_in=x_in)
                 gq = g_u1
-                if g_u1.lp:                           # 16-bit fused kernels (upconv_lp.hip)
-                    dwt, dbt, dw3 = ops.lp_upconv_fused_wgrad(x_in, gq, ct, blk.cout, P[f"{blk.prefix}.0.bias"],
-                                                              self._up_cache[blk.prefix][4], imap_t)
-                else:
-                    dwt, dbt, dw3 = ops.upconv_fused_wgrad(x_in, gq, ct, blk.cout, P[f"{blk.prefix}.0.bias"],
-                                                           self._up_cache[blk.prefix][4], imap_t, lz)
-                    if lz is not None:
-                        gq = lz[3]                    # the raw-output gradient the weight-gradient kernel wrote
+                up_wgrad = ops.lp_upconv_fused_wgrad if g_u1.lp else ops.upconv_fused_wgrad      # 16-bit: upconv_lp.hip
+                dwt, dbt, dw3 = up_wgrad(x_in, gq, ct, blk.cout, P[f"{blk.prefix}.0.bias"], self._up_cache[blk.prefix][4], imap_t, lz)
+                if lz is not None:
+                    gq = lz[3]                        # the raw-output gradient the weight-gradient kernel wrote
                 grads[f"{blk.prefix}.1.weight"] = dw3
                 grads[f"{blk.prefix}.0.weight"], grads[f"{blk.prefix}.0.bias"] = dwt, dbt
                 if g_u1.lp:
@@ -688,11 +704,22 @@ class UNetEngine:
             emit()
         emit()
         if gs != 1.0 and dx is not None:
-            ops.scale_tensors([dx], 1.0 / gs)
+            ops.scale_tensors([dx], 1.0 / gs, flag)
         if sync is not None:
+            if flag is not None:
+                # N > 1: the overflow flag travels with the last gradient bucket, so that every rank skips the step when ANY
+                # rank overflowed (the mean of the ranks' 0 / 1 flags); the caller copies grads["__overflow__"] back into
+                # overflow_flag() once the exchange has completed (fold_overflow)
+                sync.push([("__overflow__", flag.clone())])
             grads.update(sync.finish())
         self._gy_bufs = {}
         return grads, dx
+
+    def fold_overflow(self, grads: Dict[str, torch.Tensor], device) -> None:
+        """After a gradient exchange: the ranks' combined overflow flag (see backward) replaces this rank's own."""
+        red = grads.pop("__overflow__", None)
+        if red is not None:
+            self.overflow_flag(device).copy_(red.reshape(1))
 
 
 # ----------------------------------------------------------------------------- autograd glue
@@ -723,6 +750,7 @@ class _UNetFn(torch.autograd.Function):
         from .parallel import make_sync
         with torch.no_grad():
             grads, dx = fctx.engine.backward(P, ctx, g0, g1, fctx.x_req, make_sync(fctx.module))
+            fctx.engine.fold_overflow(grads, g0.device)        # (GradSync.finish has waited for every bucket)
         fctx.ctx = None
         # parameters the graph never touches (the dead centre block, models.py:241) get None,
         # exactly as torch autograd leaves them in the reference

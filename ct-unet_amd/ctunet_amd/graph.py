@@ -64,13 +64,18 @@ class _Segmenter:
 
 
 class GraphedTrainStep:
-    """model: a ctunet_amd model on the GPU; optimizer: ctunet_amd.optim.Adam/AdamW (or torch.optim with capturable=True)."""
+    """model: a ctunet_amd model on the GPU; optimizer: ctunet_amd.optim.Adam/AdamW (or torch.optim with capturable=True).
+    Build it before any eager backward of the same model, or drop every reference to that iteration's autograd graph (its
+    loss tensors) first: a live graph keeps its AccumulateGrad nodes on the default stream, and autograd's stream hand-over
+    to them inside the capture ends the capture with a fault in the HIP runtime (measured, torch 2.10 / ROCm 7.2)."""
 
     def __init__(self, model: torch.nn.Module, optimizer: torch.optim.Optimizer, example_input: torch.Tensor,
                  example_targets: Sequence[torch.Tensor], ce_lambda: float, dice_lambda: float,
                  input_requires_grad: bool = True, warmup: int = 3, distributed: bool = False, process_group=None,
                  bucket_bytes: Optional[int] = None):
         self.model, self.opt = model, optimizer
+        if hasattr(optimizer, "guard"):
+            optimizer.guard(model)             # fp16: an overflowed step is skipped inside the replayed graph too
         self._params = [p for p in model.parameters()]
         self.distributed, self.group = distributed, process_group
         if distributed and model.__dict__.get("_grad_sync_cfg") is not None:
@@ -201,6 +206,7 @@ class GraphedTrainStep:
             grads, _ = eng.backward(P, ctx, gouts[0], gouts[1] if len(gouts) == 2 else None, self.x_req, seg)
             if not capture:
                 torch.cuda.current_stream().wait_stream(self.comm_stream)
+            eng.fold_overflow(grads, self.x.device)    # (capture: part of the last segment, replayed behind the last all-reduce)
             for name, p in model.named_parameters():
                 p.grad = grads.get(name)
             self.opt.step()

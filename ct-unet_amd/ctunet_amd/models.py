@@ -137,7 +137,21 @@ class _HipNet(nn.Module):
             raise ValueError(f"ctunet_amd: unsupported precision {dtype}")
         self.__dict__["_act_dtype"] = dt
         self.__dict__["_loss_scale"] = loss_scale
+        eng = self.__dict__.get("_eng")
+        if eng is not None and eng.dtype == dt:
+            eng.loss_scale = loss_scale            # (the engine is only rebuilt when the storage type changes)
         return self
+
+    def overflow_flag(self) -> torch.Tensor:
+        """float32[1] on the model's GPU: 1 after a float16 backward whose un-scaled parameter gradients contained inf / NaN
+        (the static loss scale overflowed the 16-bit activation gradients), 0 otherwise; cleared at the start of every float16
+        backward.  Hand it to the fused optimizer (``optim.Adam.guard(model)``): an overflowed step then changes nothing --
+        parameters, moments and step counter -- also inside a replayed HIP graph.  Call again after ``set_precision``."""
+        return self._engine().overflow_flag(next(self.parameters()).device)
+
+    def overflowed(self) -> bool:
+        """Did the last float16 backward overflow?  (Synchronises; a trainer lowers ``loss_scale`` when it says yes.)"""
+        return bool(self.overflow_flag().item() != 0)
 
     def _run(self, x):
         return run_network(self, self._engine(), x)

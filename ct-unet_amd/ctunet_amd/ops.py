@@ -342,8 +342,9 @@ def conv3d_fwd(x: CL, wp: torch.Tensor, bias: Optional[torch.Tensor], out: CL, k
         if t0 is not None:
             ci, co = algo_ch if algo_ch is not None else (x.cp, out.cp)
             vox = n * d * h * w
-            TIMER.end(f"lp_conv_fwd_kernel<{'bf16' if x.lp == 1 else 'f16'}, {k}>", 2.0 * ci * co * k ** 3 * vox,
-                      2.0 * vox * (ci + co), t0, (w, x.cp, out.cp))
+            dt = 'bf16' if x.lp == 1 else 'f16'
+            TIMER.end(f"lp_conv_fwd_pair_kernel<{dt}>" if layout == 1 else f"lp_conv_fwd_kernel<{dt}, {k}>",
+                      2.0 * ci * co * k ** 3 * vox, 2.0 * vox * (ci + co), t0, (w, x.cp, out.cp))
         return
     t0 = TIMER.begin() if TIMER is not None else None
     _lib.check(lib.ctu_conv3d_fwd(x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), wp.data_ptr(),
@@ -390,9 +391,11 @@ def conv3d_wgrad(x: CL, g: CL, co: int, ci: int, k: int, cinv: Optional[torch.Te
 
 
 def conv3d_wgrad_bn_supported(dims, k: int, cin_p: int, cout_p: int, dtype=torch.float32) -> bool:
-    """Can conv3d_wgrad_bn take this layer (fp32, k = 3, full boxes and channel tiles)?"""
+    """Can conv3d_wgrad_bn take this layer (k = 3, full boxes [and channel tiles for fp32])?"""
     n, d, h, w = dims
-    return dtype == torch.float32 and bool(_lib.load().ctu_conv3d_wgrad_bn_supported(n, d, h, w, k, cin_p, cout_p))
+    if lp(dtype):
+        return bool(_lib.load().ctu_lp_conv3d_wgrad_bn_supported(n, d, h, w, k, cin_p, cout_p))
+    return bool(_lib.load().ctu_conv3d_wgrad_bn_supported(n, d, h, w, k, cin_p, cout_p))
 
 
 def conv3d_wgrad_bn(x: CL, ga: CL, y: CL, vec: torch.Tensor, coef: torch.Tensor, gy: CL, co: int, ci: int, k: int,
@@ -402,8 +405,22 @@ def conv3d_wgrad_bn(x: CL, ga: CL, y: CL, vec: torch.Tensor, coef: torch.Tensor,
     and channel offset as ga) receives the raw-output gradient for the data-gradient kernel."""
     n, d, h, w = x.dims
     lib = _lib.load()
-    assert not x.lp and ga.dims == x.dims and y.dims == x.dims and gy.dims == x.dims
+    assert ga.dims == x.dims and y.dims == x.dims and gy.dims == x.dims and ga.dtype == x.dtype == y.dtype == gy.dtype
     assert y.cs == ga.cs == gy.cs and y.cp == ga.cp == gy.cp and gy.buf.data_ptr() != ga.buf.data_ptr()
+    if x.lp:
+        need = lib.ctu_lp_conv3d_wgrad_ws_floats(n, d, h, w, k, x.cp, ga.cp)
+        assert ws.numel() >= need, (ws.numel(), need)
+        dw = torch.empty((co, ci, k, k, k), dtype=torch.float32, device=x.buf.device)
+        t0 = TIMER.begin() if TIMER is not None else None
+        _lib.check(lib.ctu_lp_conv3d_wgrad_bn(x.lp, x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), ga.ptr, ga.cs,
+                                              ga.cp, y.ptr, vec[0].data_ptr(), vec[1].data_ptr(), coef.data_ptr(), gy.ptr,
+                                              dw.data_ptr(), co, ci, _ptr(cinv), ws.data_ptr(), n, d, h, w, k, _stream()),
+                   "lp_conv3d_wgrad_bn")
+        if t0 is not None:
+            vox = n * d * h * w
+            TIMER.end(f"lp_conv_wgrad_kernel<{'bf16' if x.lp == 1 else 'f16'}, {k}> (+slab reduce)",
+                      2.0 * ci * co * k ** 3 * vox, 2.0 * vox * (ci + co), t0, (w, x.cp, ga.cp))
+        return dw
     need = lib.ctu_conv3d_wgrad_ws_floats(n, d, h, w, k, x.cp, ga.cp)
     assert ws.numel() >= need, (ws.numel(), need)
     dw = torch.empty((co, ci, k, k, k), dtype=torch.float32, device=x.buf.device)
@@ -974,8 +991,14 @@ def lp_upconv_fused_fwd(x: CL, wp16: torch.Tensor, beff: torch.Tensor, out: CL, 
                   2.0 * vox * (x.cp + 8 * out.cp), t0, (w, x.cp, out.cp))
 
 
-def lp_upconv_fused_wgrad(x: CL, g: CL, c: int, co: int, bt: torch.Tensor, pack_ws: torch.Tensor, imap):
-    """(dWT, dbT, dW3) as upconv_fused_wgrad, from 16-bit tensors: x = COARSE input, g = fine-grid raw-output gradient."""
+def lp_upconv_fused_wgrad_bn_supported(dims, cin_p: int) -> bool:
+    n, d, h, w = dims
+    return bool(_lib.load().ctu_lp_upconv_fused_wgrad_bn_supported(n, d, h, w, cin_p))
+
+
+def lp_upconv_fused_wgrad(x: CL, g: CL, c: int, co: int, bt: torch.Tensor, pack_ws: torch.Tensor, imap, lazy=None):
+    """(dWT, dbT, dW3) as upconv_fused_wgrad, from 16-bit tensors: x = COARSE input, g = fine-grid raw-output gradient.
+    lazy = (y, vec, coef, gy) as in upconv_fused_wgrad."""
     n, d, h, w = x.dims
     assert g.dims == (n, 2 * d, 2 * h, 2 * w) and x.lp and g.dtype == x.dtype and g.cp == 8 and g.cs == 8
     lib = _lib.load()
@@ -983,8 +1006,16 @@ def lp_upconv_fused_wgrad(x: CL, g: CL, c: int, co: int, bt: torch.Tensor, pack_
     dweff = torch.empty((8, 8, x.cp, 8), dtype=torch.float32, device=dev)
     ws = torch.empty(lib.ctu_lp_upconv_fused_wgrad_ws_floats(n, d, h, w, x.cp), dtype=torch.float32, device=dev)
     t0 = TIMER.begin() if TIMER is not None else None
-    _lib.check(lib.ctu_lp_upconv_fused_wgrad(x.lp, x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), g.ptr, g.cs,
-                                             dweff.data_ptr(), ws.data_ptr(), n, d, h, w, _stream()), "lp_upconv_fused_wgrad")
+    if lazy is not None:
+        y, vec, coef, gy = lazy
+        assert y.dims == g.dims and gy.dims == g.dims and y.cs == g.cs == gy.cs and gy.buf.data_ptr() != g.buf.data_ptr()
+        _lib.check(lib.ctu_lp_upconv_fused_wgrad_bn(x.lp, x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), g.ptr, g.cs,
+                                                    y.ptr, vec[0].data_ptr(), vec[1].data_ptr(), coef.data_ptr(), gy.ptr,
+                                                    dweff.data_ptr(), ws.data_ptr(), n, d, h, w, _stream()), "lp_upconv_fused_wgrad_bn")
+        g = gy
+    else:
+        _lib.check(lib.ctu_lp_upconv_fused_wgrad(x.lp, x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), g.ptr, g.cs,
+                                                 dweff.data_ptr(), ws.data_ptr(), n, d, h, w, _stream()), "lp_upconv_fused_wgrad")
     if t0 is not None:
         vox = n * d * h * w
         TIMER.end(f"lp_upconv_wgrad_kernel<{'bf16' if x.lp == 1 else 'f16'}> (+slab reduce)", vox * (16.0 * c * c + 8 * 54.0 * c * co),
@@ -1124,8 +1155,9 @@ def stitch_patches(patches: torch.Tensor, coords: torch.Tensor, shape: Tuple[int
     return out
 
 
-def scale_tensors(tensors, s: float) -> None:
-    """Every float32 CUDA tensor of the list scaled in place by s, one launch (un-scaling of loss-scaled gradients)."""
+def scale_tensors(tensors, s: float, nonfinite: Optional[torch.Tensor] = None) -> None:
+    """Every float32 CUDA tensor of the list scaled in place by s, one launch (un-scaling of loss-scaled gradients).
+    nonfinite: float32[1] device flag set to 1 when any scaled value is inf / NaN (fp16 overflow detection)."""
     import ctypes as C
     ts = [t for t in tensors if t is not None]
     if not ts:
@@ -1135,4 +1167,5 @@ def scale_tensors(tensors, s: float) -> None:
         assert t.is_contiguous() and t.dtype == torch.float32
     pa = (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
     sa = (C.c_int64 * len(ts))(*[t.numel() for t in ts])
-    _lib.check(_lib.load().ctu_scale_tensors(pa, sa, len(ts), float(s), _stream()), "scale_tensors")
+    assert nonfinite is None or (nonfinite.is_cuda and nonfinite.dtype == torch.float32 and nonfinite.numel() == 1)
+    _lib.check(_lib.load().ctu_scale_tensors(pa, sa, len(ts), float(s), _ptr(nonfinite), _stream()), "scale_tensors")

@@ -30,6 +30,16 @@ class Adam(torch.optim.Optimizer):
             raise ValueError("invalid Adam hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=True,
                                       decoupled_weight_decay=decoupled_weight_decay))
+        # fp16 training: a float32[1] device flag (model.overflow_flag()) that the backward sets when a loss-scaled gradient
+        # overflowed; a step that sees it set changes nothing (torch.amp.GradScaler.step's found_inf), also inside a replayed
+        # HIP graph.  None: every step is applied.
+        self.skip_flag = None
+
+    def guard(self, model) -> "Adam":
+        """Skip every step whose float16 backward overflowed (``model.overflow_flag()``); no-op for fp32 / bf16 models."""
+        fp16 = model.__dict__.get("_act_dtype", torch.float32) == torch.float16
+        self.skip_flag = model.overflow_flag() if fp16 and hasattr(model, "overflow_flag") else None
+        return self
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -69,6 +79,7 @@ class Adam(torch.optim.Optimizer):
             _lib.check(lib.ctu_adam_amsgrad(pa, sa, n, group["step_t"].data_ptr(), float(group["lr"]), float(b1),
                                             float(b2), float(group["eps"]), float(group["weight_decay"]),
                                             int(bool(group["decoupled_weight_decay"])),
+                                            None if self.skip_flag is None else self.skip_flag.data_ptr(),
                                             torch.cuda.current_stream().cuda_stream), "adam_amsgrad")
             # the kernel wrote the parameters through raw pointers: tell autograd / every (version-keyed) cache of
             # derived data -- the engine's MFMA-ordered weight copies -- that they changed

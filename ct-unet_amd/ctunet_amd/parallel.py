@@ -33,29 +33,17 @@ class Communicator:
     this process's current GPU, ``ncclAllReduce(avg)`` on a caller-chosen stream.  ``torch.distributed`` is only the side
     channel that hands rank 0's unique id to the other ranks."""
 
-    def __init__(self, process_group=None):
+    def __init__(self, process_group, ident: bytes):
+        """ident: rank 0's 128-byte RCCL unique id, already agreed on and broadcast by get_communicator (no collective of
+        torch.distributed happens here: the only rendezvous is ncclCommInitRank's own)."""
         import ctypes as C
         from . import _lib
         self._lib = _lib
         lib = _lib.load()
-        avail = bool(lib.ctu_comm_available())
         self.world = dist.get_world_size(process_group)
         self.rank = dist.get_rank(process_group)
-        buf = (C.c_char * 128)()
-        # rank 0's outcome travels with the id, so that a failure there is seen by every rank BEFORE anyone enters
-        # ncclCommInitRank's rendezvous (the broadcast itself always happens)
-        ok = avail and (self.rank != 0 or lib.ctu_comm_unique_id(buf) == 0)
-        box = [bytes(buf) if ok else None]
-        dist.broadcast_object_list(box, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0,
-                                   group=process_group)
-        if not avail:
-            raise RuntimeError("ctunet_amd.parallel: librccl could not be bound (ctu_comm_available() == 0)")
-        if box[0] is None:
-            raise RuntimeError("ctunet_amd.parallel: rank 0 could not create an RCCL unique id: " +
-                               (lib.ctu_last_error() or b"").decode())
-        ident = (C.c_char * 128).from_buffer_copy(box[0])
         handle = C.c_void_p()
-        _lib.check(lib.ctu_comm_init(C.byref(handle), self.world, self.rank, ident), "comm_init")
+        _lib.check(lib.ctu_comm_init(C.byref(handle), self.world, self.rank, (C.c_char * 128).from_buffer_copy(ident)), "comm_init")
         self._handle = handle
 
     def allreduce_(self, t: torch.Tensor, average: bool = True, stream=None) -> None:
@@ -99,25 +87,42 @@ _COMMS: Dict[object, object] = {}
 
 def get_communicator(process_group=None):
     """The (cached) RCCL communicator of this rank for ``process_group``; collective on first use.  The C ABI's communicator
-    (``ctu_comm_*``) by default; if it cannot be initialised on EVERY rank (agreed by an all-reduce of the outcome, so no rank
-    is left waiting in ncclCommInitRank's rendezvous alone), all ranks take torch.distributed's RCCL group instead and say so."""
+    (``ctu_comm_*``) by default.  Availability is AGREED ON before anyone enters a rendezvous: every rank reports whether the
+    library loaded and librccl could be bound (rank 0 also whether it could create the unique id) through one MIN all-reduce;
+    only if all say yes is the id broadcast and ``ncclCommInitRank`` entered -- by every rank.  Otherwise all ranks take
+    torch.distributed's RCCL group instead and say so (``bench.py --gpus N`` treats that as an error unless told otherwise)."""
     c = _COMMS.get(process_group)
     if c is None:
-        err = None
+        import ctypes as C
+        rank = dist.get_rank(process_group)
+        ok, err, ident = 1, None, None
         try:
-            c = Communicator(process_group)
+            from . import _lib
+            lib = _lib.load()
+            if not lib.ctu_comm_available():
+                raise RuntimeError("librccl could not be bound (ctu_comm_available() == 0)")
+            if rank == 0:
+                buf = (C.c_char * 128)()
+                if lib.ctu_comm_unique_id(buf) != 0:
+                    raise RuntimeError("rank 0 could not create an RCCL unique id: " + (lib.ctu_last_error() or b"").decode())
+                ident = bytes(buf)
         except Exception as e:                                  # noqa: BLE001 -- reported below, on every rank
-            c, err = None, e
-        ok = torch.tensor([0 if c is None else 1], dtype=torch.int32,
-                          device="cuda" if dist.get_backend(process_group) == "nccl" else "cpu")
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=process_group)
-        if int(ok.item()) == 0:
+            ok, err = 0, e
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda" if dist.get_backend(process_group) == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=process_group)
+        if int(flag.item()) == 0:
             import warnings
             warnings.warn(f"ctunet_amd.parallel: ctu_comm_* communicator unavailable on some rank ({err!r}); "
                           "gradient all-reduces go through torch.distributed's RCCL process group")
-            if c is not None:
-                c.close()
             c = TorchCommunicator(process_group)
+        else:
+            box = [ident]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0,
+                                       group=process_group)
+            c = Communicator(process_group, box[0])
+        if not _COMMS:
+            import atexit
+            atexit.register(close_communicators)               # (a caller that forgets close_communicators() still frees them)
         _COMMS[process_group] = c
     return c
 
@@ -235,7 +240,9 @@ def make_sync(module) -> Optional[GradSync]:
     cfg = module.__dict__.get("_grad_sync_cfg")
     if cfg is None:
         return None
-    return GradSync(cfg[0], cfg[1])
+    sync = GradSync(cfg[0], cfg[1])
+    module.__dict__["_last_grad_sync"] = sync        # tests / bench read its launched_before_finish (overlap evidence)
+    return sync
 
 
 def allreduce_mean_(tensors: Sequence[Optional[torch.Tensor]], process_group=None,

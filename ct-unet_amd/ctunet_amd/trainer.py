@@ -65,6 +65,8 @@ class StepRunner:
             p["optimizer"] = torch.optim.SGD(net.parameters(), lr=lr, momentum=p.get("momentum", 0) or 0, weight_decay=wd)
         elif not isinstance(name, torch.optim.Optimizer):
             raise ValueError(f"ctunet_amd: unknown optimizer '{name}'")
+        if hasattr(p["optimizer"], "guard"):
+            p["optimizer"].guard(net)          # float16 activations: steps whose backward overflowed are skipped
         if "scheduler" in p:      # built whenever the key exists, whatever its value (Model.py:544-546)
             p["scheduler"] = torch.optim.lr_scheduler.ReduceLROnPlateau(p["optimizer"])
 

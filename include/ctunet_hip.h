@@ -458,6 +458,14 @@ size_t ctu_lp_conv3d_wgrad_ws_floats(int N, int D, int H, int W, int k, int cin_
 int ctu_lp_conv3d_wgrad(int dtype, const void* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
                         int in_relu, const void* gout, int g_cs, int cout_p, float* dw, int Co, int Ci,
                         const int32_t* cinv, float* ws, int N, int D, int H, int W, int k, void* stream);
+/* ctu_conv3d_wgrad_bn for 16-bit tensors (BatchNorm + ReLU backward folded into the weight-gradient kernel's staging; the
+ * raw-output gradient is rounded once to the storage type and written to gy_out): k = 3, volumes at least 16 wide that are
+ * multiples of the 4 x 4*(32/bw) x bw box (ctu_lp_conv3d_wgrad_bn_supported). */
+int ctu_lp_conv3d_wgrad_bn_supported(int N, int D, int H, int W, int k, int cin_p, int cout_p);
+int ctu_lp_conv3d_wgrad_bn(int dtype, const void* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
+                           int in_relu, const void* ga, int g_cs, int cout_p, const void* y, const float* bn_scale,
+                           const float* bn_shift, const float* coef, void* gy_out, float* dw, int Co, int Ci,
+                           const int32_t* cinv, float* ws, int N, int D, int H, int W, int k, void* stream);
 
 /* first encoder convolution (C_in <= 2): the input x and dx stay fp32 NCDHW, the 8-channel side tensor is 16-bit */
 int ctu_lp_conv3d_first_fwd(int dtype, const float* x, int cin, const float* w, const float* bias, int nbias, void* out,
@@ -501,6 +509,13 @@ size_t ctu_lp_upconv_fused_wgrad_ws_floats(int N, int D, int H, int W, int cin_p
 int ctu_lp_upconv_fused_wgrad(int dtype, const void* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
                               int in_relu, const void* gout, int g_cs, float* dweff, float* ws, int N, int D, int H,
                               int W, void* stream);
+/* ... with the BatchNorm + ReLU backward of the fused op's output folded in (as ctu_lp_conv3d_wgrad_bn): gy_out feeds
+ * ctu_lp_upconv_fused_project and ctu_lp_upconv_fused_bwd_data */
+int ctu_lp_upconv_fused_wgrad_bn_supported(int N, int D, int H, int W, int cin_p);
+int ctu_lp_upconv_fused_wgrad_bn(int dtype, const void* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
+                                 int in_relu, const void* ga, int g_cs, const void* y, const float* bn_scale,
+                                 const float* bn_shift, const float* coef, void* gy_out, float* dweff, float* ws,
+                                 int N, int D, int H, int W, void* stream);
 int ctu_lp_upconv_fused_project(int dtype, const float* dweff, const void* gout, int g_cs, int nout_p, int N, int D, int H,
                                 int W, const float* bt, const float* pack_ws, const int32_t* imap, int C, int Co, int cin_p,
                                 float* dwt, float* dbt, float* dw3, float* ws, void* stream);
@@ -539,8 +554,10 @@ int ctu_lp_head_bwd_bn(int dtype, const void* in, int in_cs, int cin_p, const fl
                        float* db, float* ws, int N, int64_t nvox_per_item, const float* bn_mean,
                        const float* bn_invstd, int bn_cp, float* bn_partials, const ctu_bn_bwd_tail* tail, void* stream);
 /* Every tensor of a list scaled in place by s (one launch): un-scaling of loss-scaled fp16 gradients.
- * ptrs: HOST array of n DEVICE float pointers, sizes: HOST int64[n]. */
-int ctu_scale_tensors(void* const* ptrs, const int64_t* sizes, int n, float s, void* stream);
+ * ptrs: HOST array of n DEVICE float pointers, sizes: HOST int64[n].  nonfinite_flag: NULL or a DEVICE float[1] that is set
+ * to 1 when any scaled value is inf / NaN (the fp16 backward overflowed; the caller zeroes it per step and hands it to
+ * ctu_adam_amsgrad as skip_flag, what torch.amp.GradScaler does with found_inf). */
+int ctu_scale_tensors(void* const* ptrs, const int64_t* sizes, int n, float s, float* nonfinite_flag, void* stream);
 
 /* --------------------------------------------------------------- gradient exchange (RCCL over xGMI) ---- */
 /* One process per GPU; the only cross-GPU step of the path is the mean of the parameter gradients before the optimizer
@@ -567,10 +584,11 @@ int ctu_channel_sum(const float* x, int cs, int cp, int64_t nvox, float* partial
  * Model.py:514-527).  ptrs: HOST array of 5*n DEVICE pointers {param, grad, exp_avg, exp_avg_sq,
  * max_exp_avg_sq} (copied into the kernel arguments, 64 tensors per launch); sizes: HOST int64[n].
  * step: DEVICE float[1] step counter, incremented by this call before it is used (so a captured graph
- * keeps advancing the bias corrections).  decoupled != 0: AdamW weight decay. */
+ * keeps advancing the bias corrections).  decoupled != 0: AdamW weight decay.  skip_flag: NULL or a DEVICE float[1];
+ * non-zero = skip this update entirely (parameters, moments and the step counter untouched): an overflowed fp16 step. */
 int ctu_adam_amsgrad(void* const* ptrs, const int64_t* sizes, int n, float* step,
                      double lr, double beta1, double beta2, double eps, double weight_decay,
-                     int decoupled, void* stream);
+                     int decoupled, const float* skip_flag, void* stream);
 
 #ifdef __cplusplus
 }

@@ -26,15 +26,29 @@ def per_kernel(d, counter):
     return {k: v[0] / v[1] for k, v in agg.items()}, {k: v[1] for k, v in agg.items()}
 
 
-fetch, n = per_kernel(sys.argv[1], "FETCH_SIZE")
-write, _ = per_kernel(sys.argv[2], "WRITE_SIZE")
-out = {}
-for k in sorted(fetch):
-    rd = fetch[k] * 1024 * 2            # KiB -> B, gfx950 x2 correction
-    wr = write.get(k, 0.0) * 1024
-    out[k] = {"launches": n[k], "read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr}
-json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on `python bench.py --eager`; "
-                   "FETCH_SIZE x2 (gfx950), KiB -> bytes; average per launch over all launches of the symbol",
-           "kernels": out}, open(sys.argv[3], "w"), indent=1)
-for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:12]:
-    print(f"{k:50s} n={v['launches']:5d} rd={v['read_bytes_per_launch']/1e6:9.2f} MB wr={v['write_bytes_per_launch']/1e6:9.2f} MB")
+def section(fetch_dir, write_dir):
+    fetch, n = per_kernel(fetch_dir, "FETCH_SIZE")
+    write, _ = per_kernel(write_dir, "WRITE_SIZE")
+    out = {}
+    for k in sorted(fetch):
+        rd = fetch[k] * 1024 * 2            # KiB -> B, gfx950 x2 correction
+        wr = write.get(k, 0.0) * 1024
+        out[k] = {"launches": n[k], "read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr}
+    return out
+
+
+# old form: fetch_dir write_dir out.json; new form: out.json label=fetch_dir,write_dir ... (label "f32" -> "kernels",
+# any other label L -> "kernels_L": the 16-bit legs run different symbols, some of which rocprofv3 leaves mangled)
+if "=" in "".join(sys.argv[2:]):
+    dst, pairs = sys.argv[1], [a.split("=", 1) for a in sys.argv[2:]]
+else:
+    dst, pairs = sys.argv[3], [("f32", sys.argv[1] + "," + sys.argv[2])]
+doc = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on `python bench.py --eager [--dtype L]`; "
+               "FETCH_SIZE x2 (gfx950), KiB -> bytes; average per launch over all launches of the symbol"}
+for label, dirs in pairs:
+    out = section(*dirs.split(","))
+    doc["kernels" if label == "f32" else "kernels_" + label] = out
+    print(label)
+    for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:12]:
+        print(f"{k[:60]:60s} n={v['launches']:5d} rd={v['read_bytes_per_launch']/1e6:9.2f} MB wr={v['write_bytes_per_launch']/1e6:9.2f} MB")
+json.dump(doc, open(dst, "w"), indent=1)

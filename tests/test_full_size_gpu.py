@@ -83,11 +83,18 @@ def _gate(res, lowp):
     assert res["grad_cos_global"] > g["cos_global"] and res["grad_cos_min"][0] > g["cos"] and res["dice"] >= g["dice"], res
 
 
-@pytest.mark.parametrize("name", ["UNetSP", "recAE_v2_fixed", "UNet4_2IC"])
-def test_cfg4_192_train_step_fp32_then_bf16(name):
-    _gate(oracle_train_check(name, 192, want_fp64=FP64, lowp="bf16"), "bf16")
+# Suite budget (<= 480 s on the GPU box; the ATen-CPU oracle's fwd+bwd is what costs: 60 s at 192^3, 110-140 s
+# at 256^3 per class): by default ONE class per kernel family runs at the configuration's full size -- UNetSP (k = 3, both sizes)
+# and recAE_v2_fixed (k = 5, 192^3) -- and the family's second class (same kernels, different widths) at 128^3;
+# CTUNET_FULLSIZE_ALL=1 runs every class at the full size (run once per round, recorded in profiles/README.md).
+ALL = os.environ.get("CTUNET_FULLSIZE_ALL", "0") == "1"
 
 
-@pytest.mark.parametrize("name", ["UNetSP", "UNetSPSmall"])
-def test_cfg5_256_train_step_fp32_then_fp16(name):
-    _gate(oracle_train_check(name, 256, want_fp64=FP64, lowp="fp16"), "fp16")
+@pytest.mark.parametrize("name,size", [("UNetSP", 192), ("recAE_v2_fixed", 192), ("UNet4_2IC", 192 if ALL else 128)])
+def test_cfg4_192_train_step_fp32_then_bf16(name, size):
+    _gate(oracle_train_check(name, size, want_fp64=FP64, lowp="bf16"), "bf16")
+
+
+@pytest.mark.parametrize("name,size", [("UNetSP", 256), ("UNetSPSmall", 256 if ALL else 128)])
+def test_cfg5_256_train_step_fp32_then_fp16(name, size):
+    _gate(oracle_train_check(name, size, want_fp64=FP64, lowp="fp16"), "fp16")

@@ -55,6 +55,8 @@ CONV_CASES = [  # (k, ci, co, shape NDHW, transform)
     (3, 8, 8, (1, 4, 8, 40), False), (5, 8, 8, (1, 5, 6, 18), False), (3, 16, 8, (1, 8, 8, 16), True),
     # 8 -> 8 at >= 32-wide volumes: the pair-layout kernel (lp_conv_fwd_pair_kernel), interior + border + ragged boxes
     (3, 8, 8, (2, 5, 9, 70), True), (3, 8, 8, (1, 12, 24, 96), True), (3, 7, 8, (1, 4, 8, 32), True),
+    # ... whose weight gradient, on volumes that are multiples of the 4 x 8 x 32 box, is lp_wgrad8_kernel (the two above; batch 2)
+    (3, 8, 5, (2, 8, 16, 64), False),
 ]
 
 
@@ -472,3 +474,103 @@ def test_lp_fused_upconv_forward_backward(name, c, co, dims, segs):
     for nm, gt, want in (("dWT", dwt, wt64.grad), ("dbT", dbt, bt64.grad), ("dW3", dw3, w364.grad)):
         err = (gt.cpu().double() - want).abs().max().item()
         assert err <= 2e-3 * want.abs().max().item(), (nm, err, want.abs().max().item())
+
+
+@pytest.mark.parametrize("name", ["bf16", "fp16"])
+@pytest.mark.parametrize("ci,co,dims,cs,c0", [
+    (8, 8, (1, 8, 8, 32), 8, 0),            # (shift, channel) tiles on both sides, 32-wide boxes: lp_wgrad8_kernel<.., LZ>
+    (6, 8, (1, 12, 24, 96), 8, 0),          # ... with interior and border boxes
+    (8, 7, (2, 4, 16, 64), 16, 8),          # ... second half of a concat-level buffer, batch 2
+    (8, 8, (2, 4, 8, 16), 16, 8),           # 16-wide boxes, second half of a concat-level buffer
+    (16, 8, (1, 4, 8, 16), 8, 0),
+    (8, 16, (1, 8, 4, 32), 16, 0),
+    (32, 16, (1, 4, 8, 16), 16, 0),         # two input-channel tiles share a gradient tile
+])
+def test_lp_wgrad_with_lazy_batchnorm_backward(name, ci, co, dims, cs, c0):
+    """ops.conv3d_wgrad_bn on 16-bit tensors (BatchNorm + ReLU backward in the weight-gradient kernel's staging, the raw-output
+    gradient rounded once and written out) against the three-pass 16-bit path it replaces."""
+    ops = _ops()
+    dt = DT[name]
+    n, d, h, w = dims
+    cip, cop = ops.pad8(ci), ops.pad8(co)
+    assert ops.conv3d_wgrad_bn_supported(dims, 3, cip, cop, dt)
+    g = gen(hash((ci, co, dims)) % 1000)
+    x = rnd(torch.randn(n, ci, d, h, w, generator=g), dt)
+    y = rnd(torch.randn(n, co, d, h, w, generator=g) * 1.3 + 0.3, dt)
+    ga = rnd(torch.randn(n, co, d, h, w, generator=g), dt)
+    gamma = torch.rand(co, generator=g) * 1.5 - 0.25
+    beta = torch.randn(co, generator=g) * 0.2
+    mean = y.double().mean((0, 2, 3, 4)); var = y.double().var((0, 2, 3, 4), unbiased=False)
+    invstd = (1.0 / torch.sqrt(var + 1e-5)).float()
+    vec = torch.zeros(4, cop)
+    vec[0, :co] = gamma * invstd; vec[1, :co] = beta - mean.float() * gamma * invstd; vec[2, :co] = mean.float(); vec[3, :co] = invstd
+    vec = vec.cuda()
+    sc = torch.rand(cip, generator=g) + 0.5; sh = torch.randn(cip, generator=g) * 0.3
+    sc[ci:] = 0; sh[ci:] = 0
+    xcl = to_cl(x, cip, dt).with_xf(sc.cuda(), sh.cuda(), True)
+    ycl, gcl = to_cl(y, cop, dt, cs, c0), to_cl(ga, cop, dt, cs, c0)
+    part = torch.empty(ops.bn_bwd_partials_floats(n * d * h * w, cop), device="cuda")
+    ws = torch.empty(ops.conv3d_wgrad_ws(dims, 3, cip, cop, dt), dtype=torch.float32).cuda()
+    _, _, coef = ops.bn_relu_bwd(ycl, gcl, vec, gamma.cuda(), co, part, lazy=True)
+    gy = ops.CL(torch.full_like(gcl.buf, 9.0), c0, cop)
+    before = gcl.buf.clone()
+    dw1 = ops.conv3d_wgrad_bn(xcl, gcl, ycl, vec, coef, gy, co, ci, 3, None, ws)
+    torch.cuda.synchronize()
+    assert torch.equal(gcl.buf, before)
+    gcl2 = to_cl(ga, cop, dt, cs, c0)
+    ops.bn_relu_bwd(ycl, gcl2, vec, gamma.cuda(), co, part)
+    dw2, _ = ops.conv3d_wgrad(xcl, gcl2, co, ci, 3, None, ws, False)
+    torch.cuda.synchronize()
+    a, b = from_cl(gy, co), from_cl(gcl2, co)
+    assert (a - b).abs().max().item() <= 2 * ULP[name] * b.abs().max().item()
+    if cs > cop:                                            # the slice's neighbours are untouched
+        other = torch.ones(cs, dtype=torch.bool); other[c0:c0 + cop] = False
+        assert torch.all(gy.buf[..., other.cuda()].float() == 9.0)
+    assert rel_err(dw1, dw2) < 4 * ULP[name]
+
+
+def test_fp16_overflow_is_detected_and_the_step_skipped():
+    """A static loss scale can overflow the 16-bit activation gradients.  The un-scaling launches flag inf / NaN
+    (model.overflow_flag()), and the fused optimizer -- eagerly and inside a replayed HIP graph -- then skips the whole step:
+    parameters, moments and the step counter stay finite and unchanged.  A sane scale leaves the flag clear and trains."""
+    import ctunet_amd
+    from ctunet_amd import losses as L, optim
+    from ctunet_amd.graph import GraphedTrainStep
+    torch.manual_seed(0)
+    net = ctunet_amd.UNet(n_blocks=2, use_checkpoint=False).cuda().train()
+    x = torch.randn(1, 1, 32, 32, 32, generator=gen(2)).cuda()
+    t = onehot_target((1, 2, 32, 32, 32), 3, 0.3).cuda()
+    net.set_precision(torch.float16, loss_scale=2.0 ** 30)            # absurd: every activation gradient overflows
+    opt = optim.Adam(net.parameters(), lr=1e-3, amsgrad=True).guard(net)
+    before = [p.detach().clone() for p in net.parameters()]
+    ce, dc = L.fused_ce_dice(net(x), t, 1.0, 1.0, False)
+    (ce + dc).backward()
+    assert net.overflowed()
+    assert any(not torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None)
+    opt.step()
+    torch.cuda.synchronize()
+    for p, b in zip(net.parameters(), before):
+        assert torch.equal(p.detach(), b)                             # nothing moved
+    for st in opt.state.values():
+        assert float(st["step"]) == 0.0 and torch.isfinite(st["max_exp_avg_sq"]).all() and float(st["exp_avg"].abs().max()) == 0.0
+    # the same inside a captured graph, replayed twice (the eager loss tensors go first: an autograd graph of an earlier
+    # iteration that is still alive pins its AccumulateGrad nodes to the default stream, which breaks the capture)
+    del ce, dc
+    for p in net.parameters():
+        p.grad = None
+    gstep = GraphedTrainStep(net, opt, x, [t], 1.0, 1.0, input_requires_grad=True)
+    gstep(x, [t]); gstep(x, [t])
+    torch.cuda.synchronize()
+    assert net.overflowed()
+    for p, b in zip(net.parameters(), before):
+        assert torch.equal(p.detach(), b) and torch.isfinite(p).all()
+    # a sane scale: flag clear, weights move and stay finite
+    net.set_precision(torch.float16, loss_scale=None)
+    opt2 = optim.Adam(net.parameters(), lr=1e-3, amsgrad=True).guard(net)
+    ce, dc = L.fused_ce_dice(net(x), t, 1.0, 1.0, False)
+    (ce + dc).backward()
+    assert not net.overflowed()
+    opt2.step()
+    torch.cuda.synchronize()
+    moved = sum(float((p.detach() - b).abs().max()) > 0 for p, b in zip(net.parameters(), before) if p.grad is not None)
+    assert moved > 0 and all(torch.isfinite(p).all() for p in net.parameters())

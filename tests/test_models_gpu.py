@@ -142,7 +142,8 @@ def test_whole_net_gradients_tight_on_mask_stable_fixtures(name):
         err = (p.grad.cpu() - gt).abs().max().item()
         # (conv biases in front of a BatchNorm have an exactly-zero true gradient: rounding noise on both sides)
         assert err <= 1e-4 * scale + 1e-7, (n_, err, scale)
-        worst = max(worst, err / max(scale, 1e-30))
+        if scale > 1e-5:
+            worst = max(worst, err / scale)
     print(f"{name}: worst gradient error {worst:.2e} of the tensor's largest entry")
     for n_, b in net.named_buffers():
         assert np.allclose(b.cpu().numpy(), rec["post." + n_], rtol=1e-4, atol=1e-5), n_
@@ -222,7 +223,7 @@ def test_shipped_classes_vs_reference_checksums_and_oracle(name):
             assert float(b) == e, n_
 
 
-def oracle_train_check(name, size, batch=1, seed=1234, want_fp64=True, lowp=None):
+def oracle_train_check(name, size, batch=1, seed=1234, want_fp64=True, lowp=None, report=None):
     """One train-mode step of class `name` on a size^3 patch through the HIP path AND through the oracle on the same seeded
     weights / input / targets: outputs <= 1e-4 (north star: 1e-3), loss <= 1e-5, hard-segmentation Dice >= 0.999, and every
     parameter gradient + dx
@@ -330,6 +331,10 @@ def oracle_train_check(name, size, batch=1, seed=1234, want_fp64=True, lowp=None
         misses = []
         for n_, got, c32, r64 in checks:
             scale = r64.abs().max().item()
+            if report is not None:       # tests/arbitrate_fullsize.py: (tensor, scale, HIP vs fp64, ATen-CPU fp32 vs fp64, cosines)
+                cs = lambda u: float(torch.dot(u.detach().cpu().double().flatten(), r64.flatten())
+                                     / (u.detach().cpu().double().norm() * r64.norm() + 1e-300))
+                report.append((n_, scale, err(got, r64), err(c32, r64), cs(got), cs(c32)))
             if err(got, r64) > max(5 * err(c32, r64), floor * scale) + 1e-7:
                 misses.append((n_, err(got, r64), err(c32, r64), scale))
             a, b = got.detach().cpu().double().flatten(), r64.flatten()

@@ -63,6 +63,32 @@ def _worker(rank, world, port, tmp):
         parallel.allreduce_mean_(ts)
         assert torch.allclose(ts[0], torch.full((5,), (1 + world) / 2.0))
         assert ts[1] is None and torch.allclose(ts[2], torch.full((2, 3), 10 * (1 + world) / 2.0))
+        # 4. graph._Segmenter (the sync object of the segmented graph step) under two ranks, in the engine's backward order
+        # (head, decoder top -> bottom, encoder bottom -> top): with bucket_bytes = 1 EVERY push closes a bucket, with the
+        # default size only finish() does; the boundary callback is the all-reduce.  Bucket order, layout and means must be
+        # the same on every rank.
+        from ctunet_amd.graph import _Segmenter
+        order = ["last_conv"] + [f"u_blocks.{j}." for j in (1, 0)] + [f"d_blocks.{i}." for i in (1, 0)]
+        for bucket_bytes, nb_expected in ((1, len(order)), (parallel.DEFAULT_BUCKET_BYTES, 1)):
+            fired = []
+
+            def boundary(k, flat):
+                fired.append(k)
+                dist.all_reduce(flat)
+                flat /= world
+            seg = _Segmenter(bucket_bytes, boundary)
+            for pre in order:
+                seg.push([(n, grads[n].clone()) for n in names if n.startswith(pre)])
+            out = seg.finish()
+            assert fired == list(range(nb_expected)) and len(seg.flats) == nb_expected, (fired, len(seg.flats))
+            lay = [[(n, tuple(sh), off) for n, sh, off in bucket] for bucket in seg.layout]
+            every = [None] * world
+            dist.all_gather_object(every, lay)
+            assert all(e == every[0] for e in every)                   # same buckets, same order, same offsets on every rank
+            assert [n for bucket in lay for n, _, _ in bucket] == [n for pre in order for n in names if n.startswith(pre)]
+            assert set(out) == {n for n, _ in live}
+            for n, t in live:
+                assert torch.allclose(out[n], red[n], atol=1e-6), n    # the same means GradSync produced
         open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")
     finally:
         dist.destroy_process_group()

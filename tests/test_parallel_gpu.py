@@ -78,6 +78,8 @@ def _worker(rank, world, port, tmp):
         x, t = _rank_inputs(rank)
         ce, dc = L.fused_ce_dice(net(x.cuda()), t.cuda(), 1.0, 1.0, False)
         (ce + dc).backward()
+        # most bucket collectives were issued from push(), i.e. while the backward kernels were still being launched
+        assert net.__dict__["_last_grad_sync"].launched_before_finish >= 2
         for n, p in net.named_parameters():
             if g[0][n] is None:
                 assert p.grad is None, n
