@@ -1004,7 +1004,9 @@ constexpr int LPP_TH = 8, LPP_BW = 32, LPP_HH = LPP_TH + 2, LPP_HW = LPP_BW + 2,
 constexpr int LPP_NI = (LPP_HV + 255) / 256;
 constexpr size_t LPP_LDS = 256 + (size_t)LPP_HV * 16 + 9 * 1024;
 
-template <class T>
+// OUT32 (the first layer's data gradient, ctu_lp_conv3d_first_bwd_data_pair): the first p.nbias (<= 4) output channels are
+// written as float32 PLANES (the network input's NCDHW layout) instead of the 16-bit channels-last tensor; no statistics.
+template <class T, bool OUT32 = false>
 __global__ __launch_bounds__(256, 3) void lp_conv_fwd_pair_kernel(LpConvP p, int ntiles, int tiles_per_block) {
     typedef typename Vec<T>::v8 v8;
     constexpr int TH = LPP_TH, BW = LPP_BW, HH = LPP_HH, HW = LPP_HW, HV = LPP_HV, NI = LPP_NI;
@@ -1112,6 +1114,20 @@ __global__ __launch_bounds__(256, 3) void lp_conv_fwd_pair_kernel(LpConvP p, int
         box_of(tile, n, d0, h0, w0);
         const int gd = d0 + wave, gw = w0 + 2 * m + (kg >> 1);
         const bool full = d0 + 4 <= p.D && h0 + TH <= p.H && w0 + BW <= p.W;          // uniform
+        if constexpr (OUT32) {
+            if ((kg & 1) == 0) {                                    // channels 0..3 of both w-shifts
+                float* o32 = reinterpret_cast<float*>(p.out) + (((size_t)n * p.nbias * p.D + gd) * p.H + h0) * p.W + gw;
+                const size_t plane = (size_t)p.D * p.H * p.W;
+#pragma unroll
+                for (int ct = 0; ct < TH; ++ct)
+                    if (full || (gd < p.D && h0 + ct < p.H && gw < p.W)) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            if (c < p.nbias) o32[c * plane + (size_t)ct * p.W] = acc[ct][c];
+                    }
+            }
+            continue;
+        }
         T* obase = out + ((((size_t)n * p.D + gd) * p.H + h0) * p.W + gw) * p.out_cs + (kg & 1) * 4;
 #pragma unroll
         for (int ct = 0; ct < TH; ++ct) {
@@ -1892,6 +1908,9 @@ int lp_wg_fill(LpWgP& p, int N, int D, int H, int W) {
 #ifndef LP_WG_MINBOX
 #define LP_WG_MINBOX 2
 #endif
+#ifndef LP_UPWG4
+#define LP_UPWG4 1             // fused up-convolution weight gradient: lp_upwg4_kernel on box-multiple volumes (0: the UP = 2 mode)
+#endif
 #ifndef LP_WG8
 #define LP_WG8 1               // 8 -> 8 padded channels, k = 3, box-multiple volumes: lp_wgrad8_kernel (0: the generic kernel)
 #endif
@@ -1938,6 +1957,182 @@ int lp_upwg_launch(LpWgP& p, int gx, int tpb, hipStream_t st) {
     lp_conv_wgrad_kernel<T, 3, BW, 1, 1, 2, LZ><<<dim3(gx, 4 * (p.cin_p >> 4)), 256, lds, st>>>(p, tpb);
     CTU_CHECK_LAUNCH("lp_upconv_fused_wgrad");
     return CTU_OK;
+}
+
+// ---- fused up-convolution weight gradient, all four (p_d, p_h) parities and 32 input channels per block (coarse volumes that
+// are multiples of the 4 x 4 x 32 box, no lazy BatchNorm backward).  lp_conv_wgrad_kernel<.., UP = 2> gives every (parity, input-
+// channel tile) its own blocks: the coarse halo is staged 4 x (cin_p / 16) times and each block reads every other fine row of
+// the gradient (half of every cache line) -- 110 us for the 64^3 -> 128^3 level of UNet() against 50 MB of operands.  Here a
+// block stages the coarse halo (32 channels, two 16-channel planes) and the WHOLE fine gradient box once; wave = parity; the
+// wave's 16 gradient fragments stay in registers and each of the 25 halo rows a parity touches is read once (3 w offsets x 2
+// channel tiles) and used by the (dz, dy) taps that meet it: 332 fragment reads per 384 MFMAs; every wave owns its 24
+// accumulators, so there is no cross-wave reduction: the slabs ([12][16][16] per (parity, ci tile), lp_upwg_reduce_kernel's
+// layout) are written straight from the registers.  One block per CU (144 KB of LDS), next box's loads in flight in registers.
+constexpr int U4_HV = 6 * 6 * 34, U4_NX = (U4_HV * 4 + 255) / 256, U4_NG = 16;
+constexpr int U4_LDS = 128 + 2 * U4_HV * 32 + 64 * 1024;
+
+template <class T>
+__global__ __launch_bounds__(256, 1) void lp_upwg4_kernel(LpWgP p, int tiles_per_block) {
+    typedef typename Vec<T>::v8 v8;
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sX = smem + 128;                                 // [2 channel tiles][6][6][34] voxels x 32 B
+    unsigned char* sG = sX + (size_t)2 * U4_HV * 32;                // [8][8] fine rows x 64 fine voxels x 16 B
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15, q = i >> 2, pc = i & 3;
+    const int pd = wave >> 1, ph = wave & 1;                        // this wave's output parity
+    const int cib = blockIdx.y * 32;                                // first input channel of the block
+    const T* x = reinterpret_cast<const T*>(p.x) + cib + (tid & 3) * 8;         // (this thread's 8-channel quarter)
+    const T* gr = reinterpret_cast<const T*>(p.g);
+    const bool xf = p.scale != nullptr;
+    const int gH = 2 * p.H, gW = 2 * p.W;
+    int xa[2], ga[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int kk = 8 * g + 4 * r + q;
+        xa[r] = ((pd * 6 + ph) * 34 + kk) * 32 + 8 * pc;
+        ga[r] = (pd * 8 + ph) * 1024 + kk * 32 + 8 * pc;
+    }
+    f32x4 acc[2][12];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int t = 0; t < 12; ++t) acc[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // staging items: input item it = tid + 256 u -> (halo voxel it >> 2, 8-channel quarter it & 3 = tid & 3); gradient item ->
+    // fine voxel (fd = u >> 1, fh = (u & 1) * 4 + (tid >> 6), fw = tid & 63)
+    int xoff[U4_NX];
+    unsigned xface[U4_NX];
+#pragma unroll
+    for (int u = 0; u < U4_NX; ++u) {
+        const int it = tid + u * 256, v = it < U4_HV * 4 ? (it >> 2) : 0;
+        const int pw = v % 34, t2 = v / 34, phh = t2 % 6, pdd = t2 / 6;
+        xoff[u] = ((pdd * p.H + phh) * p.W + pw) * p.x_cs;
+        xface[u] = (pdd == 0 ? 1u : 0u) | (pdd == 5 ? 2u : 0u) | (phh == 0 ? 4u : 0u) | (phh == 5 ? 8u : 0u) |
+                   (pw == 0 ? 16u : 0u) | (pw == 33 ? 32u : 0u) | (it < U4_HV * 4 ? 0u : 64u);
+    }
+    const int goff0 = ((tid >> 6) * gW + (tid & 63)) * 8;                                   // + (fd gH + (u & 1) 4) gW 8
+    const long long xlim = ((long long)p.N * p.D * p.H * p.W - 1) * p.x_cs;
+    float wxs[8], wxh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = cib + (tid & 3) * 8 + j;
+        wxs[j] = xf ? p.scale[c] : 1.f;
+        wxh[j] = xf ? p.shift[c] : 0.f;
+    }
+    u32x4 rx[U4_NX], rg[U4_NG];
+    unsigned okx = 0;
+    int tile = blockIdx.x * tiles_per_block;
+    const int tile_end = min(p.ntiles, tile + tiles_per_block);
+    auto load_box = [&](int tl) {
+        int t = tl;
+        const int tx = t % p.tiles_w; t /= p.tiles_w;
+        const int ty = t % p.tiles_h; t /= p.tiles_h;
+        const int tz = t % p.tiles_d;
+        const int n = t / p.tiles_d;
+        const int d0 = tz * 4, h0 = ty * 4, w0 = tx * 32;
+        const unsigned bm = (d0 == 0 ? 1u : 0u) | (d0 + 4 == p.D ? 2u : 0u) | (h0 == 0 ? 4u : 0u) | (h0 + 4 == p.H ? 8u : 0u) |
+                            (w0 == 0 ? 16u : 0u) | (w0 + 32 == p.W ? 32u : 0u) | 64u;
+        const long long xb = ((((long long)n * p.D + d0 - 1) * p.H + h0 - 1) * p.W + w0 - 1) * p.x_cs;
+        okx = 0;
+        if (bm == 64u) {                                            // (uniform) interior box
+#pragma unroll
+            for (int u = 0; u < U4_NX; ++u) {
+                if (u == U4_NX - 1 && tid + u * 256 >= U4_HV * 4) continue;
+                rx[u] = *reinterpret_cast<const u32x4*>(x + xb + xoff[u]);
+                okx |= 1u << u;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U4_NX; ++u) {
+                long long e = xb + xoff[u];
+                e = e < 0 ? 0 : (e > xlim ? xlim : e);              // any readable address: the item is zeroed at the LDS write
+                rx[u] = *reinterpret_cast<const u32x4*>(x + e);
+                okx |= (xface[u] & bm) ? 0u : (1u << u);
+            }
+        }
+        const T* gb = gr + ((((long long)n * 2 * p.D + 2 * d0) * gH + 2 * h0) * gW + 2 * w0) * 8;
+#pragma unroll
+        for (int u = 0; u < U4_NG; ++u)
+            rg[u] = *reinterpret_cast<const u32x4*>(gb + goff0 + (((u >> 1) * gH + (u & 1) * 4) * gW) * 8);
+    };
+    auto rd_tr = [&](const unsigned char* base, const int (&a)[2]) -> v8 {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + a[0]));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + a[1]));
+        const s16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return *reinterpret_cast<const v8*>(&f);
+    };
+    if (tile < tile_end) load_box(tile);
+    for (; tile < tile_end; ++tile) {
+        __syncthreads();                                            // the previous box's readers are done
+#pragma unroll
+        for (int u = 0; u < U4_NX; ++u) {
+            const int it = tid + u * 256;
+            if (u == U4_NX - 1 && it >= U4_HV * 4) continue;
+            u32x4 r = rx[u];
+            if (!((okx >> u) & 1u)) r = u32x4{0u, 0u, 0u, 0u};
+            else if (xf) {
+                const f32x8 f = __builtin_convertvector(*reinterpret_cast<v8*>(&r), f32x8);
+                f32x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float a = fmaf(f[j], wxs[j], wxh[j]);
+                    o[j] = p.relu ? fmaxf(a, 0.f) : a;
+                }
+                *reinterpret_cast<v8*>(&r) = __builtin_convertvector(o, v8);
+            }
+            // plane = channel tile (quarter >> 1), 32 B per voxel
+            *reinterpret_cast<u32x4*>(sX + ((tid & 3) >> 1) * (U4_HV * 32) + (it >> 2) * 32 + (tid & 1) * 16) = r;
+        }
+#pragma unroll
+        for (int u = 0; u < U4_NG; ++u)
+            *reinterpret_cast<u32x4*>(sG + (((u >> 1) * 8 + (u & 1) * 4 + (tid >> 6)) * 64 + (tid & 63)) * 16) = rg[u];
+        __syncthreads();
+        if (tile + 1 < tile_end) load_box(tile + 1);
+        // ---- this wave's parity: 16 gradient fragments (coarse rows (td, th)), 25 halo rows x 3 w offsets x 2 channel tiles
+        v8 gf[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gf[r] = rd_tr(sG + ((2 * (r >> 2)) * 8 + 2 * (r & 3)) * 1024, ga);
+#pragma unroll
+        for (int a = 0; a < 5; ++a)
+#pragma unroll
+            for (int b = 0; b < 5; ++b) {
+                v8 xr[2][3];
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int dxx = 0; dxx < 3; ++dxx)
+                        xr[c][dxx] = rd_tr(sX + c * (U4_HV * 32) + ((a * 6 + b) * 34 + dxx) * 32, xa);
+#pragma unroll
+                for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+                    for (int dy = 0; dy < 2; ++dy) {
+                        const int td = a - dz, th = b - dy;
+                        if (td < 0 || td > 3 || th < 0 || th > 3) continue;
+#pragma unroll
+                        for (int c = 0; c < 2; ++c)
+#pragma unroll
+                            for (int dxx = 0; dxx < 3; ++dxx)
+                                acc[c][(dz * 2 + dy) * 3 + dxx] = Mfma<T>::run(xr[c][dxx], gf[td * 4 + th], acc[c][(dz * 2 + dy) * 3 + dxx]);
+                    }
+            }
+    }
+    // ---- slabs: [(parity, ci tile)][block][12][16 ci][16 = (p_w, co)], straight from the registers
+    const int n_ci_g = p.cin_p >> 4;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        float* dst = p.ws + ((size_t)(wave * n_ci_g + blockIdx.y * 2 + c) * gridDim.x + blockIdx.x) * (12 * 256);
+#pragma unroll
+        for (int t = 0; t < 12; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[t * 256 + (4 * g + r) * 16 + i] = acc[c][t][r];
+    }
+}
+
+inline bool lp_upwg4_ok(int D, int H, int W, int cin_p) { return cin_p % 32 == 0 && D % 4 == 0 && H % 4 == 0 && W % 32 == 0; }
+inline void lp_upwg4_grid(int ntiles, int* gx, int* tpb) {
+    int g = ntiles < 256 ? ntiles : 256;
+    *tpb = ceil_div(ntiles, g);
+    *gx = ceil_div(ntiles, *tpb);
 }
 
 // dW_eff[(pz,py,px)][(dz,dy,dxx-px)][cin_p][8] from the slabs [12 taps][16 ci][16 = (px, co)] (= conv3d.hip's
@@ -2096,6 +2291,36 @@ extern "C" int ctu_lp_conv3d_fwd(int dtype, const void* in, int in_cs, int rin_p
     return rc;
 }
 
+// The first layer's data gradient on the matrix pipe: g (8 padded channels, 16-bit, raw-output gradient) -> dx float32
+// [N][cin][D][H][W], cin <= 4, through lp_conv_fwd_pair_kernel<T, OUT32> (an 8 -> 8 layer whose outputs beyond cin are
+// never stored).  wp = ctu_lp_pack_conv3d_weight(w [Co][cin][27], mode 1, layout 1) with rin_p = nout_p = 8.  The VALU kernel
+// (ctu_lp_conv3d_first_bwd_data) spends 27 x 8 x cin FMAs per voxel on conversions and LDS reads: 78 us at 128^3, 0.70 ms at
+// 256^3 with two input channels; this launch costs what an 8 -> 8 forward costs.
+extern "C" int ctu_lp_conv3d_first_bwd_data_pair_supported(int cin, int W) { return cin >= 1 && cin <= 4 && W >= 32; }
+
+extern "C" int ctu_lp_conv3d_first_bwd_data_pair(int dtype, const void* g, int g_cs, const void* wp, int cin, float* dx,
+                                                 int N, int D, int H, int W, void* stream) {
+    CTU_REQUIRE(g && wp && dx, "lp_conv3d_first_bwd_data_pair: null pointer");
+    CTU_REQUIRE(ctu_lp_conv3d_first_bwd_data_pair_supported(cin, W), "lp_conv3d_first_bwd_data_pair: cin=%d W=%d", cin, W);
+    CTU_REQUIRE(g_cs >= 8 && g_cs % 8 == 0 && ((uintptr_t)g & 15) == 0 && ((uintptr_t)wp & 15) == 0 && ((uintptr_t)dx & 3) == 0,
+                "lp_conv3d_first_bwd_data_pair: strides / alignment (g_cs=%d)", g_cs);
+    CTU_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0, "lp_conv3d_first_bwd_data_pair: empty volume");
+    CTU_REQUIRE((int64_t)(6 * H + 6) * W * g_cs * 2 < (int64_t)1 << 31, "lp_conv3d_first_bwd_data_pair: volume too large for 32-bit offsets");
+    LpConvP p{};
+    p.in = g; p.wp = wp; p.out = dx;
+    p.tail = tail_or_off(nullptr);
+    p.in_cs = g_cs; p.rin_p = 8; p.relu = 0; p.out_cs = 0; p.nout_p = 8; p.nbias = cin;
+    p.N = N; p.D = D; p.H = H; p.W = W;
+    p.tiles_d = ceil_div(D, 4); p.tiles_h = ceil_div(H, LPP_TH); p.tiles_w = ceil_div(W, LPP_BW);
+    const int nt_ = lp_pair_ntiles(N, D, H, W);
+    int gx, tpb;
+    lp_pair_grid(nt_, &gx, &tpb);
+    hipStream_t st = (hipStream_t)stream;
+    CTU_DISPATCH_LP(dtype, (lp_conv_fwd_pair_kernel<T, true><<<gx, 256, LPP_LDS, st>>>(p, nt_, tpb)));
+    CTU_CHECK_LAUNCH("lp_conv3d_first_bwd_data_pair");
+    return CTU_OK;
+}
+
 extern "C" size_t ctu_lp_conv3d_wgrad_ws_floats(int N, int D, int H, int W, int k, int cin_p, int cout_p) {
     if ((k != 3 && k != 5) || cin_p <= 0 || cout_p <= 0) return 0;
     LpWgP p;
@@ -2206,6 +2431,7 @@ static void lp_upwg_geom(int N, int D, int H, int W, int cin_p, int* gx, int* tp
 extern "C" size_t ctu_lp_upconv_fused_wgrad_ws_floats(int N, int D, int H, int W, int cin_p) {
     int gx, tpb;
     lp_upwg_geom(N, D, H, W, cin_p, &gx, &tpb);
+    if (lp_upwg4_ok(D, H, W, cin_p) && gx < 256) gx = 256;        // lp_upwg4_kernel's slabs
     return (size_t)gx * 4 * (cin_p >> 4) * 12 * 256;
 }
 static int lp_upconv_fused_wgrad_impl(int dtype, const void* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
@@ -2240,10 +2466,29 @@ static int lp_upconv_fused_wgrad_impl(int dtype, const void* in, int in_cs, int 
     p.x = in; p.g = gout; p.scale = in_scale; p.shift = in_shift; p.ws = ws;
     p.x_cs = in_cs; p.cin_p = cin_p; p.relu = in_relu; p.g_cs = g_cs; p.cout_p = 16;
     if (lz) { p.lz_y = lz->y; p.lz_out = lz->out; p.lz_scale = lz->scale; p.lz_shift = lz->shift; p.lz_coef = lz->coef; p.lz_cp = lz->cp; }
+    hipStream_t st = (hipStream_t)stream;
+    if (LP_UPWG4 && !lz && lp_upwg4_ok(D, H, W, cin_p)) {
+        p.N = N; p.D = D; p.H = H; p.W = W;
+        p.tiles_d = D / 4; p.tiles_h = H / 4; p.tiles_w = W / 32;
+        p.ntiles = N * p.tiles_d * p.tiles_h * p.tiles_w;
+        int gx4, tpb4;
+        lp_upwg4_grid(p.ntiles, &gx4, &tpb4);
+        static bool raised = false;
+        if (!raised) {
+            CTU_REQUIRE(hipFuncSetAttribute((const void*)lp_upwg4_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, U4_LDS) == hipSuccess &&
+                        hipFuncSetAttribute((const void*)lp_upwg4_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, U4_LDS) == hipSuccess,
+                        "lp_upconv_fused_wgrad: cannot raise the dynamic LDS limit");
+            raised = true;
+        }
+        CTU_DISPATCH_LP(dtype, (lp_upwg4_kernel<T><<<dim3(gx4, cin_p >> 5), 256, U4_LDS, st>>>(p, tpb4)));
+        CTU_CHECK_LAUNCH("lp_upconv_fused_wgrad (4 parities)");
+        lp_upwg_reduce_kernel<<<dim3(12 * 256 / 64, 4 * (cin_p >> 4)), 1024, 0, st>>>(ws, dweff, cin_p, cin_p >> 4, gx4);
+        CTU_CHECK_LAUNCH("lp_upconv_fused_wgrad reduce");
+        return CTU_OK;
+    }
     lp_wg_fill(p, N, D, H, W);
     int gx, tpb;
     lp_upwg_geom(N, D, H, W, cin_p, &gx, &tpb);
-    hipStream_t st = (hipStream_t)stream;
     const int bw = lp_wg_box_w(W);
     int rc = CTU_OK;
     CTU_DISPATCH_LP(dtype, {

@@ -847,7 +847,7 @@ extern "C" int ctu_scale_tensors(void* const* ptrs, const int64_t* sizes, int n,
             if (tb.n[t] > mx) mx = tb.n[t];
         }
         int gx = (int)ceil_div64(mx, EW_BLOCK * 4);
-        if (gx > 128) gx = 128;
+        if (gx > 2048) gx = 2048;                                   // (dx of a 256^3 two-channel input is 134 MB)
         if (gx < 1) gx = 1;
         scale_tensors_kernel<<<dim3(gx, nt), EW_BLOCK, 0, (hipStream_t)stream>>>(tb, sc, nonfinite_flag);
         CTU_CHECK_LAUNCH("scale_tensors");

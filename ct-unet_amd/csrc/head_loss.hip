@@ -23,6 +23,7 @@ struct HeadP {
     const int32_t* imap;
     int in_cs, in_relu, Ci, Co, act, head_mode, N;
     int64_t V;
+    float gscale;            // backward: the incoming output gradients are multiplied by this (float16 loss scale), 1 otherwise
 };
 
 // activated input channels of one voxel -> logits -> y (post softmax/sigmoid)
@@ -200,6 +201,8 @@ __global__ __launch_bounds__(HB) void head_bwd_q_kernel(HeadP p, const float* __
             }
             gy[0] = a0; gy[1] = a1 - b0 + b1; gy[2] = a1; gy[3] = 0.f;
         }
+#pragma unroll
+        for (int co = 0; co < MAXCO; ++co) gy[co] *= p.gscale;      // (everything downstream is linear in the output gradients)
         float gu[MAXCO], gl[MAXCO];
 #pragma unroll
         for (int co = 0; co < MAXCO; ++co) gu[co] = (p.act & 2) ? gy[co] * y[co] * (1.f - y[co]) : gy[co];
@@ -434,7 +437,7 @@ static int fill_head(HeadP& p, const void* in, int in_cs, int cin_p, const float
     CTU_REQUIRE(in_cs >= cin_p && in_cs % 4 == 0, "%s: bad stride", name);
     CTU_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "%s: scale/shift must come together", name);
     p.in = in; p.in_scale = in_scale; p.in_shift = in_shift; p.w = w; p.bias = bias; p.imap = imap;
-    p.in_cs = in_cs; p.in_relu = in_relu; p.Ci = Ci; p.Co = Co; p.act = act; p.head_mode = head_mode; p.N = N; p.V = V;
+    p.in_cs = in_cs; p.in_relu = in_relu; p.Ci = Ci; p.Co = Co; p.act = act; p.head_mode = head_mode; p.N = N; p.V = V; p.gscale = 1.f;
     return CTU_OK;
 }
 
@@ -462,7 +465,7 @@ template <class T>
 int head_bwd_impl(const T* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift, int in_relu, const float* w,
                   const float* bias, const int32_t* imap, int Ci, int Co, int act, int head_mode, const float* g0, const float* g1,
                   T* gin, int gin_cs, float* dw, float* db, float* ws, int N, int64_t nvox_per_item, const float* bn_mean,
-                  const float* bn_invstd, int bn_cp, float* bn_partials, const ctu_bn_bwd_tail* tail, void* stream) {
+                  const float* bn_invstd, int bn_cp, float* bn_partials, const ctu_bn_bwd_tail* tail, void* stream, float gscale = 1.f) {
     CTU_REQUIRE(!tail || (bn_partials && tail->gamma && tail->invstd && tail->dgamma && tail->dbeta && tail->coef &&
                           tail->C > 0 && tail->C <= bn_cp && tail->count > 0 && (!tail->running_mean || (tail->mean && tail->running_var))),
                 "head_bwd: incomplete BatchNorm tail");
@@ -470,6 +473,7 @@ int head_bwd_impl(const T* in, int in_cs, int cin_p, const float* in_scale, cons
     int rc = fill_head(p, in, in_cs, cin_p, in_scale, in_shift, in_relu, w, bias, imap, Ci, Co, act, head_mode, N,
                        nvox_per_item, "head_bwd");
     if (rc != CTU_OK) return rc;
+    p.gscale = gscale;
     CTU_REQUIRE(g0 && (head_mode == 0 || g1) && gin && dw && db && ws, "head_bwd: null pointer");
     CTU_REQUIRE(gin_cs >= cin_p && gin_cs % 4 == 0, "head_bwd: bad gin stride");
     CTU_REQUIRE(!bn_partials || (bn_mean && bn_invstd && in_scale && in_relu && bn_cp > 0 && bn_cp % 4 == 0 && bn_cp <= cin_p),
@@ -535,10 +539,11 @@ extern "C" int ctu_lp_head_bwd_bn(int dtype, const void* in, int in_cs, int cin_
                                   int in_relu, const float* w, const float* bias, const int32_t* imap, int Ci, int Co, int act,
                                   int head_mode, const float* g0, const float* g1, void* gin, int gin_cs, float* dw,
                                   float* db, float* ws, int N, int64_t nvox_per_item, const float* bn_mean,
-                                  const float* bn_invstd, int bn_cp, float* bn_partials, const ctu_bn_bwd_tail* tail, void* stream) {
+                                  const float* bn_invstd, int bn_cp, float* bn_partials, const ctu_bn_bwd_tail* tail, float gscale,
+                                  void* stream) {
     CTU_DISPATCH_LP(dtype, return head_bwd_impl<T>((const T*)in, in_cs, cin_p, in_scale, in_shift, in_relu, w, bias, imap, Ci, Co, act,
                                                    head_mode, g0, g1, (T*)gin, gin_cs, dw, db, ws, N, nvox_per_item, bn_mean,
-                                                   bn_invstd, bn_cp, bn_partials, tail, stream));
+                                                   bn_invstd, bn_cp, bn_partials, tail, stream, gscale));
 }
 
 extern "C" size_t ctu_loss_ws_floats(int N, int64_t V) {

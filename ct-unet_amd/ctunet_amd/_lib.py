@@ -140,6 +140,8 @@ SIGNATURES = {
     "ctu_lp_conv3d_wgrad": (I, [I, P, I, I, P, P, I, P, I, I, P, I, I, P, P, I, I, I, I, I, P]),
     "ctu_lp_conv3d_first_fwd": (I, [I, P, I, P, P, I, P, I, I, P, I, I, I, I, P, P]),
     "ctu_lp_conv3d_first_bwd_data": (I, [I, P, I, P, I, I, P, I, I, I, I, P]),
+    "ctu_lp_conv3d_first_bwd_data_pair_supported": (I, [I, I]),
+    "ctu_lp_conv3d_first_bwd_data_pair": (I, [I, P, I, P, I, P, I, I, I, I, P]),
     "ctu_lp_conv3d_first_wgrad": (I, [I, P, I, P, I, P, I, P, I, I, I, I, P]),
     "ctu_lp_convt_packed_elems": (Z, [I, I, I]),
     "ctu_lp_pack_convt_weight": (I, [I, P, P, I, I, P, I, I, I, P]),
@@ -157,7 +159,7 @@ SIGNATURES = {
     "ctu_lp_skip_add": (I, [I, P, I, P, P, I, P, I, P, P, I, P, I, I, L, P]),
     "ctu_lp_channel_sum": (I, [I, P, I, I, L, P, P, I, P]),
     "ctu_lp_head_fwd": (I, [I, P, I, I, P, P, I, P, P, P, I, I, I, I, P, P, I, L, P]),
-    "ctu_lp_head_bwd_bn": (I, [I, P, I, I, P, P, I, P, P, P, I, I, I, I, P, P, P, I, P, P, P, I, L, P, P, I, P, P, P]),
+    "ctu_lp_head_bwd_bn": (I, [I, P, I, I, P, P, I, P, P, P, I, I, I, I, P, P, P, I, P, P, P, I, L, P, P, I, P, P, F, P]),
     "ctu_scale_tensors": (I, [P, P, I, F, P, P]),
     "ctu_comm_available": (I, []),
     "ctu_comm_unique_id": (I, [P]),

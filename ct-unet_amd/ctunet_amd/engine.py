@@ -536,9 +536,7 @@ class UNetEngine:
         flag = None
         if self.dtype == torch.float16:
             gs = self.loss_scale if self.loss_scale else float(2 ** max(0, (n * d * h * w).bit_length() - 5))
-            g0 = g0.contiguous().clone()
-            g1 = None if g1 is None else g1.contiguous().clone()
-            ops.scale_tensors([g0, g1], gs)
+            # (the head backward multiplies g0 / g1 by gs as it reads them: no scaled copy of the output-sized maps)
             # overflow guard: the un-scaling launches below set this flag when a gradient came out inf / NaN (a static loss
             # scale can overflow the 16-bit activation gradients); the fused optimizer skips the step when it is set
             flag = self.overflow_flag(dev)
@@ -605,12 +603,12 @@ class UNetEngine:
                 and head_in.c0 == r_last.y.c0 and head_in.buf is r_last.y.buf):
             fin = self._bwd_fin(P, r_last, head_in.buf.device)
             res = ops.head_bwd(head_in, w2, bl.detach(), ctx["imap_h"], plan.act, plan.head_mode, g0.contiguous(),
-                               None if g1 is None else g1.contiguous(), g_skip_target(0), (r_last.vec, part), fin)
+                               None if g1 is None else g1.contiguous(), g_skip_target(0), (r_last.vec, part), fin, gscale=gs)
             dwl, dbl, head_rows = res[:3]
             head_fin = res[3] if fin is not None else None
         else:
             dwl, dbl = ops.head_bwd(head_in, w2, bl.detach(), ctx["imap_h"], plan.act, plan.head_mode, g0.contiguous(),
-                                    None if g1 is None else g1.contiguous(), g_skip_target(0))
+                                    None if g1 is None else g1.contiguous(), g_skip_target(0), gscale=gs)
         g_skip_fanout(0)
         grads[plan.head + ".weight"], grads[plan.head + ".bias"] = dwl.reshape(wl.shape), dbl
         emit()

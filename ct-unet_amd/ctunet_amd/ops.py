@@ -483,11 +483,19 @@ def conv_first_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor
 
 
 def conv_first_bwd_data(g: CL, w: torch.Tensor, cin: int) -> torch.Tensor:
+    """dx (float32 NCDHW) of the first encoder convolution.  16-bit gradients of volumes at least 32 wide go through the
+    matrix pipe (the 8 -> 8 pair-layout kernel with a float32-plane epilogue; the weight's 9 KB fragment copy is made here,
+    one tiny launch), everything else through the direct kernel."""
     n, d, h, w_ = g.dims
     dx = torch.empty((n, cin, d, h, w_), dtype=torch.float32, device=g.buf.device)
     lib = _lib.load()
     t0 = TIMER.begin() if TIMER is not None else None
-    _dual(g.lp, "conv3d_first_bwd_data", g.ptr, g.cs, w.data_ptr(), cin, w.shape[0], dx.data_ptr(), n, d, h, w_, _stream())
+    if g.lp and g.cp == 8 and lib.ctu_lp_conv3d_first_bwd_data_pair_supported(cin, w_):
+        wp = pack_conv_w_lp(w, None, 8, 8, 1, g.dtype, None, 1)
+        _lib.check(lib.ctu_lp_conv3d_first_bwd_data_pair(g.lp, g.ptr, g.cs, wp.data_ptr(), cin, dx.data_ptr(), n, d, h, w_,
+                                                         _stream()), "lp_conv3d_first_bwd_data_pair")
+    else:
+        _dual(g.lp, "conv3d_first_bwd_data", g.ptr, g.cs, w.data_ptr(), cin, w.shape[0], dx.data_ptr(), n, d, h, w_, _stream())
     if t0 is not None:
         vox = n * d * h * w_
         TIMER.end(f"first_bwd_data_kernel<{cin}>", 2.0 * cin * w.shape[0] * 27 * vox, 4.0 * vox * (cin + w.shape[0]), t0)
@@ -769,10 +777,18 @@ def head_fwd(x: CL, w: torch.Tensor, b: torch.Tensor, imap, act: int, head_mode:
 
 
 def head_bwd(x: CL, w: torch.Tensor, b: torch.Tensor, imap, act: int, head_mode: int, g0: torch.Tensor,
-             g1: Optional[torch.Tensor], gin: CL, bn=None, fin=None):
+             g1: Optional[torch.Tensor], gin: CL, bn=None, fin=None, gscale: float = 1.0):
     """bn = (vec [4, bn_cp] of the BatchNorm whose activated output is x's first bn_cp channels, partials): also emit
     that BatchNorm's backward reduction rows; returns (dw, db, rows) then (rows -> bn_relu_bwd(pre_reduced=...)).
-    fin = (gamma, c, replay) with bn: the launch pair also finalizes that reduction; returns (dw, db, rows, (dgb, coef))."""
+    fin = (gamma, c, replay) with bn: the launch pair also finalizes that reduction; returns (dw, db, rows, (dgb, coef)).
+    gscale (16-bit tensors): g0 / g1 are multiplied by it as they are read (float16 loss scale)."""
+    assert gscale == 1.0 or x.lp, "gscale is the 16-bit path's loss scale"
+
+    def call(*args):                                    # (the 16-bit entry carries gscale in front of the stream)
+        if x.lp:
+            _lib.check(_lib.load().ctu_lp_head_bwd_bn(x.lp, *args[:-1], float(gscale), args[-1]), "lp_head_bwd_bn")
+        else:
+            _lib.check(_lib.load().ctu_head_bwd_bn(*args), "head_bwd_bn")
     n, d, h, w_ = x.dims
     co, ci = w.shape[0], w.shape[1]
     v = d * h * w_
@@ -792,11 +808,11 @@ def head_bwd(x: CL, w: torch.Tensor, b: torch.Tensor, imap, act: int, head_mode:
             dgb = torch.empty((2, c), dtype=torch.float32, device=dev)
             coef = torch.empty((5, bn_cp), dtype=torch.float32, device=dev)
             tail, done = make_bn_bwd_tail(c, n * v, gamma, vec, dgb, coef, replay, None), (dgb, coef)
-        _dual(x.lp, "head_bwd_bn", x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), w.data_ptr(), b.data_ptr(),
-              _ptr(imap), ci, co, act, head_mode, g0.data_ptr(), _ptr(g1), gin.ptr, gin.cs, dw.data_ptr(), db.data_ptr(),
+        call(x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), w.data_ptr(), b.data_ptr(),
+             _ptr(imap), ci, co, act, head_mode, g0.data_ptr(), _ptr(g1), gin.ptr, gin.cs, dw.data_ptr(), db.data_ptr(),
               ws.data_ptr(), n, v, vec[2].data_ptr(), vec[3].data_ptr(), bn_cp, partials.data_ptr(), _tail_arg(tail), _stream())
         return (dw, db, rows) if fin is None else (dw, db, rows, done)
-    _dual(x.lp, "head_bwd_bn", x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), w.data_ptr(), b.data_ptr(),
+    call(x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), w.data_ptr(), b.data_ptr(),
           _ptr(imap), ci, co, act, head_mode, g0.data_ptr(), _ptr(g1), gin.ptr, gin.cs, dw.data_ptr(), db.data_ptr(),
           ws.data_ptr(), n, v, None, None, 0, None, None, _stream())
     return dw, db

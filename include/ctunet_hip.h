@@ -474,6 +474,12 @@ int ctu_lp_conv3d_first_bwd_data(int dtype, const void* g, int g_cs, const float
                                  int D, int H, int W, void* stream);
 int ctu_lp_conv3d_first_wgrad(int dtype, const float* x, int cin, const void* g, int g_cs, float* dw, int Co, float* ws,
                               int N, int D, int H, int W, void* stream);
+/* the same data gradient on the matrix pipe (volumes at least 32 wide, cin <= 4): an 8 -> 8 "pair"-layout launch whose first
+ * cin outputs are stored as the float32 planes of dx.  wp = ctu_lp_pack_conv3d_weight(w, Co, Ci = cin, k = 3, rin_p = 8,
+ * nout_p = 8, mode 1, layout 1).  78 -> 33 us at 128^3 (cin 1), 0.70 -> 0.29 ms at 256^3 (cin 2), measured. */
+int ctu_lp_conv3d_first_bwd_data_pair_supported(int cin, int W);
+int ctu_lp_conv3d_first_bwd_data_pair(int dtype, const void* g, int g_cs, const void* wp, int cin, float* dx,
+                                      int N, int D, int H, int W, void* stream);
 /* ConvTranspose3d(C, C, 2, 2) + bias; packing mode 0 forward / 1 data gradient (different sizes: packed_elems(mode)) */
 size_t ctu_lp_convt_packed_elems(int rin_p, int nout_p, int mode);
 int ctu_lp_pack_convt_weight(int dtype, const float* w, void* wp, int Ci, int Co, const int32_t* cinv, int rin_p,
@@ -544,7 +550,9 @@ int ctu_lp_skip_add(int dtype, const void* a, int a_cs, const float* a_scale, co
                     void* out, int out_cs, int cp, int64_t nvox, void* stream);
 int ctu_lp_channel_sum(int dtype, const void* x, int cs, int cp, int64_t nvox, float* partials, float* out, int C,
                        void* stream);
-/* head: 16-bit input / input gradient, fp32 NCDHW outputs and output gradients (the loss stays fp32) */
+/* head: 16-bit input / input gradient, fp32 NCDHW outputs and output gradients (the loss stays fp32).
+ * ctu_lp_head_bwd_bn's gscale multiplies the incoming output gradients g0 / g1 as they are read: the float16 loss scale
+ * (1 otherwise) -- everything the launch produces is linear in them, so no scaled copy of the two output-sized maps is made. */
 int ctu_lp_head_fwd(int dtype, const void* in, int in_cs, int cin_p, const float* in_scale, const float* in_shift,
                     int in_relu, const float* w, const float* bias, const int32_t* imap, int Ci, int Co, int act,
                     int head_mode, float* out0, float* out1, int N, int64_t nvox_per_item, void* stream);
@@ -552,7 +560,8 @@ int ctu_lp_head_bwd_bn(int dtype, const void* in, int in_cs, int cin_p, const fl
                        int in_relu, const float* w, const float* bias, const int32_t* imap, int Ci, int Co, int act,
                        int head_mode, const float* g0, const float* g1, void* gin, int gin_cs, float* dw,
                        float* db, float* ws, int N, int64_t nvox_per_item, const float* bn_mean,
-                       const float* bn_invstd, int bn_cp, float* bn_partials, const ctu_bn_bwd_tail* tail, void* stream);
+                       const float* bn_invstd, int bn_cp, float* bn_partials, const ctu_bn_bwd_tail* tail, float gscale,
+                       void* stream);
 /* Every tensor of a list scaled in place by s (one launch): un-scaling of loss-scaled fp16 gradients.
  * ptrs: HOST array of n DEVICE float pointers, sizes: HOST int64[n].  nonfinite_flag: NULL or a DEVICE float[1] that is set
  * to 1 when any scaled value is inf / NaN (the fp16 backward overflowed; the caller zeroes it per step and hands it to

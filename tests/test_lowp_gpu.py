@@ -257,7 +257,14 @@ def test_lp_first_conv_and_head_against_fp32_kernels(name):
     dw16, dw32 = ops.conv_first_wgrad(x, to_cl(go, 8, dt), 7, ws).cpu(), ops.conv_first_wgrad(x, to_cl(go, 8, torch.float32), 7, ws).cpu()
     assert torch.allclose(dw16, dw32, rtol=1e-5, atol=1e-5)
     dx16, dx32 = ops.conv_first_bwd_data(to_cl(go, 8, dt), wt, 2).cpu(), ops.conv_first_bwd_data(to_cl(go, 8, torch.float32), wt, 2).cpu()
-    assert torch.allclose(dx16, dx32, rtol=1e-5, atol=1e-5)
+    # (>= 32 wide: the matrix-pipe route, whose weight fragments are 16-bit like every other layer's)
+    assert (dx16 - dx32).abs().max().item() <= 2 * ULP[name] * dx32.abs().max().item()
+    for cin, shp in ((1, (2, 5, 9, 70)), (2, (1, 12, 24, 96)), (1, (1, 4, 8, 16))):       # ragged / interior boxes; < 32 wide: direct kernel
+        wt2 = (torch.randn(7, cin, 3, 3, 3, generator=g) * 0.2).cuda()
+        go2 = rnd(torch.randn(shp[0], 7, *shp[1:], generator=g), dt)
+        a = ops.conv_first_bwd_data(to_cl(go2, 8, dt), wt2, cin).cpu()
+        b = torch.nn.grad.conv3d_input((shp[0], cin) + shp[1:], wt2.cpu(), go2, padding=1)
+        assert a.shape == b.shape and (a - b).abs().max().item() <= 2 * ULP[name] * b.abs().max().item(), (cin, shp)
     # head (SP re-encoding): 16-bit input, fp32 NCDHW outputs; backward writes a 16-bit input gradient
     hin = rnd(torch.randn(n, 14, d, h, w, generator=g), dt)
     hw_, hb = (torch.randn(3, 14, generator=g) * 0.3).cuda(), torch.randn(3, generator=g).cuda()
@@ -401,6 +408,10 @@ UPCONV_LP_CASES = [  # (C, Co, coarse NDHW, concat segments or None)
     (32, 7, (2, 6, 5, 20), None),                       # ragged boxes, 7 real output channels, batch 2
     (64, 8, (1, 4, 8, 16), None),                       # two 32-channel stages
     (28, 7, (1, 4, 4, 16), ((14, 0), (14, 16))),        # UNetSP widths: concat of two 14-channel halves in a 32-wide buffer
+    # coarse volumes that are multiples of the 4 x 4 x 32 box: the weight gradient is lp_upwg4_kernel (all four parities and 32
+    # input channels per block); (8, 12, 32) above is one too.  Interior box; two 32-channel groups + batch 2
+    (32, 8, (1, 12, 12, 96), None),
+    (64, 6, (2, 4, 8, 32), None),
 ]
 
 
