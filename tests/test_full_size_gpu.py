@@ -83,18 +83,21 @@ def _gate(res, lowp):
     assert res["grad_cos_global"] > g["cos_global"] and res["grad_cos_min"][0] > g["cos"] and res["dice"] >= g["dice"], res
 
 
-# Suite budget (<= 480 s on the GPU box; the ATen-CPU oracle's fwd+bwd is what costs: 60 s at 192^3, 110-140 s
-# at 256^3 per class): by default ONE class per kernel family runs at the configuration's full size -- UNetSP (k = 3, both sizes)
-# and recAE_v2_fixed (k = 5, 192^3) -- and the family's second class (same kernels, different widths) at 128^3;
-# CTUNET_FULLSIZE_ALL=1 runs every class at the full size (run once per round, recorded in profiles/README.md).
+# Suite budget (<= 480 s on the GPU box; what costs is the host side of a full-size case -- the ATen-CPU oracle's
+# fwd+bwd plus the float64 comparisons of 1e7..3e7-element tensors: 60 s per class at 192^3, 110-140 s at 256^3): by default
+# ONE class per kernel family runs at the configuration's full size -- UNetSP (k = 3; 192^3 bf16 and 256^3 fp16) and
+# recAE_v2_fixed (k = 5, 192^3 bf16).  The family's second class (UNet4_2IC: recAE's kernels at other widths; UNetSPSmall:
+# UNetSP's with 2 blocks) runs at full size under CTUNET_FULLSIZE_ALL=1 only (run once per round on the GPU box, result in
+# profiles/README.md); both stay covered by the per-class fp64-oracle and reduced-precision tests at 32^3 / 64^3.
 ALL = os.environ.get("CTUNET_FULLSIZE_ALL", "0") == "1"
+second = pytest.mark.skipif(not ALL, reason="second class of its kernel family at full size: CTUNET_FULLSIZE_ALL=1 (suite budget)")
 
 
-@pytest.mark.parametrize("name,size", [("UNetSP", 192), ("recAE_v2_fixed", 192), ("UNet4_2IC", 192 if ALL else 128)])
-def test_cfg4_192_train_step_fp32_then_bf16(name, size):
-    _gate(oracle_train_check(name, size, want_fp64=FP64, lowp="bf16"), "bf16")
+@pytest.mark.parametrize("name", ["UNetSP", "recAE_v2_fixed", pytest.param("UNet4_2IC", marks=second)])
+def test_cfg4_192_train_step_fp32_then_bf16(name):
+    _gate(oracle_train_check(name, 192, want_fp64=FP64, lowp="bf16"), "bf16")
 
 
-@pytest.mark.parametrize("name,size", [("UNetSP", 256), ("UNetSPSmall", 256 if ALL else 128)])
-def test_cfg5_256_train_step_fp32_then_fp16(name, size):
-    _gate(oracle_train_check(name, size, want_fp64=FP64, lowp="fp16"), "fp16")
+@pytest.mark.parametrize("name", ["UNetSP", pytest.param("UNetSPSmall", marks=second)])
+def test_cfg5_256_train_step_fp32_then_fp16(name):
+    _gate(oracle_train_check(name, 256, want_fp64=FP64, lowp="fp16"), "fp16")
