@@ -1838,6 +1838,175 @@ __global__ __launch_bounds__(256, 2) void lp_wgrad8_kernel(LpWgP p, int tiles_pe
     for (int e = tid; e < 9 * 256; e += 256) dst[e] = sS[e];
 }
 
+// ---- 16-channel tiles on both sides, k = 3, volumes that are multiples of the 4 x 8 x 32 box: lp_wgrad8_kernel's structure for
+// the plain 16 x 16 tile (27 accumulators, one (ci tile, co tile) pair per blockIdx.y).  One d plane per wave: its 8 gradient
+// fragments stay in registers, every input halo row is read once per (kd, kw) -- 9 fragments -- and used by the 3 kh taps that
+// meet it (196 fragment reads per 216 MFMAs; lp_conv_wgrad_kernel: 448); box 4 x 8 x 32 (halo 2.0x), one block per CU with the
+// next box's loads in flight in registers; face-code border handling.  16 -> 16 at 128^3: 133 -> ?? us.
+constexpr int W16_HV = 6 * 10 * 34, W16_NX = (W16_HV * 2 + 255) / 256, W16_NG = 8;
+constexpr int W16_LDS = 128 + (W16_HV + 1024) * 32;
+
+template <class T>
+__global__ __launch_bounds__(256, 1) void lp_wgrad16_kernel(LpWgP p, int tiles_per_block) {
+    typedef typename Vec<T>::v8 v8;
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sX = smem + 128;                                 // [6][10][34] voxels x 32 B (16 channels)
+    unsigned char* sG = sX + (size_t)W16_HV * 32;                   // [32 rows][32] voxels x 32 B
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15, q = i >> 2, pc = i & 3;
+    const int nco = (p.cout_p + 15) >> 4, cit = blockIdx.y / nco, cot = blockIdx.y % nco, half = tid & 1;
+    // live 8-channel halves of the two tiles (a tile's second half may lie beyond the padded channel count)
+    const bool xlive = cit * 16 + half * 8 < p.cin_p, glive = cot * 16 + half * 8 < p.cout_p;
+    const T* x = reinterpret_cast<const T*>(p.x) + cit * 16 + (xlive ? half * 8 : 0);
+    const T* gr = reinterpret_cast<const T*>(p.g) + cot * 16 + (glive ? half * 8 : 0);
+    const bool xf = p.scale != nullptr;
+    int xa[2], ga[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int kk = 8 * g + 4 * r + q;
+        xa[r] = kk * 32 + 8 * pc;
+        ga[r] = kk * 32 + 8 * pc;
+    }
+    f32x4 acc[27];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // staging items: input item it = tid + 256 u -> (halo voxel it >> 1, half it & 1 = tid & 1); gradient item -> box voxel
+    // (tid >> 1) + 128 u (row = voxel >> 5), same half
+    int xoff[W16_NX];
+    unsigned xface[W16_NX];
+#pragma unroll
+    for (int u = 0; u < W16_NX; ++u) {
+        const int it = tid + u * 256, v = it < W16_HV * 2 ? (it >> 1) : 0;
+        const int pw = v % 34, t2 = v / 34, ph = t2 % 10, pd = t2 / 10;
+        xoff[u] = ((pd * p.H + ph) * p.W + pw) * p.x_cs;
+        xface[u] = (pd == 0 ? 1u : 0u) | (pd == 5 ? 2u : 0u) | (ph == 0 ? 4u : 0u) | (ph == 9 ? 8u : 0u) |
+                   (pw == 0 ? 16u : 0u) | (pw == 33 ? 32u : 0u) | ((it < W16_HV * 2 && xlive) ? 0u : 64u);
+    }
+    const int gv0 = tid >> 1;                                                               // item u: voxel gv0 + 128 u = row 4 u + (gv0 >> 5)
+    const int goff0 = (((gv0 >> 5) & 7) * p.W + (gv0 & 31)) * p.g_cs;                       // rows 4 u + (0..3): th = (4 u + r) & 7, td = u >> 1
+    const long long xlim = ((long long)p.N * p.D * p.H * p.W - 1) * p.x_cs;
+    float wxs[8], wxh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = cit * 16 + half * 8 + j;
+        wxs[j] = (xf && xlive) ? p.scale[c] : 1.f;
+        wxh[j] = (xf && xlive) ? p.shift[c] : 0.f;
+    }
+    u32x4 rx[W16_NX], rg[W16_NG];
+    unsigned okx = 0;
+    int tile = blockIdx.x * tiles_per_block;
+    const int tile_end = min(p.ntiles, tile + tiles_per_block);
+    auto load_box = [&](int tl) {
+        int t = tl;
+        const int tx = t % p.tiles_w; t /= p.tiles_w;
+        const int ty = t % p.tiles_h; t /= p.tiles_h;
+        const int tz = t % p.tiles_d;
+        const int n = t / p.tiles_d;
+        const int d0 = tz * 4, h0 = ty * 8, w0 = tx * 32;
+        const unsigned bm = (d0 == 0 ? 1u : 0u) | (d0 + 4 == p.D ? 2u : 0u) | (h0 == 0 ? 4u : 0u) | (h0 + 8 == p.H ? 8u : 0u) |
+                            (w0 == 0 ? 16u : 0u) | (w0 + 32 == p.W ? 32u : 0u) | 64u;
+        const long long xb = ((((long long)n * p.D + d0 - 1) * p.H + h0 - 1) * p.W + w0 - 1) * p.x_cs;
+        okx = 0;
+#pragma unroll
+        for (int u = 0; u < W16_NX; ++u) {
+            long long e = xb + xoff[u];
+            e = e < 0 ? 0 : (e > xlim ? xlim : e);                  // any readable address: an outside item is zeroed at the LDS write
+            rx[u] = *reinterpret_cast<const u32x4*>(x + e);
+            okx |= (xface[u] & bm) ? 0u : (1u << u);
+        }
+        const T* gb = gr + ((((long long)n * p.D + d0) * p.H + h0) * p.W + w0) * p.g_cs;
+#pragma unroll
+        for (int u = 0; u < W16_NG; ++u) {
+            // row 4 u + r (r = gv0 >> 5): td = u >> 1, th = (u & 1) * 4 + r
+            const u32x4 r = *reinterpret_cast<const u32x4*>(gb + goff0 + (((u >> 1) * p.H + (u & 1) * 4) * p.W) * p.g_cs);
+            rg[u] = glive ? r : u32x4{0u, 0u, 0u, 0u};
+        }
+    };
+    auto rd_tr = [&](const unsigned char* base, const int (&a)[2]) -> v8 {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + a[0]));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + a[1]));
+        const s16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return *reinterpret_cast<const v8*>(&f);
+    };
+    if (tile < tile_end) load_box(tile);
+    for (; tile < tile_end; ++tile) {
+        __syncthreads();                                            // the previous box's readers are done
+#pragma unroll
+        for (int u = 0; u < W16_NX; ++u) {
+            const int it = tid + u * 256;
+            if (u == W16_NX - 1 && it >= W16_HV * 2) continue;
+            u32x4 r = rx[u];
+            if (!((okx >> u) & 1u)) r = u32x4{0u, 0u, 0u, 0u};
+            else if (xf) {
+                const f32x8 f = __builtin_convertvector(*reinterpret_cast<v8*>(&r), f32x8);
+                f32x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float a = fmaf(f[j], wxs[j], wxh[j]);
+                    o[j] = p.relu ? fmaxf(a, 0.f) : a;
+                }
+                *reinterpret_cast<v8*>(&r) = __builtin_convertvector(o, v8);
+            }
+            *reinterpret_cast<u32x4*>(sX + it * 16) = r;
+        }
+#pragma unroll
+        for (int u = 0; u < W16_NG; ++u) *reinterpret_cast<u32x4*>(sG + (tid + u * 256) * 16) = rg[u];
+        __syncthreads();
+        if (tile + 1 < tile_end) load_box(tile + 1);
+        // ---- this wave's d plane: 8 gradient fragments in registers; per halo row 9 input fragments (kd, kw) x the kh taps
+        v8 gf[8];
+#pragma unroll
+        for (int h = 0; h < 8; ++h) gf[h] = rd_tr(sG + (wave * 8 + h) * 1024, ga);
+#pragma unroll
+        for (int hp = 0; hp < 10; ++hp) {
+            v8 xr[3][3];
+#pragma unroll
+            for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) xr[kd][kw] = rd_tr(sX + (((wave + kd) * 10 + hp) * 34 + kw) * 32, xa);
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const int h = hp - kh;
+                if (h < 0 || h > 7) continue;
+#pragma unroll
+                for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw)
+                        acc[(kd * 3 + kh) * 3 + kw] = Mfma<T>::run(xr[kd][kw], gf[h], acc[(kd * 3 + kh) * 3 + kw]);
+            }
+        }
+    }
+    // ---- cross-wave sum in LDS, one slab per block (layout of lp_conv_wgrad_kernel<T, 3, .., 1, 1>)
+    float* sS = reinterpret_cast<float*>(smem + 128);
+    for (int wv = 0; wv < 4; ++wv) {
+        __syncthreads();
+        if (wave == wv) {
+#pragma unroll
+            for (int t = 0; t < 27; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float* e = &sS[t * 256 + (4 * g + r) * 16 + i];        // row = ci 4 g + r, col = co i
+                    *e = (wv == 0) ? acc[t][r] : (*e + acc[t][r]);
+                }
+        }
+    }
+    __syncthreads();
+    float* dst = p.ws + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (27 * 256);
+    for (int e = tid; e < 27 * 256; e += 256) dst[e] = sS[e];
+}
+
+inline bool lp_wg16_ok(int D, int H, int W, int k, int cin_p, int cout_p) {
+    return k == 3 && cin_p >= 16 && cout_p >= 16 && D % 4 == 0 && H % 8 == 0 && W % 32 == 0;
+}
+inline void lp_wg16_grid(int ntiles, int pairs, int* gx, int* tpb) {
+    int g = 256 / pairs;
+    if (g < 8) g = 8;
+    if (g > ntiles) g = ntiles;
+    *tpb = ceil_div(ntiles, g);
+    *gx = ceil_div(ntiles, *tpb);
+}
+
 // the geometries lp_wgrad8_kernel takes
 inline bool lp_wg8_ok(int D, int H, int W, int k, int cin_p, int cout_p) {
     return k == 3 && cin_p == 8 && cout_p == 8 && D % 4 == 0 && H % 8 == 0 && W % 32 == 0;
@@ -1907,6 +2076,9 @@ int lp_wg_fill(LpWgP& p, int N, int D, int H, int W) {
 // reduction and its slab, which the reduce kernel reads back) are those of several boxes' MFMAs
 #ifndef LP_WG_MINBOX
 #define LP_WG_MINBOX 2
+#endif
+#ifndef LP_WG16
+#define LP_WG16 1              // 16-channel tiles, k = 3, box-multiple volumes: lp_wgrad16_kernel (0: the generic kernel)
 #endif
 #ifndef LP_UPWG4
 #define LP_UPWG4 1             // fused up-convolution weight gradient: lp_upwg4_kernel on box-multiple volumes (0: the UP = 2 mode)
@@ -2321,6 +2493,23 @@ extern "C" int ctu_lp_conv3d_first_bwd_data_pair(int dtype, const void* g, int g
     return CTU_OK;
 }
 
+// kernel symbols the launches above pick for a geometry (measurement only: bench.py's per-kernel roofline leg and
+// scripts/stage_table.py tag their event pairs with them)
+extern "C" const char* ctu_lp_conv3d_fwd_kernel_name(int N, int D, int H, int W, int k, int rin_p, int nout_p, int layout) {
+    (void)nout_p;
+    if (layout == 1) return "lp_conv_fwd_pair_kernel";
+    LpConvP p;
+    const int ntiles = lp_fill(p, N, D, H, W, rin_p);
+    const LpBox bx = lp_box(W, rin_p, (int64_t)N * D * H * W);
+    if (k == 3 && lp_use_persist(3, rin_p, ntiles) && bx.bw >= 16) return "lp_conv_fwd_p1_kernel";
+    if (k == 3 && bx.bw == 8 && bx.th == 4) return "lp_conv_fwd_small_kernel";
+    return "lp_conv_fwd_kernel";
+}
+extern "C" const char* ctu_lp_conv3d_wgrad_kernel_name(int D, int H, int W, int k, int cin_p, int cout_p) {
+    if (LP_WG8 && lp_wg8_ok(D, H, W, k, cin_p, cout_p)) return "lp_wgrad8_kernel";
+    return (LP_WG16 && lp_wg16_ok(D, H, W, k, cin_p, cout_p)) ? "lp_wgrad16_kernel" : "lp_conv_wgrad_kernel";
+}
+
 extern "C" size_t ctu_lp_conv3d_wgrad_ws_floats(int N, int D, int H, int W, int k, int cin_p, int cout_p) {
     if ((k != 3 && k != 5) || cin_p <= 0 || cout_p <= 0) return 0;
     LpWgP p;
@@ -2331,6 +2520,12 @@ extern "C" size_t ctu_lp_conv3d_wgrad_ws_floats(int N, int D, int H, int W, int 
     const int ntap = (k == 3 ? 9 : k) * lp_wg_qn(k, lp_wg_sm(W, cin_p), lp_wg_sn(W, cout_p));
     size_t n = (size_t)gx * pairs * planes * ntap * 256;
     if (lp_wg8_ok(D, H, W, k, cin_p, cout_p) && n < (size_t)512 * 9 * 256) n = (size_t)512 * 9 * 256;     // lp_wgrad8_kernel's slabs
+    if (lp_wg16_ok(D, H, W, k, cin_p, cout_p)) {                                                         // lp_wgrad16_kernel's
+        int gx16, tpb16;
+        lp_wg16_grid(N * (D / 4) * (H / 8) * (W / 32), pairs, &gx16, &tpb16);
+        const size_t n16 = (size_t)gx16 * pairs * 27 * 256;
+        if (n < n16) n = n16;
+    }
     return n;
 }
 
@@ -2391,6 +2586,26 @@ static int lp_conv3d_wgrad_impl(int dtype, const void* in, int in_cs, int cin_p,
         });
         CTU_CHECK_LAUNCH("lp_conv3d_wgrad (8 -> 8)");
         lp_wgrad_reduce_kernel<3, 2, 2><<<dim3(ceil_div(9 * 256, 64)), 1024, 0, st>>>(ws, dw, Co, Ci, cinv, cin_p, cout_p, gx8);
+        CTU_CHECK_LAUNCH("lp_conv3d_wgrad reduce");
+        return CTU_OK;
+    }
+    if (LP_WG16 && !lz && lp_wg16_ok(D, H, W, k, cin_p, cout_p)) {
+        p.N = N; p.D = D; p.H = H; p.W = W;
+        p.tiles_d = D / 4; p.tiles_h = H / 8; p.tiles_w = W / 32;
+        p.ntiles = N * p.tiles_d * p.tiles_h * p.tiles_w;
+        const int pairs16 = ((cin_p + 15) >> 4) * ((cout_p + 15) >> 4);
+        int gx16, tpb16;
+        lp_wg16_grid(p.ntiles, pairs16, &gx16, &tpb16);
+        static bool raised = false;
+        if (!raised) {
+            CTU_REQUIRE(hipFuncSetAttribute((const void*)lp_wgrad16_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, W16_LDS) == hipSuccess &&
+                        hipFuncSetAttribute((const void*)lp_wgrad16_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, W16_LDS) == hipSuccess,
+                        "lp_conv3d_wgrad: cannot raise the dynamic LDS limit");
+            raised = true;
+        }
+        CTU_DISPATCH_LP(dtype, (lp_wgrad16_kernel<T><<<dim3(gx16, pairs16), 256, W16_LDS, st>>>(p, tpb16)));
+        CTU_CHECK_LAUNCH("lp_conv3d_wgrad (16-channel tiles)");
+        lp_wgrad_reduce_kernel<3, 1, 1><<<dim3(ceil_div(pairs16 * 27 * 256, 64)), 1024, 0, st>>>(ws, dw, Co, Ci, cinv, cin_p, cout_p, gx16);
         CTU_CHECK_LAUNCH("lp_conv3d_wgrad reduce");
         return CTU_OK;
     }

@@ -141,6 +141,8 @@ SIGNATURES = {
     "ctu_lp_conv3d_first_fwd": (I, [I, P, I, P, P, I, P, I, I, P, I, I, I, I, P, P]),
     "ctu_lp_conv3d_first_bwd_data": (I, [I, P, I, P, I, I, P, I, I, I, I, P]),
     "ctu_lp_conv3d_first_bwd_data_pair_supported": (I, [I, I]),
+    "ctu_lp_conv3d_fwd_kernel_name": (C.c_char_p, [I, I, I, I, I, I, I, I]),
+    "ctu_lp_conv3d_wgrad_kernel_name": (C.c_char_p, [I, I, I, I, I, I]),
     "ctu_lp_conv3d_first_bwd_data_pair": (I, [I, P, I, P, I, P, I, I, I, I, P]),
     "ctu_lp_conv3d_first_wgrad": (I, [I, P, I, P, I, P, I, P, I, I, I, I, P]),
     "ctu_lp_convt_packed_elems": (Z, [I, I, I]),

@@ -342,9 +342,9 @@ def conv3d_fwd(x: CL, wp: torch.Tensor, bias: Optional[torch.Tensor], out: CL, k
         if t0 is not None:
             ci, co = algo_ch if algo_ch is not None else (x.cp, out.cp)
             vox = n * d * h * w
-            dt = 'bf16' if x.lp == 1 else 'f16'
-            TIMER.end(f"lp_conv_fwd_pair_kernel<{dt}>" if layout == 1 else f"lp_conv_fwd_kernel<{dt}, {k}>",
-                      2.0 * ci * co * k ** 3 * vox, 2.0 * vox * (ci + co), t0, (w, x.cp, out.cp))
+            name = lib.ctu_lp_conv3d_fwd_kernel_name(n, d, h, w, k, x.cp, out.cp, layout).decode()
+            TIMER.end(f"{name}<{'bf16' if x.lp == 1 else 'f16'}, {k}>", 2.0 * ci * co * k ** 3 * vox, 2.0 * vox * (ci + co), t0,
+                      (w, x.cp, out.cp))
         return
     t0 = TIMER.begin() if TIMER is not None else None
     _lib.check(lib.ctu_conv3d_fwd(x.ptr, x.cs, x.cp, _ptr(x.scale), _ptr(x.shift), int(x.relu), wp.data_ptr(),
@@ -372,7 +372,8 @@ def conv3d_wgrad(x: CL, g: CL, co: int, ci: int, k: int, cinv: Optional[torch.Te
                    "lp_conv3d_wgrad")
         if t0 is not None:
             vox = n * d * h * w
-            TIMER.end(f"lp_conv_wgrad_kernel<{'bf16' if x.lp == 1 else 'f16'}, {k}> (+slab reduce)",
+            name = lib.ctu_lp_conv3d_wgrad_kernel_name(d, h, w, k, x.cp, g.cp).decode()
+            TIMER.end(f"{name}<{'bf16' if x.lp == 1 else 'f16'}, {k}> (+slab reduce)",
                       2.0 * ci * co * k ** 3 * vox, 2.0 * vox * (ci + co), t0, (w, x.cp, g.cp))
         return dw, (channel_sum(g, co) if want_bias else None)
     need = lib.ctu_conv3d_wgrad_ws_floats(n, d, h, w, k, x.cp, g.cp)
@@ -418,7 +419,8 @@ def conv3d_wgrad_bn(x: CL, ga: CL, y: CL, vec: torch.Tensor, coef: torch.Tensor,
                    "lp_conv3d_wgrad_bn")
         if t0 is not None:
             vox = n * d * h * w
-            TIMER.end(f"lp_conv_wgrad_kernel<{'bf16' if x.lp == 1 else 'f16'}, {k}> (+slab reduce)",
+            name = lib.ctu_lp_conv3d_wgrad_kernel_name(d, h, w, k, x.cp, ga.cp).decode()
+            TIMER.end(f"{name}<{'bf16' if x.lp == 1 else 'f16'}, {k}> (+slab reduce)",
                       2.0 * ci * co * k ** 3 * vox, 2.0 * vox * (ci + co), t0, (w, x.cp, ga.cp))
         return dw
     need = lib.ctu_conv3d_wgrad_ws_floats(n, d, h, w, k, x.cp, ga.cp)
@@ -490,7 +492,8 @@ def conv_first_bwd_data(g: CL, w: torch.Tensor, cin: int) -> torch.Tensor:
     dx = torch.empty((n, cin, d, h, w_), dtype=torch.float32, device=g.buf.device)
     lib = _lib.load()
     t0 = TIMER.begin() if TIMER is not None else None
-    if g.lp and g.cp == 8 and lib.ctu_lp_conv3d_first_bwd_data_pair_supported(cin, w_):
+    pair = bool(g.lp and g.cp == 8 and lib.ctu_lp_conv3d_first_bwd_data_pair_supported(cin, w_))
+    if pair:
         wp = pack_conv_w_lp(w, None, 8, 8, 1, g.dtype, None, 1)
         _lib.check(lib.ctu_lp_conv3d_first_bwd_data_pair(g.lp, g.ptr, g.cs, wp.data_ptr(), cin, dx.data_ptr(), n, d, h, w_,
                                                          _stream()), "lp_conv3d_first_bwd_data_pair")
@@ -498,7 +501,8 @@ def conv_first_bwd_data(g: CL, w: torch.Tensor, cin: int) -> torch.Tensor:
         _dual(g.lp, "conv3d_first_bwd_data", g.ptr, g.cs, w.data_ptr(), cin, w.shape[0], dx.data_ptr(), n, d, h, w_, _stream())
     if t0 is not None:
         vox = n * d * h * w_
-        TIMER.end(f"first_bwd_data_kernel<{cin}>", 2.0 * cin * w.shape[0] * 27 * vox, 4.0 * vox * (cin + w.shape[0]), t0)
+        tag = f"lp_conv_fwd_pair_kernel<{'bf16' if g.lp == 1 else 'f16'}, dx of the first layer>" if pair else f"first_bwd_data_kernel<{cin}>"
+        TIMER.end(tag, 2.0 * cin * w.shape[0] * 27 * vox, (2.0 * w.shape[0] if g.lp else 4.0 * w.shape[0]) * vox + 4.0 * vox * cin, t0)
     return dx
 
 

@@ -477,6 +477,9 @@ int ctu_lp_conv3d_first_wgrad(int dtype, const float* x, int cin, const void* g,
 /* the same data gradient on the matrix pipe (volumes at least 32 wide, cin <= 4): an 8 -> 8 "pair"-layout launch whose first
  * cin outputs are stored as the float32 planes of dx.  wp = ctu_lp_pack_conv3d_weight(w, Co, Ci = cin, k = 3, rin_p = 8,
  * nout_p = 8, mode 1, layout 1).  78 -> 33 us at 128^3 (cin 1), 0.70 -> 0.29 ms at 256^3 (cin 2), measured. */
+/* kernel symbol a 16-bit forward / weight-gradient launch of this geometry runs (measurement tags, as ctu_conv3d_*_kernel_name) */
+const char* ctu_lp_conv3d_fwd_kernel_name(int N, int D, int H, int W, int k, int rin_p, int nout_p, int layout);
+const char* ctu_lp_conv3d_wgrad_kernel_name(int D, int H, int W, int k, int cin_p, int cout_p);
 int ctu_lp_conv3d_first_bwd_data_pair_supported(int cin, int W);
 int ctu_lp_conv3d_first_bwd_data_pair(int dtype, const void* g, int g_cs, const void* wp, int cin, float* dx,
                                       int N, int D, int H, int W, void* stream);

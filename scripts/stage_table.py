@@ -89,8 +89,9 @@ if a.profiled:
 def family(tag):
     """Substring every dispatch of the launch site carries in its kernel name (mangled or not)."""
     base = tag.split("<")[0].split(" ")[0]
-    return {"upconv_fused_wgrad_kernel": "conv3d_wgrad_k3s_kernel", "lp_upconv_wgrad_kernel": "lp_conv_wgrad_kernel",
-            "lp_conv_fwd_kernel": "lp_conv_fwd", "lp_conv_fwd_pair_kernel": "lp_conv_fwd",
+    return {"upconv_fused_wgrad_kernel": "conv3d_wgrad_k3s_kernel", "lp_upconv_wgrad_kernel": "lp_upwg4_kernel",
+            "lp_conv_fwd_kernel": "lp_conv_fwd", "lp_conv_fwd_pair_kernel": "lp_conv_fwd", "lp_conv_fwd_p1_kernel": "lp_conv_fwd",
+            "lp_conv_fwd_small_kernel": "lp_conv_fwd", "lp_wgrad8_kernel": "lp_wgrad8_kernel",
             "convt2_fwd": "convt2_kernel", "convt2_bwd_data": "convt2_kernel", "convt2_wgrad": "convt2_wgrad_kernel",
             "convt2_fwd_lp": "lp_convt_fwd_kernel", "convt2_bwd_data_lp": "lp_convt_bwd_data_kernel",
             "convt2_wgrad_lp": "lp_convt_wgrad_kernel"}.get(base, base)

@@ -57,6 +57,8 @@ CONV_CASES = [  # (k, ci, co, shape NDHW, transform)
     (3, 8, 8, (2, 5, 9, 70), True), (3, 8, 8, (1, 12, 24, 96), True), (3, 7, 8, (1, 4, 8, 32), True),
     # ... whose weight gradient, on volumes that are multiples of the 4 x 8 x 32 box, is lp_wgrad8_kernel (the two above; batch 2)
     (3, 8, 5, (2, 8, 16, 64), False),
+    # 16-channel tiles on box-multiple volumes: lp_wgrad16_kernel (interior + border boxes; half-empty last tiles; batch 2)
+    (3, 16, 16, (1, 8, 16, 64), True), (3, 40, 24, (2, 4, 8, 32), True), (3, 32, 16, (1, 12, 24, 96), False),
 ]
 
 
