@@ -1846,7 +1846,7 @@ __global__ __launch_bounds__(256, 2) void lp_wgrad8_kernel(LpWgP p, int tiles_pe
 constexpr int W16_HV = 6 * 10 * 34, W16_NX = (W16_HV * 2 + 255) / 256, W16_NG = 8;
 constexpr int W16_LDS = 128 + (W16_HV + 1024) * 32;
 
-template <class T>
+template <class T, bool LZ>
 __global__ __launch_bounds__(256, 1) void lp_wgrad16_kernel(LpWgP p, int tiles_per_block) {
     typedef typename Vec<T>::v8 v8;
     typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -1893,7 +1893,20 @@ __global__ __launch_bounds__(256, 1) void lp_wgrad16_kernel(LpWgP p, int tiles_p
         wxs[j] = (xf && xlive) ? p.scale[c] : 1.f;
         wxh[j] = (xf && xlive) ? p.shift[c] : 0.f;
     }
-    u32x4 rx[W16_NX], rg[W16_NG];
+    // LZ (lazy BatchNorm + ReLU backward, as in lp_conv_wgrad_kernel): g is the gradient w.r.t. the ACTIVATED output; the raw-
+    // output gradient is formed at the LDS write from the raw output y (same geometry) and stored to p.lz_out
+    const ptrdiff_t lz_ydelta = LZ ? reinterpret_cast<const char*>(p.lz_y) - reinterpret_cast<const char*>(p.g) : 0;
+    float lsc[LZ ? 8 : 1], lsh[LZ ? 8 : 1], lk0[LZ ? 8 : 1], lA[LZ ? 8 : 1], lB[LZ ? 8 : 1];
+    if constexpr (LZ) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = cot * 16 + half * 8 + j;
+            const bool in = c < p.lz_cp;
+            lsc[j] = in ? p.lz_scale[c] : 0.f; lsh[j] = in ? p.lz_shift[c] : 0.f;
+            lk0[j] = in ? p.lz_coef[c] : 0.f; lA[j] = in ? p.lz_coef[3 * p.lz_cp + c] : 0.f; lB[j] = in ? p.lz_coef[4 * p.lz_cp + c] : 0.f;
+        }
+    }
+    u32x4 rx[W16_NX], rg[W16_NG], ry[LZ ? W16_NG : 1];
     unsigned okx = 0;
     int tile = blockIdx.x * tiles_per_block;
     const int tile_end = min(p.ntiles, tile + tiles_per_block);
@@ -1919,8 +1932,10 @@ __global__ __launch_bounds__(256, 1) void lp_wgrad16_kernel(LpWgP p, int tiles_p
 #pragma unroll
         for (int u = 0; u < W16_NG; ++u) {
             // row 4 u + r (r = gv0 >> 5): td = u >> 1, th = (u & 1) * 4 + r
-            const u32x4 r = *reinterpret_cast<const u32x4*>(gb + goff0 + (((u >> 1) * p.H + (u & 1) * 4) * p.W) * p.g_cs);
+            const T* src = gb + goff0 + (((u >> 1) * p.H + (u & 1) * 4) * p.W) * p.g_cs;
+            const u32x4 r = *reinterpret_cast<const u32x4*>(src);
             rg[u] = glive ? r : u32x4{0u, 0u, 0u, 0u};
+            if constexpr (LZ) ry[u] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(src) + lz_ydelta);
         }
     };
     auto rd_tr = [&](const unsigned char* base, const int (&a)[2]) -> v8 {
@@ -1949,6 +1964,28 @@ __global__ __launch_bounds__(256, 1) void lp_wgrad16_kernel(LpWgP p, int tiles_p
                 *reinterpret_cast<v8*>(&r) = __builtin_convertvector(o, v8);
             }
             *reinterpret_cast<u32x4*>(sX + it * 16) = r;
+        }
+        if constexpr (LZ) {
+            if (glive) {
+                int t = tile;
+                const int tx = t % p.tiles_w; t /= p.tiles_w;
+                const int ty = t % p.tiles_h; t /= p.tiles_h;
+                const int tz = t % p.tiles_d;
+                const int n = t / p.tiles_d;
+                T* ob = reinterpret_cast<T*>(p.lz_out) + cot * 16 + half * 8 +
+                        ((((long long)n * p.D + tz * 4) * p.H + ty * 8) * p.W + tx * 32) * p.g_cs;
+#pragma unroll
+                for (int u = 0; u < W16_NG; ++u) {
+                    const f32x8 gq = __builtin_convertvector(*reinterpret_cast<v8*>(&rg[u]), f32x8);
+                    const f32x8 yq = __builtin_convertvector(*reinterpret_cast<v8*>(&ry[u]), f32x8);
+                    f32x8 o;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        o[j] = fmaf(lk0[j], (fmaf(yq[j], lsc[j], lsh[j]) > 0.f) ? gq[j] : 0.f, fmaf(lA[j], yq[j], lB[j]));
+                    *reinterpret_cast<v8*>(&rg[u]) = __builtin_convertvector(o, v8);
+                    if (cit == 0) *reinterpret_cast<u32x4*>(ob + goff0 + (((u >> 1) * p.H + (u & 1) * 4) * p.W) * p.g_cs) = rg[u];
+                }
+            }
         }
 #pragma unroll
         for (int u = 0; u < W16_NG; ++u) *reinterpret_cast<u32x4*>(sG + (tid + u * 256) * 16) = rg[u];
@@ -2589,7 +2626,7 @@ static int lp_conv3d_wgrad_impl(int dtype, const void* in, int in_cs, int cin_p,
         CTU_CHECK_LAUNCH("lp_conv3d_wgrad reduce");
         return CTU_OK;
     }
-    if (LP_WG16 && !lz && lp_wg16_ok(D, H, W, k, cin_p, cout_p)) {
+    if (LP_WG16 && lp_wg16_ok(D, H, W, k, cin_p, cout_p)) {
         p.N = N; p.D = D; p.H = H; p.W = W;
         p.tiles_d = D / 4; p.tiles_h = H / 8; p.tiles_w = W / 32;
         p.ntiles = N * p.tiles_d * p.tiles_h * p.tiles_w;
@@ -2598,12 +2635,19 @@ static int lp_conv3d_wgrad_impl(int dtype, const void* in, int in_cs, int cin_p,
         lp_wg16_grid(p.ntiles, pairs16, &gx16, &tpb16);
         static bool raised = false;
         if (!raised) {
-            CTU_REQUIRE(hipFuncSetAttribute((const void*)lp_wgrad16_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, W16_LDS) == hipSuccess &&
-                        hipFuncSetAttribute((const void*)lp_wgrad16_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, W16_LDS) == hipSuccess,
+            CTU_REQUIRE(hipFuncSetAttribute((const void*)lp_wgrad16_kernel<bf16_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, W16_LDS) == hipSuccess &&
+                        hipFuncSetAttribute((const void*)lp_wgrad16_kernel<f16_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, W16_LDS) == hipSuccess &&
+                        hipFuncSetAttribute((const void*)lp_wgrad16_kernel<bf16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, W16_LDS) == hipSuccess &&
+                        hipFuncSetAttribute((const void*)lp_wgrad16_kernel<f16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, W16_LDS) == hipSuccess,
                         "lp_conv3d_wgrad: cannot raise the dynamic LDS limit");
             raised = true;
         }
-        CTU_DISPATCH_LP(dtype, (lp_wgrad16_kernel<T><<<dim3(gx16, pairs16), 256, W16_LDS, st>>>(p, tpb16)));
+        // (lazy BatchNorm backward: only the output-channel tile's FIRST input-channel tile forms and stores the raw-output
+        //  gradient -- every (ci tile, co tile) block of a co tile would write the same values)
+        CTU_DISPATCH_LP(dtype, {
+            if (lz) lp_wgrad16_kernel<T, true><<<dim3(gx16, pairs16), 256, W16_LDS, st>>>(p, tpb16);
+            else lp_wgrad16_kernel<T, false><<<dim3(gx16, pairs16), 256, W16_LDS, st>>>(p, tpb16);
+        });
         CTU_CHECK_LAUNCH("lp_conv3d_wgrad (16-channel tiles)");
         lp_wgrad_reduce_kernel<3, 1, 1><<<dim3(ceil_div(pairs16 * 27 * 256, 64)), 1024, 0, st>>>(ws, dw, Co, Ci, cinv, cin_p, cout_p, gx16);
         CTU_CHECK_LAUNCH("lp_conv3d_wgrad reduce");

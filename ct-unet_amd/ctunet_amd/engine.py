@@ -42,9 +42,10 @@ BN_MOMENTUM = 0.1
 # BatchNorm + ReLU backward applied by the weight-gradient kernel while it stages the gradient (ops.conv3d_wgrad_bn) instead
 # of a separate in-place pass over the layer (CTUNET_LAZY_BN=0: the separate ctu_bn_relu_bwd_apply pass)
 LAZY_BN = os.environ.get("CTUNET_LAZY_BN", "1") != "0"
-# ... on the 16-bit path too (ops.conv3d_wgrad_bn with 16-bit tensors).  Off by default: the 16-bit weight-gradient kernels are
-# bound by their staging instructions, and the folded transform costs them what the separate pass cost (UNet() 128^3 bf16:
-# 2.564 ms with it, 2.560 without)
+# ... on the 16-bit path too (ops.conv3d_wgrad_bn with 16-bit tensors; every 16-bit weight-gradient kernel has the LZ variant).
+# Off by default -- measured SLOWER at every size: the separate pass moves half the bytes it moves in fp32, while the folded
+# form adds a read of y and a write of the second gradient buffer to HBM-bound kernels (UNet() 128^3 bf16 2.31 ms with it, 2.24
+# without; UNetSP 192^3 bf16 5.92 vs 5.69; 256^3 fp16 11.96 vs 11.39)
 LAZY_BN_LP = os.environ.get("CTUNET_LAZY_BN_LP", "0") != "0"
 # the launch that writes a BatchNorm's partial rows also finalizes them (its last block: ctu_bn_tail / ctu_bn_bwd_tail)
 # instead of a separate ctu_bn_finalize / ctu_bn_bwd_finalize launch (CTUNET_BN_TAIL=0: the separate launches)

@@ -498,6 +498,8 @@ def test_lp_fused_upconv_forward_backward(name, c, co, dims, segs):
     (16, 8, (1, 4, 8, 16), 8, 0),
     (8, 16, (1, 8, 4, 32), 16, 0),
     (32, 16, (1, 4, 8, 16), 16, 0),         # two input-channel tiles share a gradient tile
+    (32, 14, (1, 8, 16, 64), 16, 0),        # 16-channel tiles on a box-multiple volume: lp_wgrad16_kernel<.., LZ>, two ci tiles
+    (16, 24, (2, 4, 8, 32), 32, 0),         # ... two co tiles (the second half empty), batch 2
 ])
 def test_lp_wgrad_with_lazy_batchnorm_backward(name, ci, co, dims, cs, c0):
     """ops.conv3d_wgrad_bn on 16-bit tensors (BatchNorm + ReLU backward in the weight-gradient kernel's staging, the raw-output
