@@ -1880,8 +1880,9 @@ __global__ __launch_bounds__(256, 1) void lp_wgrad16_kernel(LpWgP p, int tiles_p
         const int it = tid + u * 256, v = it < W16_HV * 2 ? (it >> 1) : 0;
         const int pw = v % 34, t2 = v / 34, ph = t2 % 10, pd = t2 / 10;
         xoff[u] = ((pd * p.H + ph) * p.W + pw) * p.x_cs;
+        // (bits 8..: the halo column -- the volume's last box along w may be partial, its items are checked against the row end)
         xface[u] = (pd == 0 ? 1u : 0u) | (pd == 5 ? 2u : 0u) | (ph == 0 ? 4u : 0u) | (ph == 9 ? 8u : 0u) |
-                   (pw == 0 ? 16u : 0u) | (pw == 33 ? 32u : 0u) | ((it < W16_HV * 2 && xlive) ? 0u : 64u);
+                   (pw == 0 ? 16u : 0u) | ((it < W16_HV * 2 && xlive) ? 0u : 64u) | ((unsigned)pw << 8);
     }
     const int gv0 = tid >> 1;                                                               // item u: voxel gv0 + 128 u = row 4 u + (gv0 >> 5)
     const int goff0 = (((gv0 >> 5) & 7) * p.W + (gv0 & 31)) * p.g_cs;                       // rows 4 u + (0..3): th = (4 u + r) & 7, td = u >> 1
@@ -1908,6 +1909,7 @@ __global__ __launch_bounds__(256, 1) void lp_wgrad16_kernel(LpWgP p, int tiles_p
     }
     u32x4 rx[W16_NX], rg[W16_NG], ry[LZ ? W16_NG : 1];
     unsigned okx = 0;
+    bool gok = false;                                               // the loaded box's gradient items lie inside the row
     int tile = blockIdx.x * tiles_per_block;
     const int tile_end = min(p.ntiles, tile + tiles_per_block);
     auto load_box = [&](int tl) {
@@ -1918,7 +1920,8 @@ __global__ __launch_bounds__(256, 1) void lp_wgrad16_kernel(LpWgP p, int tiles_p
         const int n = t / p.tiles_d;
         const int d0 = tz * 4, h0 = ty * 8, w0 = tx * 32;
         const unsigned bm = (d0 == 0 ? 1u : 0u) | (d0 + 4 == p.D ? 2u : 0u) | (h0 == 0 ? 4u : 0u) | (h0 + 8 == p.H ? 8u : 0u) |
-                            (w0 == 0 ? 16u : 0u) | (w0 + 32 == p.W ? 32u : 0u) | 64u;
+                            (w0 == 0 ? 16u : 0u) | 64u;
+        const unsigned wmax = (unsigned)(p.W - w0);                 // halo columns 0 .. wmax lie inside the row (33 = all)
         const long long xb = ((((long long)n * p.D + d0 - 1) * p.H + h0 - 1) * p.W + w0 - 1) * p.x_cs;
         okx = 0;
 #pragma unroll
@@ -1926,15 +1929,17 @@ __global__ __launch_bounds__(256, 1) void lp_wgrad16_kernel(LpWgP p, int tiles_p
             long long e = xb + xoff[u];
             e = e < 0 ? 0 : (e > xlim ? xlim : e);                  // any readable address: an outside item is zeroed at the LDS write
             rx[u] = *reinterpret_cast<const u32x4*>(x + e);
-            okx |= (xface[u] & bm) ? 0u : (1u << u);
+            okx |= ((xface[u] & 0x7fu & bm) || (xface[u] >> 8) > wmax) ? 0u : (1u << u);
         }
-        const T* gb = gr + ((((long long)n * p.D + d0) * p.H + h0) * p.W + w0) * p.g_cs;
+        gok = glive && (unsigned)(gv0 & 31) < wmax;                 // this thread's box column lies inside the row
+        // (a column beyond the row end reads the row's last voxel instead -- readable -- and is zeroed)
+        const T* gb = gr + ((((long long)n * p.D + d0) * p.H + h0) * p.W + w0) * p.g_cs - (gok || !glive ? 0 : ((gv0 & 31) - (int)wmax + 1) * p.g_cs);
 #pragma unroll
         for (int u = 0; u < W16_NG; ++u) {
             // row 4 u + r (r = gv0 >> 5): td = u >> 1, th = (u & 1) * 4 + r
             const T* src = gb + goff0 + (((u >> 1) * p.H + (u & 1) * 4) * p.W) * p.g_cs;
             const u32x4 r = *reinterpret_cast<const u32x4*>(src);
-            rg[u] = glive ? r : u32x4{0u, 0u, 0u, 0u};
+            rg[u] = gok ? r : u32x4{0u, 0u, 0u, 0u};
             if constexpr (LZ) ry[u] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(src) + lz_ydelta);
         }
     };
@@ -1966,7 +1971,7 @@ __global__ __launch_bounds__(256, 1) void lp_wgrad16_kernel(LpWgP p, int tiles_p
             *reinterpret_cast<u32x4*>(sX + it * 16) = r;
         }
         if constexpr (LZ) {
-            if (glive) {
+            if (gok) {                                              // (the registers hold box `tile`: gok is its flag)
                 int t = tile;
                 const int tx = t % p.tiles_w; t /= p.tiles_w;
                 const int ty = t % p.tiles_h; t /= p.tiles_h;
@@ -2034,7 +2039,7 @@ __global__ __launch_bounds__(256, 1) void lp_wgrad16_kernel(LpWgP p, int tiles_p
 }
 
 inline bool lp_wg16_ok(int D, int H, int W, int k, int cin_p, int cout_p) {
-    return k == 3 && cin_p >= 16 && cout_p >= 16 && D % 4 == 0 && H % 8 == 0 && W % 32 == 0;
+    return k == 3 && cin_p >= 16 && cout_p >= 16 && D % 4 == 0 && H % 8 == 0 && W >= 32 && W % 8 == 0;     // (last w box may be partial)
 }
 inline void lp_wg16_grid(int ntiles, int pairs, int* gx, int* tpb) {
     int g = 256 / pairs;
@@ -2559,7 +2564,7 @@ extern "C" size_t ctu_lp_conv3d_wgrad_ws_floats(int N, int D, int H, int W, int 
     if (lp_wg8_ok(D, H, W, k, cin_p, cout_p) && n < (size_t)512 * 9 * 256) n = (size_t)512 * 9 * 256;     // lp_wgrad8_kernel's slabs
     if (lp_wg16_ok(D, H, W, k, cin_p, cout_p)) {                                                         // lp_wgrad16_kernel's
         int gx16, tpb16;
-        lp_wg16_grid(N * (D / 4) * (H / 8) * (W / 32), pairs, &gx16, &tpb16);
+        lp_wg16_grid(N * (D / 4) * (H / 8) * ceil_div(W, 32), pairs, &gx16, &tpb16);
         const size_t n16 = (size_t)gx16 * pairs * 27 * 256;
         if (n < n16) n = n16;
     }
@@ -2628,7 +2633,7 @@ static int lp_conv3d_wgrad_impl(int dtype, const void* in, int in_cs, int cin_p,
     }
     if (LP_WG16 && lp_wg16_ok(D, H, W, k, cin_p, cout_p)) {
         p.N = N; p.D = D; p.H = H; p.W = W;
-        p.tiles_d = D / 4; p.tiles_h = H / 8; p.tiles_w = W / 32;
+        p.tiles_d = D / 4; p.tiles_h = H / 8; p.tiles_w = ceil_div(W, 32);
         p.ntiles = N * p.tiles_d * p.tiles_h * p.tiles_w;
         const int pairs16 = ((cin_p + 15) >> 4) * ((cout_p + 15) >> 4);
         int gx16, tpb16;

@@ -10,6 +10,8 @@ the slice, ``relu``): consumers see ``relu(raw * scale + shift)``.
 """
 from __future__ import annotations
 
+import os
+
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
@@ -165,6 +167,8 @@ class KernelTimer:
 
 
 TIMER: Optional[KernelTimer] = None      # set by bench.py; None in normal operation
+# 16-bit first-layer weight gradient: volumes with at least this many voxels go through the matrix pipe (conv_first_wgrad)
+FIRST_WGRAD_MFMA_MIN_VOX = int(os.environ.get("CTUNET_FIRST_WGRAD_MFMA_MIN_VOX", "4000000"))
 
 
 def _tile_tag(w: int) -> str:
@@ -509,6 +513,14 @@ def conv_first_bwd_data(g: CL, w: torch.Tensor, cin: int) -> torch.Tensor:
 def conv_first_wgrad(x: torch.Tensor, g: CL, co: int, ws: torch.Tensor) -> torch.Tensor:
     n, cin, d, h, w_ = x.shape
     lib = _lib.load()
+    if (g.lp and g.cp == 8 and n * d * h * w_ >= FIRST_WGRAD_MFMA_MIN_VOX
+            and lib.ctu_lp_conv3d_wgrad_kernel_name(d, h, w_, 3, 8, 8) == b"lp_wgrad8_kernel"):
+        # large 16-bit volumes: an 8-channel 16-bit copy of the input (one streaming pass) + the 8 -> 8 matrix-pipe weight
+        # gradient instead of the direct VALU kernel (192^3 x 2 channels: 223 -> 75 + 45 us; 256^3: 520 -> 196 + 100; no gain at
+        # 128^3 x 1, hence the threshold).  The input enters this product rounded to 16 bits, like every other layer's.
+        x8 = ncdhw_to_cl(x, 8, g.dtype)
+        need = lib.ctu_lp_conv3d_wgrad_ws_floats(n, d, h, w_, 3, 8, 8)
+        return conv3d_wgrad(x8, g, co, cin, 3, None, ws if ws.numel() >= need else torch.empty(need, device=x.device), False)[0]
     assert ws.numel() >= lib.ctu_conv3d_first_wgrad_ws_floats(n, d, h, w_, cin)
     dw = torch.empty((co, cin, 3, 3, 3), dtype=torch.float32, device=x.device)
     t0 = TIMER.begin() if TIMER is not None else None

@@ -59,6 +59,7 @@ CONV_CASES = [  # (k, ci, co, shape NDHW, transform)
     (3, 8, 5, (2, 8, 16, 64), False),
     # 16-channel tiles on box-multiple volumes: lp_wgrad16_kernel (interior + border boxes; half-empty last tiles; batch 2)
     (3, 16, 16, (1, 8, 16, 64), True), (3, 40, 24, (2, 4, 8, 32), True), (3, 32, 16, (1, 12, 24, 96), False),
+    (3, 16, 24, (2, 4, 8, 48), True), (3, 24, 16, (1, 8, 8, 40), False),       # ... partial last box along w (UNetSP's 48^3 level)
 ]
 
 
@@ -258,6 +259,14 @@ def test_lp_first_conv_and_head_against_fp32_kernels(name):
     ws = torch.empty(ops.conv_first_wgrad_ws((n, d, h, w), 2)).cuda()
     dw16, dw32 = ops.conv_first_wgrad(x, to_cl(go, 8, dt), 7, ws).cpu(), ops.conv_first_wgrad(x, to_cl(go, 8, torch.float32), 7, ws).cpu()
     assert torch.allclose(dw16, dw32, rtol=1e-5, atol=1e-5)
+    # large volumes take the matrix-pipe route (16-bit copy of the input + lp_wgrad8_kernel): forced here by the threshold
+    old_thr, ops.FIRST_WGRAD_MFMA_MIN_VOX = ops.FIRST_WGRAD_MFMA_MIN_VOX, 0
+    try:
+        dwm = ops.conv_first_wgrad(x, to_cl(go, 8, dt), 7, ws).cpu()
+    finally:
+        ops.FIRST_WGRAD_MFMA_MIN_VOX = old_thr
+    ref = torch.nn.grad.conv3d_weight(rnd(x.cpu(), dt).double(), (7, 2, 3, 3, 3), go.double(), padding=1)
+    assert (dwm.double() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
     dx16, dx32 = ops.conv_first_bwd_data(to_cl(go, 8, dt), wt, 2).cpu(), ops.conv_first_bwd_data(to_cl(go, 8, torch.float32), wt, 2).cpu()
     # (>= 32 wide: the matrix-pipe route, whose weight fragments are 16-bit like every other layer's)
     assert (dx16 - dx32).abs().max().item() <= 2 * ULP[name] * dx32.abs().max().item()

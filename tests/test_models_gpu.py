@@ -303,6 +303,7 @@ def oracle_train_check(name, size, batch=1, seed=1234, want_fp64=True, lowp=None
             if n_ != "dx":
                 dot, na, nb = dot + float(torch.dot(a, b)), na + float(a.norm()) ** 2, nb + float(b.norm()) ** 2
         versus_fp32.global_cos = dot / (na * nb) ** 0.5       # direction of the whole parameter-gradient vector
+        versus_fp32.rows = [(n_, a_, c_) for (a_, n_), (c_, _) in zip(l2, cos)]
         return max(l2), min(cos)
 
     net, outs, loss, dx = hip_step("fp32")
@@ -349,8 +350,15 @@ def oracle_train_check(name, size, batch=1, seed=1234, want_fp64=True, lowp=None
         # the agreement of two CORRECT implementations degrades with the voxel count -- measured here: worst tensor L2
         # 3.5e-2 / cos 0.9999 at 192^3, 0.22 / 0.982 at 256^3 (a 4-channel BatchNorm gamma); the fp64 rule above is the
         # tight gate and holds at 128^3
-        l2_gate, cos_gate = (6e-2, 0.998) if size <= 192 else (0.3, 0.97)
-        assert worst_l2[0] <= l2_gate and worst_cos[0] >= cos_gate, (worst_l2, worst_cos)
+        # Arbitrated once against fp64 (tests/arbitrate_fullsize.py -> profiles/r03_arbitrate_UNetSP_256.txt): at 256^3 the
+        # ATen-CPU fp32 oracle is the outlier on the FULL-RESOLUTION layers (sums of 1.7e7 terms: its BatchNorm gamma / beta
+        # gradients of d_blocks.0 and u_blocks.<last> are 6e-2 .. 1.6e-1 of scale off the fp64 value, cosine 0.995 .. 0.999,
+        # where this path is at 1e-4 .. 5e-3), every other tensor of both sides is within 1.6e-2.  So only the full-resolution
+        # blocks' tensors (and the head bias, 3.7e-2 on the ATen side) keep the loose gate; everything else is held to the 192^3 one.
+        top = ("d_blocks.0.", f"u_blocks.{len(getattr(net, 'u_blocks', ())) - 1}.", "last_conv.bias") if size > 192 else ()
+        bad = [(n_, a_, c_) for n_, a_, c_ in versus_fp32.rows
+               if ((a_ > 0.3 or c_ < 0.97) if (top and n_.startswith(top)) else (a_ > 6e-2 or c_ < 0.998))]
+        assert not bad, bad
     if lowp is None:
         return None
     del net
