@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void lp_convt_fwd_kernel(LpCtP p) {
     }
     const int n16 = (p.nout_p + 15) >> 4;
     const size_t fH = (size_t)2 * p.W, fD = fH * 2 * p.H;
-    for (int nt = 0; nt < n16; ++nt) {
+    for (int nt = blockIdx.y; nt < n16; nt += gridDim.y) {           // (small grids: one output tile per blockIdx.y)
         const int cb = nt * 16 + 4 * kg;
         float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
         if (p.bias) {
@@ -198,7 +198,9 @@ __global__ __launch_bounds__(256) void lp_convt_bwd_data_kernel(LpCtP p) {
     }
     const size_t fH = (size_t)2 * p.W, fD = fH * 2 * p.H;
     const int nch = p.rin_p >> 3, ksn = 2 * nch, n16 = (p.nout_p + 15) >> 4;
-    for (int nt0 = 0; nt0 < n16; nt0 += 2) {
+    // (small grids: the output-tile passes are spread over blockIdx.y -- 64 blocks x 4 passes of 32 dependent K-steps was one
+    //  54 us latency chain at 16^3 x 128 channels)
+    for (int nt0 = 2 * blockIdx.y; nt0 < n16; nt0 += 2 * gridDim.y) {
         f32x4 acc[CTV][2];
 #pragma unroll
         for (int ct = 0; ct < CTV; ++ct) { acc[ct][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[ct][1] = acc[ct][0]; }
@@ -477,7 +479,9 @@ extern "C" int ctu_lp_convt2_fwd(int dtype, const void* in, int in_cs, int rin_p
     const int ksn = (rin_p + 31) >> 5;
     hipStream_t st = (hipStream_t)stream;
     const bool wide = p.nvox > 65536;                  // 64 voxels per wave only where that still fills the chip
-    const unsigned grid = (unsigned)ceil_div64(p.nvox, wide ? 256 : 64);
+    const unsigned gx = (unsigned)ceil_div64(p.nvox, wide ? 256 : 64);
+    // deep levels: 64 blocks x 8 output tiles x 8 taps was one serial chain per wave -- one output tile per blockIdx.y there
+    const dim3 grid(gx, gx < 256 ? (unsigned)((nout_p + 15) >> 4) : 1u);
 #define CTU_CT_FWD(K)                                                                   \
     case K:                                                                             \
         if (wide) lp_convt_fwd_kernel<T, K, 4><<<grid, 256, 0, st>>>(p);                \
@@ -506,7 +510,9 @@ extern "C" int ctu_lp_convt2_bwd_data(int dtype, const void* gout, int g_cs, int
     p.in = gout; p.wp = wp; p.out = gin; p.in_cs = g_cs; p.rin_p = rout_p; p.out_cs = gin_cs; p.nout_p = nin_p;
     p.N = N; p.D = D; p.H = H; p.W = W; p.nvox = (int64_t)N * D * H * W;
     const bool wide = p.nvox > 65536;
-    const unsigned grid = (unsigned)ceil_div64(p.nvox, wide ? 256 : 64);
+    const unsigned gx = (unsigned)ceil_div64(p.nvox, wide ? 256 : 64);
+    const int passes = (((nin_p + 15) >> 4) + 1) >> 1;              // pairs of 16-wide output tiles
+    const dim3 grid(gx, (gx < 256 && passes > 1) ? passes : 1);
     CTU_DISPATCH_LP(dtype, {
         if (wide) lp_convt_bwd_data_kernel<T, 4><<<grid, 256, 0, (hipStream_t)stream>>>(p);
         else lp_convt_bwd_data_kernel<T, 1><<<grid, 256, 0, (hipStream_t)stream>>>(p);
