@@ -83,7 +83,8 @@ def pmc_traffic(kernel):
             doc = json.load(f)
         tag = kernel.split(" (")[0]
         dt = "bf16" if "<bf16" in tag else "f16" if "<f16" in tag else None
-        ks = doc.get("kernels" if dt is None else "kernels_" + dt, {})
+        # (the fp16 instantiations move the bytes of the bf16 ones: one 16-bit counter pass serves both)
+        ks = doc.get("kernels" if dt is None else "kernels_" + dt, None) or doc.get("kernels_bf16" if dt else "kernels", {})
         if tag in ks:
             return round(ks[tag]["hbm_bytes_per_launch"])
         base = tag.split("<")[0]

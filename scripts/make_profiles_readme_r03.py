@@ -38,9 +38,9 @@ dom = [float(r["AverageNs"]) / 1e3 for r in ks if "conv3d_fwd_k3_persist<1, true
 tr = json.load(open(R + "r03_hbm_traffic.json"))
 pk = tr["kernels"]["conv3d_fwd_k3_persist<1, true>"]
 kb, nb, totb, grpb = stats("r03_kernel_stats_bf16.csv")
-b_conv = grpb(lambda s: ("lp_conv" in s or "lp_wgrad" in s or "first_" in s) and "upconv" not in s)
-b_up = grpb(lambda s: "upconv" in s or "upwg" in s); b_ct = grpb(lambda s: "convt" in s)
-b_bn = grpb(lambda s: "bn_" in s or "channel_sum" in s); b_pool = grpb(lambda s: "maxpool" in s)
+b_conv = grpb(lambda s: ("lp_conv_" in s or "lp_wgrad" in s or "first_" in s) and "upconv" not in s and "pack" not in s)
+b_up = grpb(lambda s: ("upconv" in s or "upwg" in s) and "pack" not in s); b_ct = grpb(lambda s: "convt" in s and "pack" not in s)
+b_bn = grpb(lambda s: "bn_relu_bwd" in s or "bn_finalize" in s or "bn_bwd_finalize" in s or "channel_sum" in s); b_pool = grpb(lambda s: "maxpool" in s)
 b_head = grpb(lambda s: "head_" in s); b_loss = grpb(lambda s: "loss_" in s)
 b_rest = totb - b_conv - b_up - b_ct - b_bn - b_pool - b_head - b_loss
 
