@@ -3,10 +3,12 @@
 // (reference: nn.BatchNorm3d's batch statistics, running-stat update and backward sums; models.py:27-32).
 //
 // Hand-off between blocks of one launch (the per-XCD L2s are not coherent): every partial row is stored write-through
-// (sc1 = relaxed agent-scope atomic store), every storing wave drains its stores (s_waitcnt vmcnt(0)), the block's
-// barrier, then ONE lane draws a ticket with a relaxed agent-scope fetch_add; the block that draws the last ticket reads
-// the rows with sc1 loads (they bypass its L1) -- no fence, no L2 write-back.  The counter is one zero-initialised word per
-// layer; the last block puts it back to zero, so a replayed graph needs no memset node.
+// (sc1 = agent-scope atomic store), every storing wave drains its stores (s_waitcnt vmcnt(0)), the block's barrier, then ONE
+// lane draws a ticket with an agent-scope ACQ_REL fetch_add -- the release orders this block's row stores before the ticket,
+// the acquire in the block that draws the LAST ticket orders its row loads (sc1, past its L1) after every other block's
+// release: the happens-before chain the memory model asks for (round 2 used a relaxed ticket and relied on the waitcnt
+// alone).  The counter is one zero-initialised word per layer; the last block puts it back to zero, so a replayed
+// graph needs no memset node.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "ctunet_hip.h"
@@ -36,7 +38,7 @@ __device__ __forceinline__ bool tail_last_block(unsigned* counter, unsigned nblo
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned prev = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned prev = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         const int last = prev + 1u == nblocks_total;
         if (last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_tail_last = last;
