@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void lp_convt_wgrad_kernel(LpCtWgP p, int chun
     constexpr int SX = MT * 32, SG = NTL * 32;                      // LDS bytes per voxel of the X / G images
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* sXf = reinterpret_cast<float*>(smem);                    // [2][MT * 16]
-    unsigned char* sX = smem + 256;                                 // [128 voxels][MT * 16 ch]
+    unsigned char* sX = smem + 512;                                 // [128 voxels][MT * 16 ch]
     unsigned char* sG = sX + 128 * SX;                              // [8 taps][128 voxels][NTL * 16 ch]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, i = lane & 15, q = i >> 2, pc = i & 3;
     const int ncog = ((p.cout_p + 15) >> 4) / NTL + ((((p.cout_p + 15) >> 4) % NTL) ? 1 : 0);
@@ -546,9 +546,15 @@ extern "C" int ctu_lp_convt2_wgrad(int dtype, const void* in, int in_cs, int cin
     ctw_grid(p.nvox, pairs, &gx, &cpb);
     hipStream_t st = (hipStream_t)stream;
     // tile groups per block: 2 x 2 while the accumulators (8 taps x MT x NTL) and the gradient image fit
-    const int mt = nci >= 2 ? 2 : 1, ntl = nco >= 2 ? 2 : 1;
+#ifndef LP_CTW_MT4
+#define LP_CTW_MT4 1
+#endif
+    // 4 x 1 groups where there are at least four input-channel tiles: the gradient (8x the input's bytes) is then read ONCE per
+    // output-channel tile instead of once per pair of input-channel tiles, and a block's LDS image is 48 KB instead of 74
+    const bool mt4 = LP_CTW_MT4 && nci >= 4;
+    const int mt = mt4 ? 4 : (nci >= 2 ? 2 : 1), ntl = mt4 ? 1 : (nco >= 2 ? 2 : 1);
     const dim3 grid(gx, ceil_div(nci, mt) * ceil_div(nco, ntl));
-    const size_t lds = 256 + 128 * (size_t)mt * 32 + 8 * 128 * (size_t)ntl * 32;
+    const size_t lds = 512 + 128 * (size_t)mt * 32 + 8 * 128 * (size_t)ntl * 32;
     CTU_DISPATCH_LP(dtype, {
         if (mt == 2 && ntl == 2) {
             // the dynamic-LDS limit is raised only for launches that need more than the default 64 KB, and only to what they need
@@ -559,7 +565,8 @@ extern "C" int ctu_lp_convt2_wgrad(int dtype, const void* in, int in_cs, int cin
         raised = lds;
     }
             lp_convt_wgrad_kernel<T, 2, 2><<<grid, 256, lds, st>>>(p, cpb);
-        } else if (mt == 2) lp_convt_wgrad_kernel<T, 2, 1><<<grid, 256, lds, st>>>(p, cpb);
+        } else if (mt == 4) lp_convt_wgrad_kernel<T, 4, 1><<<grid, 256, lds, st>>>(p, cpb);
+        else if (mt == 2) lp_convt_wgrad_kernel<T, 2, 1><<<grid, 256, lds, st>>>(p, cpb);
         else if (ntl == 2) lp_convt_wgrad_kernel<T, 1, 2><<<grid, 256, lds, st>>>(p, cpb);
         else lp_convt_wgrad_kernel<T, 1, 1><<<grid, 256, lds, st>>>(p, cpb);
     });
