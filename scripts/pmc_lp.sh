@@ -21,7 +21,7 @@ for d in sorted(glob.glob("gpurun_out/pmc_lp_*_[AB]")):
     seen = set()
     for r in csv.DictReader(open(f[0])):
         k = r["Kernel_Name"]
-        if "lp_conv" not in k:
+        if "lp_conv" not in k and "lp_wgrad" not in k:
             continue
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         if (r["Dispatch_Id"], k) not in seen:
