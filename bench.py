@@ -158,7 +158,7 @@ def cpu_baseline(size, model="UNet", precision="fp32", mode="train", batch=1, st
     dices, rels = [], []
     for g_, r_ in zip(gots, refs):
         g_ = g_.cpu()
-        a_, b_ = g_.argmax(1) == 1, r_.argmax(1) == 1
+        a_, b_ = O.argmax1(g_) == 1, O.argmax1(r_) == 1
         tot = int(a_.sum()) + int(b_.sum())
         dices.append(2.0 * int((a_ & b_).sum()) / tot if tot else 1.0)
         rels.append(float((g_ - r_).abs().max() / r_.abs().max()))

@@ -296,7 +296,7 @@ def test_lp_first_conv_and_head_against_fp32_kernels(name):
 # -------------------------------------------------------------------------------------------------------- whole nets
 def _metrics(outs, refs, loss, ref_loss, grads, ref_g, dx, ref_dx):
     res = {"out_err": max(rel_err(o, r) for o, r in zip(outs, refs)),
-           "dice": min(float(O.hard_dice(o.detach().float().cpu(), F.one_hot(r.argmax(1), r.shape[1]).movedim(-1, 1).float()))
+           "dice": min(float(O.hard_dice(o.detach().float().cpu(), F.one_hot(O.argmax1(r), r.shape[1]).movedim(-1, 1).float()))
                        for o, r in zip(outs, refs)),
            "loss_err": abs(float(loss) - float(ref_loss))}
     cos, l2 = [], []

@@ -187,7 +187,7 @@ def test_shipped_classes_vs_reference_checksums_and_oracle(name):
         assert close_summary(summarize(o), e, 1e-4, 1e-6)
         assert rel_err(o, r) < 1e-4
         # hard segmentation agreement ("Dice vs CPU ref")
-        assert O.hard_dice(o.cpu(), torch.nn.functional.one_hot(r.argmax(1), r.shape[1]).movedim(-1, 1).float()) >= 0.999
+        assert O.hard_dice(o.cpu(), torch.nn.functional.one_hot(O.argmax1(r), r.shape[1]).movedim(-1, 1).float()) >= 0.999
     # logits (pre-activation) are the sensitive quantity at default init: check through the oracle
     lg_ref = O.forward(spec, sd0, x, training=False, return_logits=True)
     net.train()
@@ -309,7 +309,7 @@ def oracle_train_check(name, size, batch=1, seed=1234, want_fp64=True, lowp=None
     net, outs, loss, dx = hip_step("fp32")
     for o, r in zip(outs, refs):
         assert rel_err(o, r) < 1e-4
-        assert O.hard_dice(o.cpu(), torch.nn.functional.one_hot(r.argmax(1), r.shape[1]).movedim(-1, 1).float()) >= 0.999
+        assert O.hard_dice(o.cpu(), torch.nn.functional.one_hot(O.argmax1(r), r.shape[1]).movedim(-1, 1).float()) >= 0.999
     assert abs(loss - l32.item()) < 1e-5
     worst_l2, worst_cos = versus_fp32(net, dx)
     print(f"[{name} {size}^3 fp32] grad L2 err max {worst_l2}, cos min {worst_cos}")
@@ -365,7 +365,7 @@ def oracle_train_check(name, size, batch=1, seed=1234, want_fp64=True, lowp=None
     m, outs, loss_lp, dx = hip_step(lowp)
     l2, cos = versus_fp32(m, dx)
     res = {"out_err": max(rel_err(o, r) for o, r in zip(outs, refs)),
-           "dice": min(float(O.hard_dice(o.cpu(), torch.nn.functional.one_hot(r.argmax(1), r.shape[1]).movedim(-1, 1).float()))
+           "dice": min(float(O.hard_dice(o.cpu(), torch.nn.functional.one_hot(O.argmax1(r), r.shape[1]).movedim(-1, 1).float()))
                        for o, r in zip(outs, refs)),
            "loss_err": abs(loss_lp - l32.item()), "loss": l32.item(), "grad_l2_max": l2, "grad_cos_min": cos,
            "grad_cos_global": versus_fp32.global_cos}
