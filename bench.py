@@ -398,6 +398,8 @@ def main():
                                           "16-bit activations / activation gradients in HBM and LDS, v_mfma_f32_16x16x32 with fp32 accumulation; "
                                           "fp32 BatchNorm statistics, master weights, weight gradients and optimizer state; every kernel of "
                                           "the step reads and writes the 16-bit tensors directly (no fp32 copies)"),
+                       # peak device memory of this process over warm-up + timed steps (allocator high-water mark, all pools)
+                       "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 1e9, 3),
                        "whole_step_tflops_algorithmic": round(flop_vox * value / 1e12, 2),
                        "whole_step_frac_of_mfma_peak": round(flop_vox * value / world / 1e12 /
                                                              (PEAK_16BIT_MFMA_TFLOPS if lowp else PEAK_FP32_MFMA_TFLOPS), 4),
