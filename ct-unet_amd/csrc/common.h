@@ -7,7 +7,7 @@
 
 #include "ctunet_hip.h"
 
-#define CTU_ABI_VERSION 6
+#define CTU_ABI_VERSION 7
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

@@ -174,7 +174,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 6          # CTU_ABI_VERSION of the csrc/ this file mirrors (bumped on any signature change)
+ABI_VERSION = 7          # CTU_ABI_VERSION of the csrc/ this file mirrors (bumped on any signature change)
 
 
 class CtuError(RuntimeError):
