@@ -1842,7 +1842,8 @@ __global__ __launch_bounds__(256, 2) void lp_wgrad8_kernel(LpWgP p, int tiles_pe
 // the plain 16 x 16 tile (27 accumulators, one (ci tile, co tile) pair per blockIdx.y).  One d plane per wave: its 8 gradient
 // fragments stay in registers, every input halo row is read once per (kd, kw) -- 9 fragments -- and used by the 3 kh taps that
 // meet it (196 fragment reads per 216 MFMAs; lp_conv_wgrad_kernel: 448); box 4 x 8 x 32 (halo 2.0x), one block per CU with the
-// next box's loads in flight in registers; face-code border handling.  16 -> 16 at 128^3: 133 -> ?? us.
+// next box's loads in flight in registers; face-code border handling; the last box along w may be partial (any W >= 32 that is a
+// multiple of 8).  16 -> 16 at 128^3: 139 -> 71 us, 64 -> 16 at 64^3: 107 -> 47 us.
 constexpr int W16_HV = 6 * 10 * 34, W16_NX = (W16_HV * 2 + 255) / 256, W16_NG = 8;
 constexpr int W16_LDS = 128 + (W16_HV + 1024) * 32;
 
